@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py -- rays/s of the GazeNeRF volumetric hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode fwd|fwdbwd] [--side S]
+
+A "step" is one pass of the hot path (both MLP streams) over one batch of synthetic input:
+the 512x512-ray, 64-samples-per-ray render BASELINE.json quotes the metric on (SURVEY.md 8(d)
+cfg2b: featmap_size=512 -> 262 144 rays), inputs resident in HBM before the timed region.
+``--mode fwdbwd`` adds the backward pass (ray micro-batches of ``--micro`` rays, gradients
+accumulated, then all-reduced over RCCL when N>1).  With N>1 every rank renders its own image
+(images are sharded, no data-path collective in forward): weak scaling.
+
+Prints ONE JSON line on rank 0 with the driver's fields plus
+  roofline     -- the fused MLP kernel against the gfx950 fp32-MFMA peak (157.3 TFLOP/s):
+                  algorithmic FLOPs per launch / HIP-event duration of that kernel alone;
+  cpu_baseline -- the CPU oracle (oracle/oracle.py, a port of the reference's PyTorch path, pinned
+                  to it by tests/golden) timed on this host's cores on a bounded ray sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_SAMPLE_STREAM = 2 * 1351680          # folded count, fwd
+PEAK_FP32_MFMA_TFLOPS = 157.3                 # MI355X_MICROARCH.md chip-level parameters
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mode", choices=("fwd", "fwdbwd"), default=os.environ.get("GNR_BENCH_MODE", "fwdbwd"))
+    ap.add_argument("--side", type=int, default=512, help="rays per image = side^2")
+    ap.add_argument("--samples", type=int, default=64)
+    ap.add_argument("--micro", type=int, default=16384, help="rays per backward micro-batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=512)
+    return ap.parse_args()
+
+
+def cpu_baseline(mode, n_rays, n_samples):
+    """The oracle on this host's cores, bounded sample (SURVEY.md 8(d) CPU-baseline plan (ii))."""
+    from gazenerf_amd import synth
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sub = (torch.arange(n_rays) * 8) % 4096
+    p = synth.synth_problem(64, batch=1, seed=5, ray_subset=sub)
+    face = synth.hash_mlp_params("face", seed=0, density_scale=50.0)
+    eyes = synth.hash_mlp_params("eyes", seed=0, density_scale=50.0)
+    t_rand = synth.synth_jitter(1, n_rays, n_samples, seed=5) if mode == "fwdbwd" else None
+
+    def one():
+        if mode == "fwd":
+            with torch.no_grad():
+                O.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"],
+                                    p["appea_code"], face, eyes, n_samples)
+        else:
+            fp = {k: v.clone().requires_grad_(True) for k, v in face.items()}
+            ep = {k: v.clone().requires_grad_(True) for k, v in eyes.items()}
+            leaves = {k: p[k].clone().requires_grad_(True) for k in ("R", "T", "shape_code", "gaze", "appea_code")}
+            out = O.render_two_stream(p["xy"], leaves["R"], leaves["T"], p["Kinv"], leaves["shape_code"],
+                                      leaves["gaze"], leaves["appea_code"], fp, ep, n_samples, t_rand=t_rand)
+            O.synthetic_loss(out).backward()
+
+    one()                                   # warm-up
+    times = []
+    t_all = time.time()
+    while len(times) < 3 or (time.time() - t_all < 10.0 and len(times) < 20):
+        t0 = time.time()
+        one()
+        times.append(time.time() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": n_rays / med, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d rays x %d samples, both streams, %s, median of %d runs (%.2f s each), "
+                      "PyTorch-CPU oracle pinned to the reference by tests/golden"
+                      % (n_rays, n_samples, mode, len(times), med)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the render op)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from gazenerf_amd import render, synth
+    from gazenerf_amd.hiptime import KernelTimer
+    from gazenerf_amd.parallel import GradAllReducer
+
+    side, n_p = args.side, args.samples
+    n_rays = side * side
+    to = lambda d: {k: v.to(dev) for k, v in d.items()}
+    p = to(synth.synth_problem(side, batch=1, camera=str(3 + rank), seed=100 + rank))
+    face = to(synth.hash_mlp_params("face", seed=0, density_scale=50.0))
+    eyes = to(synth.hash_mlp_params("eyes", seed=0, density_scale=50.0))
+    plist = [face[k] for k in render.PARAM_ORDER] + [eyes[k] for k in render.PARAM_ORDER]
+    leaves = [p[k] for k in ("R", "T", "shape_code", "gaze", "appea_code")]
+    micro = min(args.micro, n_rays)
+    t_rand = synth.synth_jitter(1, micro, n_p, seed=7).to(dev) if args.mode == "fwdbwd" else None
+    reducer = GradAllReducer(plist, world) if (args.mode == "fwdbwd") else None
+    timer = KernelTimer()
+    kernel_ms = []
+
+    def step(timed):
+        if args.mode == "fwd":
+            with torch.no_grad():
+                with timer:
+                    render.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"],
+                                             p["appea_code"], face, eyes, n_samples=n_p)
+                if timed:
+                    kernel_ms.append(timer.elapsed_ms())
+            return
+        for t in plist + leaves:
+            t.requires_grad_(True)
+            t.grad = None
+        for r0 in range(0, n_rays, micro):
+            xy = p["xy"][:, :, r0:r0 + micro].contiguous()
+            with timer:
+                out = render.render_two_stream(xy, p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"],
+                                               p["appea_code"], face, eyes, n_samples=n_p,
+                                               t_rand=t_rand[:, :xy.shape[2]])
+            if timed:
+                kernel_ms.append(timer.elapsed_ms())
+            loss = sum((out["feat_" + t] ** 2).mean() + out["bg_alpha_" + t].mean() for t in ("face", "eyes"))
+            loss.backward()
+        reducer.all_reduce()
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * n_rays * args.steps / dt
+        # dominant kernel: the fused MLP forward kernel; one launch covers `rays_per_launch` rays
+        rays_per_launch = n_rays if args.mode == "fwd" else micro
+        flop_per_launch = rays_per_launch * n_p * 2 * FLOP_PER_SAMPLE_STREAM
+        avg_ms = sum(kernel_ms) / max(1, len(kernel_ms))
+        achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        res = {
+            "metric": "rays/sec (512x512, 64 samples/ray) %s" % ("fwd+bwd" if args.mode == "fwdbwd" else "fwd"),
+            "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg2b: %dx%d rays x %d samples/ray, two streams (face+eyes), %s, "
+                                   "1 image per GPU%s" % (side, side, n_p, args.mode,
+                                                          ", %d-ray micro-batches" % micro if args.mode == "fwdbwd" else ""),
+                       "rays_per_step_per_gpu": n_rays, "samples_per_ray": n_p,
+                       "parallelism": "dp%d (images sharded)" % world},
+            "roofline": {"bound": "mfma", "kernel": "gnr::fwd_kernel", "achieved": achieved,
+                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "flop_per_launch": flop_per_launch, "avg_launch_ms": avg_ms,
+                         "launches_timed": len(kernel_ms)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.mode, args.cpu_rays, n_p)
+        print(json.dumps(res), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

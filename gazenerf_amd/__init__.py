@@ -1,0 +1,11 @@
+"""gazenerf_amd -- MI355X-native volumetric renderer for GazeNeRF's hot path.
+
+Public surface:
+    render_two_stream, importance_resample, sample_zvals   (gazenerf_amd.render)
+    HotPathRenderer, MLPParams                             (gazenerf_amd.module)
+    synth                                                  synthetic input recipe
+    build.build()                                          compile libgnr.so for gfx950
+"""
+from . import synth  # noqa: F401
+from .render import importance_resample, render_two_stream, sample_zvals  # noqa: F401
+from .module import HotPathRenderer, MLPParams  # noqa: F401

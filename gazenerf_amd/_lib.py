@@ -1,0 +1,99 @@
+"""ctypes binding of libgnr.so -- mirrors include/gnr.h field for field.
+
+There is no CPU or PyTorch fallback: if the HIP library is missing this module raises, loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgnr.so")
+
+N_TRUNK = 8
+N_RGB = 3
+WS_FWD, WS_FWD_SAVE, WS_BWD = 0, 1, 2
+ABI_VERSION = 1
+
+_p = C.c_void_p
+
+
+class GnrProblem(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("n_rays", C.c_int32), ("n_samples", C.c_int32),
+                ("hidden", C.c_int32), ("feat_nc", C.c_int32), ("shape_dims", C.c_int32),
+                ("gaze_dims", C.c_int32), ("appea_dims", C.c_int32),
+                ("world_z1", C.c_float), ("world_z2", C.c_float),
+                ("xy", _p), ("R", _p), ("T", _p), ("Kinv", _p),
+                ("shape_code", _p), ("gaze", _p), ("appea_code", _p),
+                ("t_rand", _p), ("z_edges", _p)]
+
+
+class GnrWeights(C.Structure):
+    _fields_ = [("fea_w", _p * N_TRUNK), ("fea_b", _p * N_TRUNK),
+                ("density_w", _p), ("density_b", _p),
+                ("rgb_w", _p * N_RGB), ("rgb_b", _p * N_RGB)]
+
+
+GnrWeightGrads = GnrWeights      # identical layout (include/gnr.h)
+
+
+class GnrOutputs(C.Structure):
+    _fields_ = [("feat", _p * 2), ("bg_alpha", _p * 2), ("depth", _p * 2), ("weights", _p * 2)]
+
+
+class GnrOutputGrads(C.Structure):
+    _fields_ = [("feat", _p * 2), ("bg_alpha", _p * 2)]
+
+
+class GnrInputGrads(C.Structure):
+    _fields_ = [("R", _p), ("T", _p), ("shape_code", _p), ("gaze", _p), ("appea_code", _p)]
+
+
+EXPORTS = ("gnr_abi_version", "gnr_workspace_bytes", "gnr_fwd", "gnr_bwd", "gnr_resample",
+           "gnr_sample_zvals", "gnr_set_kernel_timing", "gnr_last_error")
+
+_lib = None
+
+
+class GnrError(RuntimeError):
+    """Raised when a libgnr entry point returns non-zero (message from gnr_last_error)."""
+
+
+def load():
+    """dlopen libgnr.so (once).  Raises if it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "gazenerf_amd: %s is missing. Build it with `python -m gazenerf_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for the render op." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.gnr_abi_version.restype = C.c_int
+    lib.gnr_last_error.restype = C.c_char_p
+    lib.gnr_workspace_bytes.restype = C.c_size_t
+    lib.gnr_workspace_bytes.argtypes = [C.POINTER(GnrProblem), C.c_int, C.c_int]
+    lib.gnr_fwd.restype = C.c_int
+    lib.gnr_fwd.argtypes = [C.POINTER(GnrProblem), C.POINTER(GnrWeights), C.POINTER(GnrWeights),
+                            C.POINTER(GnrOutputs), C.c_int, _p, C.c_size_t, _p]
+    lib.gnr_bwd.restype = C.c_int
+    lib.gnr_bwd.argtypes = [C.POINTER(GnrProblem), C.POINTER(GnrWeights), C.POINTER(GnrWeights),
+                            C.POINTER(GnrOutputGrads), C.POINTER(GnrInputGrads),
+                            C.POINTER(GnrWeightGrads), C.POINTER(GnrWeightGrads),
+                            _p, C.c_size_t, _p, C.c_size_t, _p]
+    lib.gnr_resample.restype = C.c_int
+    lib.gnr_resample.argtypes = [_p, _p, _p, C.c_int64, C.c_int32, C.c_int32, _p, _p]
+    lib.gnr_sample_zvals.restype = C.c_int
+    lib.gnr_sample_zvals.argtypes = [C.POINTER(GnrProblem), _p, _p]
+    lib.gnr_set_kernel_timing.restype = C.c_int
+    lib.gnr_set_kernel_timing.argtypes = [_p, _p]
+    if lib.gnr_abi_version() != ABI_VERSION:
+        raise RuntimeError("libgnr.so ABI %d != binding ABI %d; rebuild" % (lib.gnr_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc: int, lib=None):
+    if rc != 0:
+        lib = lib or load()
+        raise GnrError(lib.gnr_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,202 @@
+// gnr_api.hip -- the C ABI of libgnr.so (include/gnr.h): validation, workspace carving, launches.
+// No torch types, no allocation, no global state besides the thread-local error string.
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "gnr_internal.h"
+
+namespace gnr {
+void launch_zvals(const GnrProblem& p, float* out, hipStream_t stream);
+void launch_resample(const float* w, const float* cz, const float* u, long n_rays, int nc, int nf,
+                     float* zout, hipStream_t stream);
+int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, const GnrOutputGrads* dout,
+            const GnrInputGrads* din, const GnrWeightGrads* const* dw, void* saved, size_t saved_bytes,
+            void* scratch, size_t scratch_bytes, hipStream_t stream);
+size_t bwd_scratch_bytes(const GnrProblem* p, int n_streams);
+
+static thread_local std::string g_err;
+thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+
+int fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+int check_problem(const GnrProblem* p, int n_streams) {
+    if (!p) return fail("gnr: problem is NULL");
+    if (n_streams < 1 || n_streams > 2) return fail("gnr: n_streams must be 1 or 2 (got %d)", n_streams);
+    if (p->hidden != H) return fail("gnr: this build supports hidden=%d only (got %d)", H, p->hidden);
+    if (p->feat_nc < 1 || p->feat_nc > FEAT_PAD) return fail("gnr: feat_nc must be in [1,%d] (got %d)", FEAT_PAD, p->feat_nc);
+    if (p->batch < 1 || p->n_rays < 1) return fail("gnr: empty problem (batch=%d n_rays=%d)", p->batch, p->n_rays);
+    if (p->n_samples < 2) return fail("gnr: n_samples must be >= 2 (got %d)", p->n_samples);
+    if ((p->n_samples + CHUNK - 1) / CHUNK > 16) return fail("gnr: n_samples must be <= 512 (got %d)", p->n_samples);
+    if (p->shape_dims < 0 || p->gaze_dims < 0 || p->appea_dims < 0) return fail("gnr: negative latent dims");
+    if (!p->xy || !p->R || !p->T || !p->Kinv) return fail("gnr: xy/R/T/Kinv must be non-NULL");
+    if ((p->shape_dims && !p->shape_code) || (p->gaze_dims && !p->gaze) || (p->appea_dims && !p->appea_code))
+        return fail("gnr: latent code pointer is NULL");
+    return 0;
+}
+
+static int check_weights(const GnrWeights* w, const char* tag) {
+    if (!w) return fail("gnr: %s weights are NULL", tag);
+    for (int i = 0; i < GNR_N_TRUNK; ++i)
+        if (!w->fea_w[i] || !w->fea_b[i]) return fail("gnr: %s FeaExt_module_%d is NULL", tag, i);
+    if (!w->density_w || !w->density_b) return fail("gnr: %s density_module is NULL", tag);
+    for (int i = 0; i < GNR_N_RGB; ++i)
+        if (!w->rgb_w[i] || !w->rgb_b[i]) return fail("gnr: %s RGB_layer_%d is NULL", tag, i);
+    return 0;
+}
+
+// Carve the forward workspace.  base == nullptr only sizes it.
+size_t carve_fwd(const GnrProblem* p, int n_streams, bool save, char* base, FwdParams* fp) {
+    const int cpr = (p->n_samples + CHUNK - 1) / CHUNK;
+    const size_t n_chunks = (size_t)p->batch * p->n_rays * cpr;
+    const size_t M = n_chunks * CHUNK;
+    size_t off = 0;
+    auto take = [&](size_t floats) {
+        float* ptr = base ? (float*)(base + off) : nullptr;
+        off += align_up(floats * sizeof(float));
+        return ptr;
+    };
+    if (fp) {
+        fp->prob = *p;
+        fp->n_streams = n_streams;
+        fp->chunks_per_ray = cpr;
+        fp->n_chunks = (long)n_chunks;
+        fp->M = (long)M;
+        fp->save = save ? 1 : 0;
+    }
+    for (int s = 0; s < n_streams; ++s) {
+        StreamWs w{};
+        w.packed = take(PACKED_FLOATS);
+        w.bias = take((size_t)N_CHAIN * p->batch * H);
+        w.wsig = take(H + 4);
+        w.part_feat = take(n_chunks * FEAT_PAD);
+        w.part_sc = take(n_chunks * 4);
+        w.wl = take(M);
+        if (save) {
+            w.act_h = take((size_t)8 * M * H);
+            w.act_y0 = take(M * H);
+            w.act_y1 = take(M * H2);
+            w.act_feat = take(M * FEAT_PAD);
+            w.sigma_raw = take(M);
+        }
+        if (fp) fp->ws[s] = w;
+    }
+    float* zval = take(M);
+    float* enc = nullptr; float* delta = nullptr; float* pts = nullptr;
+    if (save) { enc = take(M * ENC_PAD); delta = take(M); pts = take(M * 4); }
+    if (fp) { fp->zval = zval; fp->enc = enc; fp->delta = delta; fp->pts = pts; }
+    return off;
+}
+
+}  // namespace gnr
+
+using namespace gnr;
+
+extern "C" {
+
+int gnr_abi_version(void) { return GNR_ABI_VERSION; }
+
+const char* gnr_last_error(void) { return g_err.c_str(); }
+
+int gnr_set_kernel_timing(void* ev_start, void* ev_stop) {
+    g_ev_start = (hipEvent_t)ev_start;
+    g_ev_stop = (hipEvent_t)ev_stop;
+    return 0;
+}
+
+size_t gnr_workspace_bytes(const GnrProblem* p, int n_streams, int kind) {
+    if (check_problem(p, n_streams)) return 0;
+    switch (kind) {
+        case GNR_WS_FWD: return carve_fwd(p, n_streams, false, nullptr, nullptr);
+        case GNR_WS_FWD_SAVE: return carve_fwd(p, n_streams, true, nullptr, nullptr);
+        case GNR_WS_BWD: return bwd_scratch_bytes(p, n_streams);
+        default: fail("gnr: unknown workspace kind %d", kind); return 0;
+    }
+}
+
+int gnr_fwd(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes, const GnrOutputs* out,
+            int save_for_backward, void* workspace, size_t ws_bytes, void* stream) {
+    const int n_streams = eyes ? 2 : 1;
+    if (check_problem(p, n_streams)) return 1;
+    if (check_weights(face, "first-stream")) return 1;
+    if (eyes && check_weights(eyes, "second-stream")) return 1;
+    if (!out) return fail("gnr_fwd: outputs are NULL");
+    for (int s = 0; s < n_streams; ++s)
+        if (!out->feat[s] || !out->bg_alpha[s]) return fail("gnr_fwd: feat/bg_alpha output %d is NULL", s);
+    const bool save = save_for_backward != 0;
+    const size_t need = carve_fwd(p, n_streams, save, nullptr, nullptr);
+    if (!workspace || ws_bytes < need) return fail("gnr_fwd: workspace too small (%zu < %zu bytes)", ws_bytes, need);
+    if (((uintptr_t)workspace & 255) != 0) return fail("gnr_fwd: workspace must be 256-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+
+    FwdParams fp{};
+    carve_fwd(p, n_streams, save, (char*)workspace, &fp);
+    fp.want_wl = (out->weights[0] || (n_streams > 1 && out->weights[1])) ? 1 : 0;
+    const GnrWeights* ws_in[2] = {face, eyes};
+    launch_prep(*p, n_streams, ws_in, fp.ws, st);
+    if (g_ev_start) hipEventRecord(g_ev_start, st);
+    launch_fwd(fp, st);
+    if (g_ev_stop) hipEventRecord(g_ev_stop, st);
+
+    CombineParams cp{};
+    cp.prob = *p;
+    cp.n_streams = n_streams;
+    cp.chunks_per_ray = fp.chunks_per_ray;
+    for (int s = 0; s < n_streams; ++s) {
+        cp.part_feat[s] = fp.ws[s].part_feat;
+        cp.part_sc[s] = fp.ws[s].part_sc;
+        cp.wl[s] = fp.ws[s].wl;
+    }
+    cp.out = *out;
+    launch_combine(cp, st);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("gnr_fwd: launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int gnr_bwd(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes, const GnrOutputGrads* dout,
+            const GnrInputGrads* din, const GnrWeightGrads* dface, const GnrWeightGrads* deyes,
+            void* saved_workspace, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream) {
+    const int n_streams = eyes ? 2 : 1;
+    if (check_problem(p, n_streams)) return 1;
+    if (check_weights(face, "first-stream")) return 1;
+    if (eyes && check_weights(eyes, "second-stream")) return 1;
+    if (!dout) return fail("gnr_bwd: output gradients are NULL");
+    const GnrWeights* w[2] = {face, eyes};
+    const GnrWeightGrads* dw[2] = {dface, deyes};
+    return run_bwd(p, n_streams, w, dout, din, dw, saved_workspace, saved_bytes, scratch, scratch_bytes,
+                   (hipStream_t)stream);
+}
+
+int gnr_resample(const float* weights, const float* coarse_z, const float* u, int64_t n_rays_total,
+                 int32_t n_coarse, int32_t n_fine, float* z_out, void* stream) {
+    if (!weights || !coarse_z || !z_out) return fail("gnr_resample: NULL pointer");
+    if (n_rays_total < 1) return fail("gnr_resample: no rays");
+    if (n_coarse < 3 || n_fine < 1) return fail("gnr_resample: need n_coarse >= 3 and n_fine >= 1");
+    if (n_coarse + n_fine + 1 > 512) return fail("gnr_resample: n_coarse + n_fine + 1 must be <= 512");
+    launch_resample(weights, coarse_z, u, (long)n_rays_total, n_coarse, n_fine, z_out, (hipStream_t)stream);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("gnr_resample: launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int gnr_sample_zvals(const GnrProblem* p, float* zvals_out, void* stream) {
+    if (check_problem(p, 1)) return 1;
+    if (!zvals_out) return fail("gnr_sample_zvals: output is NULL");
+    launch_zvals(*p, zvals_out, (hipStream_t)stream);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("gnr_sample_zvals: launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+"""nn.Module surface of the hot path with the reference's parameter names.
+
+``HotPathRenderer`` owns ``fg_CD_predictor_face`` / ``fg_CD_predictor_eyes`` (and optionally
+``fine_fg_CD_predictor``) whose parameters are named and shaped exactly like the reference's
+``MLPforNeRF`` (models/mlp_nerf.py:29-93: ``FeaExt_module_{0..7}``, ``density_module``,
+``RGB_layer_{0,1,2}``, Conv2d weights ``[out,in,1,1]``), so
+``renderer.load_state_dict(check_dict["net"], strict=False)`` fills them from a reference
+checkpoint (trainer/gazenerf_trainer.py:116,173).  The arithmetic is libgnr's; these modules
+only hold parameters.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import render as R_
+from . import synth
+
+
+class MLPParams(nn.Module):
+    """Parameter container mirroring MLPforNeRF (models/mlp_nerf.py:13-93), same init rules."""
+
+    def __init__(self, vp_channels: int, vd_channels: int, n_layers: int = 8, h_channel: int = 384,
+                 res_nfeat: int = 258):
+        super().__init__()
+        self.vp_channels, self.vd_channels = vp_channels, vd_channels
+        self.n_layers, self.h_channel, self.res_nfeat = n_layers, h_channel, res_nfeat
+        skips = [n_layers // 2]
+        self.add_module("FeaExt_module_0", nn.Conv2d(vp_channels, h_channel, 1))
+        for i in range(n_layers - 1):
+            cin = h_channel + vp_channels if i in skips else h_channel
+            m = nn.Conv2d(cin, h_channel, 1)
+            nn.init.xavier_uniform_(m.weight.data)
+            self.add_module("FeaExt_module_%d" % (i + 1), m)
+        m = nn.Conv2d(h_channel, 1, 1)
+        nn.init.xavier_uniform_(m.weight.data)
+        m.bias.data[:] = 0.0
+        self.add_module("density_module", m)
+        m = nn.Conv2d(h_channel, h_channel, 1)
+        nn.init.xavier_uniform_(m.weight.data)
+        self.add_module("RGB_layer_0", m)
+        self.add_module("RGB_layer_1", nn.Conv2d(h_channel + vd_channels, h_channel // 2, 1))
+        self.add_module("RGB_layer_2", nn.Conv2d(h_channel // 2, res_nfeat, 1))
+
+    def param_list(self):
+        sd = dict(self.named_parameters())
+        return [sd[k] for k in R_.PARAM_ORDER]
+
+    def forward(self, *a, **k):
+        raise RuntimeError("MLPParams only holds parameters; evaluate it through HotPathRenderer")
+
+
+class HotPathRenderer(nn.Module):
+    """GazeNeRF's two-stream volumetric renderer (the hot span of GazeNeRFNet._forward).
+
+    forward(batch_xy, batch_Rmats, batch_Tvecs, batch_inv_inmats, shape_code, appea_code, gaze_code,
+            for_train=False, t_rand=None) -> dict(feat_face, bg_alpha_face, feat_eyes, bg_alpha_eyes, ...)
+
+    ``for_train=True`` applies the stratified jitter of utils/model_utils.py:302-307; pass ``t_rand``
+    to pin the draw, otherwise one is drawn with ``torch.rand`` on the device.
+    With ``hier_sampling=True`` the intended fine pass runs as well:
+    FineSample on the face weights -> third MLP over 64+128 samples -> "feat_fine"/"bg_alpha_fine".
+    """
+
+    def __init__(self, num_sample_coarse: int = 64, num_sample_fine: int = 128, world_z1: float = 2.5,
+                 world_z2: float = -3.5, hidden: int = 384, featmap_nc: int = 258,
+                 shape_dims: int = synth.SHAPE_DIMS, gaze_dims: int = synth.GAZE_DIMS,
+                 appea_dims: int = synth.APPEA_DIMS, hier_sampling: bool = False):
+        super().__init__()
+        self.num_sample_coarse, self.num_sample_fine = num_sample_coarse, num_sample_fine
+        self.world_z1, self.world_z2 = world_z1, world_z2
+        self.hidden, self.featmap_nc = hidden, featmap_nc
+        self.hier_sampling = hier_sampling
+        vp = 63 + shape_dims + gaze_dims
+        self.fg_CD_predictor_eyes = MLPParams(vp, appea_dims, h_channel=hidden, res_nfeat=featmap_nc)
+        self.fg_CD_predictor_face = MLPParams(vp, appea_dims, h_channel=hidden, res_nfeat=featmap_nc)
+        if hier_sampling:
+            self.fine_fg_CD_predictor = MLPParams(vp, appea_dims, h_channel=hidden, res_nfeat=featmap_nc)
+
+    def forward(self, batch_xy, batch_Rmats, batch_Tvecs, batch_inv_inmats, shape_code, appea_code,
+                gaze_code, for_train: bool = False, t_rand: Optional[torch.Tensor] = None,
+                u_fine: Optional[torch.Tensor] = None, return_weights: bool = False):
+        B, _, n_r = batch_xy.shape
+        n_p = self.num_sample_coarse
+        if for_train and t_rand is None:
+            t_rand = torch.rand(B, n_r, n_p + 1, device=batch_xy.device)
+        want_w = return_weights or self.hier_sampling
+        out = R_.render_two_stream(
+            batch_xy, batch_Rmats, batch_Tvecs, batch_inv_inmats, shape_code, gaze_code, appea_code,
+            self.fg_CD_predictor_face.param_list(), self.fg_CD_predictor_eyes.param_list(),
+            n_samples=n_p, world_z1=self.world_z1, world_z2=self.world_z2, t_rand=t_rand,
+            return_weights=want_w, hidden=self.hidden, feat_nc=self.featmap_nc)
+        if self.hier_sampling:
+            zv = R_.sample_zvals(batch_xy, batch_Rmats.detach(), batch_Tvecs.detach(), batch_inv_inmats,
+                                 n_samples=n_p, world_z1=self.world_z1, world_z2=self.world_z2, t_rand=t_rand)
+            if for_train and u_fine is None:
+                u_fine = torch.rand(B * n_r, self.num_sample_fine + 1, device=batch_xy.device)
+            edges = R_.importance_resample(out["w_face"], zv, n_fine=self.num_sample_fine, u=u_fine)
+            fine = R_.render_two_stream(
+                batch_xy, batch_Rmats, batch_Tvecs, batch_inv_inmats, shape_code, gaze_code, appea_code,
+                self.fine_fg_CD_predictor.param_list(), None,
+                n_samples=n_p + self.num_sample_fine, world_z1=self.world_z1, world_z2=self.world_z2,
+                z_edges=edges, hidden=self.hidden, feat_nc=self.featmap_nc)
+            out["feat_fine"], out["bg_alpha_fine"] = fine["feat_face"], fine["bg_alpha_face"]
+            out["fine_edges"] = edges
+        return out

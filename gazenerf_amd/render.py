@@ -1,0 +1,323 @@
+"""The render op: GazeNeRF's volumetric hot path on MI355X, behind libgnr.so.
+
+``render_two_stream`` replaces the span of the reference from ``self.sample_func(...)``
+(models/gaze_nerf.py:231) through the two ``self.calc_color_func(...)`` calls
+(models/gaze_nerf.py:157-162): GenSamplePoints -> Embedder -> latent concat ->
+MLPforNeRF (face, eyes) -> CalcRayColor.  Argument meaning follows the reference:
+
+    batch_xy [B,2,N_r]  R [B,3,3] c2w  T [B,3,1]  Kinv [B,3,3]
+    shape_code [B,179]  gaze [B,2]  appea_code [B,127]
+    face_params / eyes_params: the 24 tensors of one MLPforNeRF each, in ``PARAM_ORDER``
+      (weights in Conv2d layout [out,in,1,1] or [out,in])
+    t_rand None == reference ``disturb=False`` ("test"); a [B,N_r,N_p+1] tensor == "train" with
+      exactly that stratified jitter (replaces torch.rand_like, utils/model_utils.py:306)
+
+Gradients flow to R, T, shape_code, gaze, appea_code and all 48 parameter tensors through a
+``torch.autograd.Function`` whose forward/backward are single calls into the C ABI.
+PyTorch here is plumbing: it owns the device buffers and the stream.  All inputs must be CUDA
+(ROCm) float32 tensors; anything else raises -- there is no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from . import _lib
+
+PARAM_ORDER = tuple(
+    ["FeaExt_module_%d.%s" % (i, k) for i in range(8) for k in ("weight", "bias")]
+    + ["density_module.weight", "density_module.bias"]
+    + ["RGB_layer_%d.%s" % (i, k) for i in range(3) for k in ("weight", "bias")])
+N_PARAMS = len(PARAM_ORDER)   # 24
+
+
+def params_to_list(params) -> list:
+    """Accept a dict/state-dict (reference key names) or a 24-sequence in PARAM_ORDER."""
+    if isinstance(params, dict):
+        return [params[k] for k in PARAM_ORDER]
+    params = list(params)
+    if len(params) != N_PARAMS:
+        raise ValueError("expected %d parameter tensors, got %d" % (N_PARAMS, len(params)))
+    return params
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _check_tensor(name, t, shape=None):
+    if not torch.is_tensor(t):
+        raise TypeError("%s must be a tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on a CUDA/ROCm device (the render op has no CPU path)" % name)
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32, got %s" % (name, t.dtype))
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError("%s must have shape %s, got %s" % (name, tuple(shape), tuple(t.shape)))
+
+
+def _weights_struct(plist: Sequence[torch.Tensor], cls=_lib.GnrWeights):
+    w = cls()
+    for i in range(8):
+        w.fea_w[i] = plist[2 * i].data_ptr() if plist[2 * i] is not None else None
+        w.fea_b[i] = plist[2 * i + 1].data_ptr() if plist[2 * i + 1] is not None else None
+    w.density_w = plist[16].data_ptr() if plist[16] is not None else None
+    w.density_b = plist[17].data_ptr() if plist[17] is not None else None
+    for i in range(3):
+        w.rgb_w[i] = plist[18 + 2 * i].data_ptr() if plist[18 + 2 * i] is not None else None
+        w.rgb_b[i] = plist[19 + 2 * i].data_ptr() if plist[19 + 2 * i] is not None else None
+    return w
+
+
+def _expected_param_shapes(hidden, vp, appea, feat_nc):
+    shapes = [(hidden, vp), (hidden,)]
+    for i in range(1, 8):
+        shapes += [(hidden, hidden + vp if i == 5 else hidden), (hidden,)]
+    shapes += [(1, hidden), (1,)]
+    shapes += [(hidden, hidden), (hidden,), (hidden // 2, hidden + appea), (hidden // 2,),
+               (feat_nc, hidden // 2), (feat_nc,)]
+    return shapes
+
+
+def _prep_params(plist, hidden, vp, appea, feat_nc, tag):
+    out = []
+    for name, t, shp in zip(PARAM_ORDER, plist, _expected_param_shapes(hidden, vp, appea, feat_nc)):
+        _check_tensor("%s.%s" % (tag, name), t)
+        if t.dim() == 4:                       # Conv2d [out,in,1,1] == row-major [out,in]
+            if t.shape[2:] != (1, 1):
+                raise ValueError("%s.%s: only 1x1 kernels" % (tag, name))
+            t = t.reshape(t.shape[0], t.shape[1])
+        if tuple(t.shape) != shp:
+            raise ValueError("%s.%s must have shape %s, got %s" % (tag, name, shp, tuple(t.shape)))
+        out.append(t.contiguous())
+    return out
+
+
+class _Problem:
+    """Validated, contiguous inputs + the ctypes GnrProblem that points at them."""
+
+    def __init__(self, xy, R, T, Kinv, shape_code, gaze, appea_code, n_samples, world_z1, world_z2,
+                 t_rand, z_edges, hidden, feat_nc):
+        _check_tensor("batch_xy", xy)
+        if xy.dim() != 3 or xy.shape[1] != 2:
+            raise ValueError("batch_xy must be [B,2,N_r], got %s" % (tuple(xy.shape),))
+        B, _, n_r = xy.shape
+        _check_tensor("R", R, (B, 3, 3))
+        _check_tensor("T", T, (B, 3, 1))
+        _check_tensor("Kinv", Kinv, (B, 3, 3))
+        _check_tensor("shape_code", shape_code)
+        _check_tensor("gaze", gaze)
+        _check_tensor("appea_code", appea_code)
+        if shape_code.shape[0] != B or gaze.shape[0] != B or appea_code.shape[0] != B:
+            raise ValueError("latent codes must have batch %d" % B)
+        if t_rand is not None:
+            _check_tensor("t_rand", t_rand, (B, n_r, n_samples + 1))
+        if z_edges is not None:
+            _check_tensor("z_edges", z_edges, (B, n_r, n_samples + 1))
+        self.tensors = [t.contiguous() if t is not None else None
+                        for t in (xy, R, T, Kinv, shape_code, gaze, appea_code, t_rand, z_edges)]
+        xy, R, T, Kinv, shape_code, gaze, appea_code, t_rand, z_edges = self.tensors
+        p = _lib.GnrProblem()
+        p.batch, p.n_rays, p.n_samples = B, n_r, int(n_samples)
+        p.hidden, p.feat_nc = int(hidden), int(feat_nc)
+        p.shape_dims, p.gaze_dims, p.appea_dims = shape_code.shape[1], gaze.shape[1], appea_code.shape[1]
+        p.world_z1, p.world_z2 = float(world_z1), float(world_z2)
+        p.xy, p.R, p.T, p.Kinv = xy.data_ptr(), R.data_ptr(), T.data_ptr(), Kinv.data_ptr()
+        p.shape_code, p.gaze, p.appea_code = shape_code.data_ptr(), gaze.data_ptr(), appea_code.data_ptr()
+        p.t_rand = t_rand.data_ptr() if t_rand is not None else None
+        p.z_edges = z_edges.data_ptr() if z_edges is not None else None
+        self.c = p
+        self.B, self.n_r, self.n_p = B, n_r, int(n_samples)
+        self.device = xy.device
+        self.vp = 63 + p.shape_dims + p.gaze_dims
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _alloc_ws(nbytes, device):
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
+def _run_forward(prob: _Problem, streams, save: bool, want_depth: bool, want_weights: bool):
+    lib = _lib.load()
+    dev = prob.device
+    n_streams = len(streams)
+    feat_nc = prob.c.feat_nc
+    kind = _lib.WS_FWD_SAVE if save else _lib.WS_FWD
+    with torch.cuda.device(dev):
+        nbytes = lib.gnr_workspace_bytes(C.byref(prob.c), n_streams, kind)
+        if nbytes == 0:
+            _lib.check(1, lib)
+        ws = _alloc_ws(nbytes, dev)
+        outs = _lib.GnrOutputs()
+        res = []
+        for s in range(n_streams):
+            feat = torch.empty(prob.B, feat_nc, prob.n_r, device=dev, dtype=torch.float32)
+            bga = torch.empty(prob.B, 1, prob.n_r, device=dev, dtype=torch.float32)
+            dep = torch.empty(prob.B, 1, prob.n_r, device=dev, dtype=torch.float32) if want_depth else None
+            wts = (torch.empty(prob.B, 1, prob.n_r, prob.n_p, device=dev, dtype=torch.float32)
+                   if want_weights else None)
+            outs.feat[s], outs.bg_alpha[s] = feat.data_ptr(), bga.data_ptr()
+            outs.depth[s] = dep.data_ptr() if dep is not None else None
+            outs.weights[s] = wts.data_ptr() if wts is not None else None
+            res.append((feat, bga, dep, wts))
+        w0 = _weights_struct(streams[0])
+        w1 = _weights_struct(streams[1]) if n_streams > 1 else None
+        rc = lib.gnr_fwd(C.byref(prob.c), C.byref(w0), C.byref(w1) if w1 is not None else None,
+                         C.byref(outs), 1 if save else 0, C.c_void_p(ws.data_ptr()), ws.numel(),
+                         _stream_ptr(dev))
+        _lib.check(rc, lib)
+    return res, ws
+
+
+class _RenderFn(torch.autograd.Function):
+    """forward = gnr_fwd, backward = gnr_bwd.  Inputs: 5 differentiable problem tensors, then
+    24 * n_streams parameter tensors; non-differentiable context travels in ``cfg``."""
+
+    @staticmethod
+    def forward(ctx, cfg, R, T, shape_code, gaze, appea_code, *flat_params):
+        n_streams = cfg["n_streams"]
+        prob = _Problem(cfg["xy"], R, T, cfg["Kinv"], shape_code, gaze, appea_code, cfg["n_samples"],
+                        cfg["world_z1"], cfg["world_z2"], cfg["t_rand"], cfg["z_edges"],
+                        cfg["hidden"], cfg["feat_nc"])
+        streams = [_prep_params(flat_params[24 * s:24 * (s + 1)], cfg["hidden"], prob.vp,
+                                prob.c.appea_dims, cfg["feat_nc"], "stream%d" % s)
+                   for s in range(n_streams)]
+        need_grad = any(ctx.needs_input_grad[1:])
+        res, ws = _run_forward(prob, streams, need_grad, cfg["want_depth"], cfg["want_weights"])
+        ctx.cfg, ctx.prob, ctx.streams = cfg, prob, streams
+        ctx.saved_ws = ws if need_grad else None
+        ctx.param_shapes = [tuple(t.shape) for t in flat_params]
+        outs = []
+        nondiff = []
+        for feat, bga, dep, wts in res:
+            outs += [feat, bga]
+            for extra in (dep, wts):
+                if extra is not None:
+                    outs.append(extra)
+                    nondiff.append(extra)
+        ctx.mark_non_differentiable(*nondiff)
+        ctx.out_layout = [(dep is not None, wts is not None) for _, _, dep, wts in res]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lib = _lib.load()
+        prob, streams, cfg = ctx.prob, ctx.streams, ctx.cfg
+        if ctx.saved_ws is None:
+            raise RuntimeError("render_two_stream: backward called but forward saved nothing")
+        dev = prob.device
+        n_streams = len(streams)
+        dout = _lib.GnrOutputGrads()
+        keep = []
+        gi = 0
+        for s, (has_d, has_w) in enumerate(ctx.out_layout):
+            gf, ga = grads[gi], grads[gi + 1]
+            gi += 2 + int(has_d) + int(has_w)
+            for g, field in ((gf, dout.feat), (ga, dout.bg_alpha)):
+                if g is not None:
+                    g = g.contiguous().float()
+                    keep.append(g)
+                    field[s] = g.data_ptr()
+                else:
+                    field[s] = None
+        B = prob.B
+        gR = torch.empty(B, 3, 3, device=dev)
+        gT = torch.empty(B, 3, 1, device=dev)
+        gshape = torch.empty(B, prob.c.shape_dims, device=dev)
+        ggaze = torch.empty(B, prob.c.gaze_dims, device=dev)
+        gappea = torch.empty(B, prob.c.appea_dims, device=dev)
+        din = _lib.GnrInputGrads()
+        din.R, din.T = gR.data_ptr(), gT.data_ptr()
+        din.shape_code, din.gaze, din.appea_code = gshape.data_ptr(), ggaze.data_ptr(), gappea.data_ptr()
+        gparams = [[torch.empty_like(t) for t in streams[s]] for s in range(n_streams)]
+        dw = [_weights_struct(g, _lib.GnrWeightGrads) for g in gparams]
+        w = [_weights_struct(st) for st in streams]
+        with torch.cuda.device(dev):
+            nbytes = lib.gnr_workspace_bytes(C.byref(prob.c), n_streams, _lib.WS_BWD)
+            scratch = _alloc_ws(max(nbytes, 256), dev)
+            rc = lib.gnr_bwd(C.byref(prob.c), C.byref(w[0]), C.byref(w[1]) if n_streams > 1 else None,
+                             C.byref(dout), C.byref(din), C.byref(dw[0]),
+                             C.byref(dw[1]) if n_streams > 1 else None,
+                             C.c_void_p(ctx.saved_ws.data_ptr()), ctx.saved_ws.numel(),
+                             C.c_void_p(scratch.data_ptr()), scratch.numel(), _stream_ptr(dev))
+            _lib.check(rc, lib)
+        ctx.saved_ws = None
+        flat = []
+        for s in range(n_streams):
+            for g, shp in zip(gparams[s], ctx.param_shapes[24 * s:24 * (s + 1)]):
+                flat.append(g.reshape(shp))
+        return (None, gR, gT, gshape, ggaze, gappea, *flat)
+
+
+def render_two_stream(batch_xy, R, T, Kinv, shape_code, gaze, appea_code, face_params, eyes_params=None,
+                      *, n_samples: int, world_z1: float = 2.5, world_z2: float = -3.5,
+                      t_rand: Optional[torch.Tensor] = None, z_edges: Optional[torch.Tensor] = None,
+                      return_depth: bool = False, return_weights: bool = False,
+                      hidden: int = 384, feat_nc: int = 258):
+    """Run the hot path.  Returns a dict with feat_face [B,feat_nc,N_r], bg_alpha_face [B,1,N_r]
+    (and *_eyes when ``eyes_params`` is given; depth_* / w_* [B,1,N_r,N_p] on request).
+
+    ``eyes_params=None`` evaluates a single MLP -- the hierarchical fine pass with the third
+    network (models/gaze_nerf.py:102-108); its results come back under the "face" keys.
+    """
+    streams = [params_to_list(face_params)]
+    if eyes_params is not None:
+        streams.append(params_to_list(eyes_params))
+    cfg = dict(xy=batch_xy, Kinv=Kinv, n_samples=int(n_samples), world_z1=world_z1, world_z2=world_z2,
+               t_rand=t_rand, z_edges=z_edges, hidden=hidden, feat_nc=feat_nc, n_streams=len(streams),
+               want_depth=return_depth, want_weights=return_weights)
+    flat = [t for st in streams for t in st]
+    outs = _RenderFn.apply(cfg, R, T, shape_code, gaze, appea_code, *flat)
+    res: Dict[str, torch.Tensor] = {}
+    it = iter(outs)
+    for tag in ("face", "eyes")[:len(streams)]:
+        res["feat_" + tag] = next(it)
+        res["bg_alpha_" + tag] = next(it)
+        if return_depth:
+            res["depth_" + tag] = next(it)
+        if return_weights:
+            res["w_" + tag] = next(it)
+    return res
+
+
+def sample_zvals(batch_xy, R, T, Kinv, *, n_samples: int, world_z1: float = 2.5, world_z2: float = -3.5,
+                 t_rand=None, z_edges=None):
+    """Left sample edges [B,1,N_r,N_p] -- ``fg_sample_dict["zvals"]`` (utils/model_utils.py:312-313)."""
+    lib = _lib.load()
+    B = batch_xy.shape[0]
+    dummy = torch.zeros(B, 1, device=batch_xy.device)
+    prob = _Problem(batch_xy, R, T, Kinv, dummy, dummy, dummy, n_samples, world_z1, world_z2, t_rand,
+                    z_edges, 384, 258)
+    out = torch.empty(B, 1, prob.n_r, prob.n_p, device=prob.device)
+    with torch.cuda.device(prob.device):
+        _lib.check(lib.gnr_sample_zvals(C.byref(prob.c), C.c_void_p(out.data_ptr()), _stream_ptr(prob.device)), lib)
+    return out
+
+
+def importance_resample(w_face, zvals, *, n_fine: int, u: Optional[torch.Tensor] = None):
+    """FineSample.forward (utils/model_utils.py:413-490): coarse weights [B,1,N_r,N_c] + coarse left
+    edges [B,1,N_r,N_c] -> sorted merged edges [B,N_r,N_c+n_fine+1], to be passed back as
+    ``z_edges`` with ``n_samples = N_c + n_fine``.  ``u`` [B*N_r, n_fine+1] replaces torch.rand
+    (``disturb=True``); None == the deterministic linspace of ``disturb=False``.  No gradient
+    (the reference detaches the weights, model_utils.py:418)."""
+    lib = _lib.load()
+    w = w_face.detach()
+    _check_tensor("w_face", w)
+    _check_tensor("zvals", zvals, tuple(w.shape))
+    B, _, n_r, nc = w.shape
+    w = w.contiguous()
+    z = zvals.detach().contiguous()
+    if u is not None:
+        _check_tensor("u", u, (B * n_r, n_fine + 1))
+        u = u.contiguous()
+    out = torch.empty(B, n_r, nc + n_fine + 1, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = lib.gnr_resample(C.c_void_p(w.data_ptr()), C.c_void_p(z.data_ptr()), _ptr(u), B * n_r, nc,
+                              int(n_fine), C.c_void_p(out.data_ptr()), _stream_ptr(w.device))
+        _lib.check(rc, lib)
+    return out

@@ -1,0 +1,168 @@
+/*
+ * gnr.h -- C ABI of libgnr.so, the MI355X (gfx950) volumetric renderer for GazeNeRF.
+ *
+ * This is the drop-in boundary for ONE hot path of the reference:
+ * everything between `self.sample_func(...)` (models/gaze_nerf.py:231) and the two
+ * `self.calc_color_func(...)` calls (models/gaze_nerf.py:157-162):
+ *
+ *     GenSamplePoints.forward      utils/model_utils.py:364-375   ray dirs + plane-sweep samples
+ *     Embedder.forward             utils/model_utils.py:272-280   positional encoding
+ *     latent concat                models/gaze_nerf.py:136-143, 248-262
+ *     MLPforNeRF.forward (x2)      models/mlp_nerf.py:95-119      face + eyes streams
+ *     CalcRayColor.forward (x2)    utils/model_utils.py:516-534   alpha compositing
+ *     FineSample.forward           utils/model_utils.py:413-490   importance resampling
+ *
+ * The reference has no FFI layer of its own (it is pure Python/PyTorch); the entry points below
+ * are what a ctypes / pybind stub inside GazeNeRFNet.calc_color_with_code would bind
+ * (INTEGRATION.md shows that stub).  Plain pointers and sizes only: no torch types.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 unless stated; tensors are contiguous, row-major,
+ *     in the reference's own layouts (channels-first outputs [B, C, N_r]);
+ *   - the caller owns every buffer, including the workspace; the library allocates nothing and
+ *     keeps no state between calls (safe for several modules / devices per process);
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no host synchronisation;
+ *   - every function returns 0 on success, non-zero on error; gnr_last_error() then describes it
+ *     (thread-local).  Bindings turn that into an exception so the reference's
+ *     `try: ... except: continue` around a batch (trainer/gazenerf_trainer.py:576-582) keeps working.
+ */
+#ifndef GNR_H_
+#define GNR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNR_ABI_VERSION 1
+#define GNR_N_TRUNK 8          /* FeaExt_module_0..7   (models/mlp_nerf.py:29-58)  */
+#define GNR_N_RGB 3            /* RGB_layer_0..2       (models/mlp_nerf.py:68-93)  */
+
+/* One call of the hot path: B images x N_r rays x N_p samples.
+ * Replaces the argument list of GenSamplePoints.forward (utils/model_utils.py:364) plus the
+ * latent codes GazeNeRFNet._forward receives (models/gaze_nerf.py:211-224). */
+typedef struct GnrProblem {
+    int32_t batch;          /* B                                                              */
+    int32_t n_rays;         /* N_r per image                                                  */
+    int32_t n_samples;      /* N_p per ray  (opt.num_sample_coarse, or 192 for the fine pass) */
+    int32_t hidden;         /* opt.mlp_hidden_nchannels; this build supports 384              */
+    int32_t feat_nc;        /* opt.featmap_nc; this build supports <= 288 (reference: 258)    */
+    int32_t shape_dims;     /* 179 = iden + expr (configs/gazenerf_options.py:17)             */
+    int32_t gaze_dims;      /* 2                                                              */
+    int32_t appea_dims;     /* 127                                                            */
+    float   world_z1;       /* 2.5   (configs/gazenerf_options.py:24)                         */
+    float   world_z2;       /* -3.5                                                           */
+    const float* xy;          /* [B,2,N_r]  pixel grid (utils/render_utils.py:24-32)          */
+    const float* R;           /* [B,3,3]    cam-to-world rotation                             */
+    const float* T;           /* [B,3,1]    camera centre                                     */
+    const float* Kinv;        /* [B,3,3]    inverse intrinsics at feature-map scale           */
+    const float* shape_code;  /* [B,shape_dims]                                               */
+    const float* gaze;        /* [B,gaze_dims]                                                */
+    const float* appea_code;  /* [B,appea_dims]                                               */
+    const float* t_rand;      /* [B,N_r,N_p+1] stratified jitter in [0,1) (model_utils.py:306),
+                                 or NULL == reference `disturb=False`                         */
+    const float* z_edges;     /* [B,N_r,N_p+1] explicit sample edges (the sorted z of
+                                 FineSample, model_utils.py:476-481) or NULL == plane sweep    */
+} GnrProblem;
+
+/* Parameters of one MLPforNeRF (models/mlp_nerf.py:13-93).  weight = Conv2d [out,in,1,1] memory
+ * == row-major [out,in]; bias [out].  Shapes for hidden H, vp = 63+shape_dims+gaze_dims:
+ *   fea_w[0] [H,vp]  fea_w[1..4,6,7] [H,H]  fea_w[5] [H,vp+H]  density_w [1,H]
+ *   rgb_w[0] [H,H]   rgb_w[1] [H/2,H+appea_dims]   rgb_w[2] [feat_nc,H/2]                     */
+typedef struct GnrWeights {
+    const float* fea_w[GNR_N_TRUNK];
+    const float* fea_b[GNR_N_TRUNK];
+    const float* density_w;
+    const float* density_b;
+    const float* rgb_w[GNR_N_RGB];
+    const float* rgb_b[GNR_N_RGB];
+} GnrWeights;
+
+/* Same shapes, gradients (written, not accumulated).  Any pointer may be NULL == not wanted. */
+typedef struct GnrWeightGrads {
+    float* fea_w[GNR_N_TRUNK];
+    float* fea_b[GNR_N_TRUNK];
+    float* density_w;
+    float* density_b;
+    float* rgb_w[GNR_N_RGB];
+    float* rgb_b[GNR_N_RGB];
+} GnrWeightGrads;
+
+/* Results of CalcRayColor.forward (utils/model_utils.py:516-534) per stream
+ * (index 0 = first weight set / "face", 1 = second / "eyes").  depth / weights may be NULL. */
+typedef struct GnrOutputs {
+    float* feat[2];        /* [B,feat_nc,N_r]                                       */
+    float* bg_alpha[2];    /* [B,1,N_r]                                             */
+    float* depth[2];       /* [B,1,N_r]      or NULL                                */
+    float* weights[2];     /* [B,1,N_r,N_p]  or NULL (face weights feed FineSample) */
+} GnrOutputs;
+
+/* Upstream gradients of the four outputs the caller consumes (NULL == zero). */
+typedef struct GnrOutputGrads {
+    const float* feat[2];      /* [B,feat_nc,N_r] */
+    const float* bg_alpha[2];  /* [B,1,N_r]       */
+} GnrOutputGrads;
+
+/* Gradients w.r.t. the problem's differentiable inputs (written; NULL == not wanted).
+ * No gradient is produced for xy, Kinv, t_rand or z_edges. */
+typedef struct GnrInputGrads {
+    float* R;            /* [B,3,3] */
+    float* T;            /* [B,3,1] */
+    float* shape_code;   /* [B,shape_dims] */
+    float* gaze;         /* [B,gaze_dims]  */
+    float* appea_code;   /* [B,appea_dims] */
+} GnrInputGrads;
+
+enum {
+    GNR_WS_FWD = 0,        /* scratch for an inference forward                                   */
+    GNR_WS_FWD_SAVE = 1,   /* scratch + saved activations for a later gnr_bwd (training forward) */
+    GNR_WS_BWD = 2         /* scratch for gnr_bwd (in addition to the saved forward workspace)   */
+};
+
+int gnr_abi_version(void);
+
+/* Bytes of workspace `kind` needs for problem `p` with `n_streams` (1 or 2) weight sets. */
+size_t gnr_workspace_bytes(const GnrProblem* p, int n_streams, int kind);
+
+/* Forward: samples -> encoding -> MLP(s) -> compositing.  `eyes` may be NULL (single stream: the
+ * hierarchical fine pass with the third MLP, models/gaze_nerf.py:102-108).
+ * save_for_backward != 0 keeps per-layer activations in `workspace` (size GNR_WS_FWD_SAVE);
+ * that buffer must then reach gnr_bwd untouched. */
+int gnr_fwd(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes,
+            const GnrOutputs* out, int save_for_backward,
+            void* workspace, size_t ws_bytes, void* stream);
+
+/* Backward of gnr_fwd for the same problem and weights. */
+int gnr_bwd(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes,
+            const GnrOutputGrads* dout,
+            const GnrInputGrads* din, const GnrWeightGrads* dface, const GnrWeightGrads* deyes,
+            void* saved_workspace, size_t saved_bytes,
+            void* scratch, size_t scratch_bytes, void* stream);
+
+/* FineSample.forward (utils/model_utils.py:413-490): inverse-CDF resampling of the coarse
+ * weights.  weights [n_rays_total, n_coarse], coarse_z [n_rays_total, n_coarse] (left edges),
+ * u [n_rays_total, n_fine+1] uniform draws or NULL == linspace(0,1,n_fine+1) (`disturb=False`).
+ * Writes the sorted merged edges z_out [n_rays_total, n_coarse + n_fine + 1]; feed them back
+ * through GnrProblem.z_edges with n_samples = n_coarse + n_fine. */
+int gnr_resample(const float* weights, const float* coarse_z, const float* u,
+                 int64_t n_rays_total, int32_t n_coarse, int32_t n_fine,
+                 float* z_out, void* stream);
+
+/* Left sample edges of the plane sweep, [B,N_r,N_p] -- the `zvals` FineSample needs
+ * (utils/model_utils.py:312-313).  Honours p->t_rand / p->z_edges. */
+int gnr_sample_zvals(const GnrProblem* p, float* zvals_out, void* stream);
+
+/* Measurement hook: subsequent gnr_fwd / gnr_bwd calls made by THIS thread record the two
+ * hipEvent_t (passed as void*) on their stream immediately before / after the dominant kernel of
+ * the call (the fused MLP kernel in gnr_fwd; the dgrad-chain kernel in gnr_bwd), so a harness can
+ * time that kernel alone.  Pass NULLs to switch it off (the default). */
+int gnr_set_kernel_timing(void* ev_start, void* ev_stop);
+
+const char* gnr_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNR_H_ */

@@ -21,13 +21,9 @@ import torch.nn.functional as F
 
 
 # --------------------------------------------------------------------------- A1
-def gen_sample_points(xy, R, T, Kinv, n_samples, world_z1=2.5, world_z2=-3.5, t_rand=None):
-    """utils/model_utils.py:364-375 (forward), 332-362, 291-330.
-
-    xy [B,2,N_r]; R [B,3,3] cam-to-world; T [B,3,1]; Kinv [B,3,3].
-    ``t_rand`` [B,N_r,n_samples+1] replaces ``torch.rand_like`` (model_utils.py:306);
-    ``None`` is the reference's ``disturb=False``.
-    """
+def sample_edges(xy, R, T, Kinv, n_samples, world_z1=2.5, world_z2=-3.5, t_rand=None):
+    """Ray geometry + the N_p+1 sample edges (before the edge->sample rule), model_utils.py:364-372,
+    339-357, 302-307.  Returns (edges [B,N_r,N_p+1], ray_o, ray_d, ray_l as [B,C,N_r,1])."""
     xyz = F.pad(xy, [0, 0, 0, 1, 0, 0], mode="constant", value=1.0)          # :365
     ray_d = R.bmm(Kinv.bmm(xyz))                                              # :366
     ray_l = torch.norm(ray_d, dim=1, keepdim=True)                            # :367
@@ -49,7 +45,21 @@ def gen_sample_points(xy, R, T, Kinv, n_samples, world_z1=2.5, world_z2=-3.5, t_
         upper = torch.cat([mids, zvals[:, :, -1:]], dim=-1)
         lower = torch.cat([zvals[:, :, :1], mids], dim=-1)
         zvals = lower + (upper - lower) * t_rand
+    return zvals, ray_o, ray_d, ray_l
 
+
+def gen_sample_points(xy, R, T, Kinv, n_samples, world_z1=2.5, world_z2=-3.5, t_rand=None,
+                      z_edges=None):
+    """utils/model_utils.py:364-375 (forward), 332-362, 291-330.
+
+    xy [B,2,N_r]; R [B,3,3] cam-to-world; T [B,3,1]; Kinv [B,3,3].
+    ``t_rand`` [B,N_r,n_samples+1] replaces ``torch.rand_like`` (model_utils.py:306);
+    ``None`` is the reference's ``disturb=False``.  ``z_edges`` overrides the edges (the fine
+    pass, model_utils.py:476-488).
+    """
+    zvals, ray_o, ray_d, ray_l = sample_edges(xy, R, T, Kinv, n_samples, world_z1, world_z2, t_rand)
+    if z_edges is not None:
+        zvals = z_edges
     return points_from_zvals(zvals, ray_o, ray_d, ray_l)
 
 
@@ -160,13 +170,13 @@ def _stream(params, pts_embed, shape_ext, appea, dists, zvals):
 
 
 def render_two_stream(xy, R, T, Kinv, shape_code, gaze, appea_code, face_params, eyes_params,
-                      n_samples, world_z1=2.5, world_z2=-3.5, t_rand=None):
+                      n_samples, world_z1=2.5, world_z2=-3.5, t_rand=None, z_edges=None):
     """models/gaze_nerf.py:231-262 + 136-162: the whole hot path for both streams.
 
     Returns a dict: feat_face/feat_eyes [B,C_f,N_r], bg_alpha_* [B,1,N_r], depth_* [B,1,N_r],
     w_face/w_eyes [B,1,N_r,N_p] and the sample dict under "samples".
     """
-    sd = gen_sample_points(xy, R, T, Kinv, n_samples, world_z1, world_z2, t_rand)
+    sd = gen_sample_points(xy, R, T, Kinv, n_samples, world_z1, world_z2, t_rand, z_edges)
     emb = embed(sd["pts"])
     shape_ext = torch.cat([shape_code, gaze], dim=1)                          # gaze_nerf.py:248
     out = {"samples": sd}
