@@ -1,13 +1,712 @@
-// gnr_bwd.hip -- backward of the hot path (placeholder until the dgrad chain + wgrad land).
-#include "gnr_internal.h"
+// gnr_bwd.hip -- backward of the hot path (gfx950).
+//
+// Per stream (face, then eyes; the dY scratch is re-used):
+//   1. gt_kernel          upstream d(feat_out) [B,C,N_r] -> row-major [ray][288]
+//   2. comp_bwd_kernel    CalcRayColor backward (utils/model_utils.py:498-534) per ray:
+//                         s_i = g . feat_i, w_i, dL/dsigma_raw_i, sum_i dL/ddelta_i * delta_i
+//   3. packT_kernel       W^T as MFMA A-fragments in the chain's k-order
+//   4. bwd_chain_kernel   register-chained dgrad through RGB2..L0 (same structure and FLOPs as the
+//                         forward kernel), ReLU masks from the saved activations, every layer's dY
+//                         dumped row-major for the weight gradients, d(encoding) -> d(pts) partials
+//   5. launch_wgrad x12   dW = dY^T X  (gnr_wgrad.hip), colsum for the biases
+//   6. latent_kernel      per-image bias sums -> d(shape,gaze,appea) and the latent columns of dW
+// Once per call: geo_kernel  d(pts), dL/dl partials -> dR, dT (GenSamplePoints backward).
+#include "gnr_chain.h"
 
 namespace gnr {
 int fail(const char* fmt, ...);
+size_t carve_fwd(const GnrProblem* p, int n_streams, bool save, char* base, FwdParams* fp);
+size_t wgrad_partial_floats(long M, int n_valid, int k_valid, int* splits_out);
+void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, long M,
+                  float* dW, int ldw, int col_off, int enc_map, float* partial, hipStream_t stream);
+void launch_colsum(const float* Y, int ld, int C, int batch, long rows_per_image, float* out, int out_ld,
+                   float* part, hipStream_t stream);
+extern thread_local hipEvent_t g_ev_start, g_ev_stop;
 
-size_t bwd_scratch_bytes(const GnrProblem*, int) { return 256; }
-
-int run_bwd(const GnrProblem*, int, const GnrWeights* const*, const GnrOutputGrads*, const GnrInputGrads*,
-            const GnrWeightGrads* const*, void*, size_t, void*, size_t, hipStream_t) {
-    return fail("gnr_bwd: not implemented in this build");
+// ---------------------------------------------------------------------------------------------
+// transposed weight stream.  Backward "layer" ids, in execution order:
+//   0: RGB2^T (in 9 tiles -> out 6)   1: RGB1^T (6 -> 12)   2: RGB0^T (12 -> 12)
+//   3..5: L7^T, L6^T, L5h^T (12 -> 12)   6: L5e^T (12 -> 2)   7..10: L4^T..L1^T   11: L0e^T (12 -> 2)
+// ---------------------------------------------------------------------------------------------
+constexpr int N_BL = 12;
+__host__ __device__ constexpr int bl_in_tiles(int l) { return l == 0 ? NT_F : (l == 1 ? NT_H2 : NT_H); }
+__host__ __device__ constexpr int bl_out_tiles(int l) { return l == 0 ? NT_H2 : ((l == 6 || l == 11) ? 2 : NT_H); }
+__host__ __device__ constexpr size_t bl_floats(int l) { return (size_t)bl_in_tiles(l) * 16 * bl_out_tiles(l) * 64; }
+__host__ __device__ constexpr size_t bl_offset(int l) {
+    size_t o = 0;
+    for (int i = 0; i < l; ++i) o += bl_floats(i);
+    return o;
 }
+constexpr size_t PACKEDT_FLOATS = bl_offset(N_BL);
+
+struct PackTParams {
+    const float* w[N_BL];
+    int ld[N_BL];
+    int n_valid[N_BL];     // forward outputs (contraction length here)
+    int col0[N_BL];        // first source column of the outputs of this backward layer
+    int k_valid[N_BL];     // number of valid output channels (hidden) ; enc layers: 64 slots
+    int enc[N_BL];
+    float* packed;
+};
+
+__global__ void packT_kernel(const PackTParams pp) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < PACKEDT_FLOATS;
+         e += (size_t)gridDim.x * blockDim.x) {
+        int l = 0;
+        size_t off = 0;
+        while (l + 1 < N_BL && e >= off + bl_floats(l)) { off += bl_floats(l); ++l; }
+        const size_t loc = e - off;
+        const int kt_n = bl_out_tiles(l);
+        const int sg = (int)(loc / ((size_t)kt_n * 256));
+        const int rem = (int)(loc % ((size_t)kt_n * 256));
+        const int kt = rem / 256, lane = (rem % 256) / 4, jj = rem % 4;
+        const int step = 4 * sg + jj, h = lane >> 5;
+        const int n = dlayout_channel(step, h);              // contraction index: forward output channel
+        const int krow = 32 * kt + (lane & 31);              // output row of this backward layer
+        int col = -1;
+        if (pp.enc[l]) {
+            // output rows follow the C/D layout of an encoding register file: row i' of tile t'
+            // belongs to lane-half h' = (i'>>2)&1, register r = (i'&3) + 4 (i'>>3)
+            const int tq = krow >> 5, iq = krow & 31;
+            const int hq = (iq >> 2) & 1, r = (iq & 3) + 4 * (iq >> 3);
+            col = enc_channel(16 * tq + r, hq);
+        } else if (krow < pp.k_valid[l]) {
+            col = pp.col0[l] + krow;
+        }
+        float v = 0.0f;
+        if (n < pp.n_valid[l] && col >= 0) v = pp.w[l][(size_t)n * pp.ld[l] + col];
+        pp.packed[e] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// upstream gradient transpose: g[b][n][ray] -> gT[ray_g][288] (zero padded / zero when NULL)
+// ---------------------------------------------------------------------------------------------
+__global__ void gt_kernel(const float* __restrict__ g, int feat_nc, int n_rays, long n_rays_total,
+                          float* __restrict__ gT) {
+    __shared__ float tile[32][33];
+    const long ray0 = (long)blockIdx.x * 32;
+    const int n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 256 threads: 8 rows at a time
+    for (int yy = ty; yy < 32; yy += 8) {
+        const int n = n0 + yy;
+        const long rg = ray0 + tx;
+        float v = 0.0f;
+        if (g && n < feat_nc && rg < n_rays_total) {
+            const long b = rg / n_rays, r = rg - b * n_rays;
+            v = g[(b * feat_nc + n) * n_rays + r];
+        }
+        tile[yy][tx] = v;
+    }
+    __syncthreads();
+    for (int yy = ty; yy < 32; yy += 8) {
+        const long rg = ray0 + yy;
+        if (rg < n_rays_total) gT[rg * FEAT_PAD + n0 + tx] = tile[tx][yy];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// CalcRayColor backward.  One wavefront per ray.
+//   out_n = sum_i w_i f_i[n], bg = 1 - sum_i w_i, w_i = a_i T_i, T_i = prod_{j<i} x_j, x = 1-a+1e-10
+//   q_i  = g.f_i - g_bg ;  dL/da_i = q_i T_i - (sum_{j>i} q_j w_j) / x_i
+//   a = 1 - exp(-sigma delta): dL/dsigma = dL/da delta e, dL/ddelta = dL/da sigma e,  e = exp(-sigma delta)
+// ---------------------------------------------------------------------------------------------
+struct CompBwdParams {
+    GnrProblem prob;
+    int chunks_per_ray;
+    const float* gT;          // [rays][288]
+    const float* g_bg;        // [B,1,N_r] or NULL
+    const float* act_feat;    // [M][288]
+    const float* sigma_raw;   // [M]
+    const float* delta;       // [M]
+    float* wglob;             // [M]  w_i
+    float* dsig;              // [M]  dL/dsigma_raw_i
+    float* csum;              // [rays] sum_i dL/ddelta_i * delta_i
+    int accumulate;
+};
+
+constexpr int CB_MAX = 512;
+
+__global__ __launch_bounds__(256) void comp_bwd_kernel(const CompBwdParams cp) {
+    __shared__ float sh_q[4][CB_MAX], sh_x[4][CB_MAX], sh_T[4][CB_MAX], sh_S[4][CB_MAX];
+    const GnrProblem& p = cp.prob;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long n_rays_total = (long)p.batch * p.n_rays;
+    const long ray = (long)blockIdx.x * 4 + wave;
+    const bool live = ray < n_rays_total;
+    const int np = p.n_samples, cpr = cp.chunks_per_ray;
+    float* q = sh_q[wave]; float* xx = sh_x[wave]; float* TT = sh_T[wave]; float* SS = sh_S[wave];
+    const long row0 = live ? ray * cpr * CHUNK : 0;       // padded rows of this ray are contiguous
+
+    float g[5];
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        const int c = lane + 64 * m;
+        g[m] = (live && c < FEAT_PAD) ? cp.gT[ray * FEAT_PAD + c] : 0.0f;
+    }
+    const float gbg = (live && cp.g_bg) ? cp.g_bg[ray] : 0.0f;
+    if (live) {
+        for (int i = 0; i < np; ++i) {
+            const float* fr = cp.act_feat + (row0 + i) * FEAT_PAD;
+            float v = 0.0f;
+#pragma unroll
+            for (int m = 0; m < 5; ++m) {
+                const int c = lane + 64 * m;
+                if (c < FEAT_PAD) v = fmaf(fr[c], g[m], v);
+            }
+            v += __shfl_xor(v, 32);
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 8);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 1);
+            if (lane == 0) q[i] = v - gbg;
+        }
+    }
+    __syncthreads();
+    if (live) {
+        for (int i = lane; i < np; i += 64) {
+            const float sr = cp.sigma_raw[row0 + i];
+            const float sg = fmaxf(sr, 0.0f);
+            const float e = expf(-sg * cp.delta[row0 + i]);
+            xx[i] = ((1.0f - (1.0f - e))) + 1e-10f;      // x = 1 - alpha + 1e-10 with alpha = 1 - e
+        }
+    }
+    __syncthreads();
+    if (live && lane == 0) {
+        float T = 1.0f;
+        for (int i = 0; i < np; ++i) { TT[i] = T; T *= xx[i]; }
+    }
+    __syncthreads();
+    if (live) {
+        for (int i = lane; i < np; i += 64) {
+            const float sr = cp.sigma_raw[row0 + i];
+            const float e = expf(-fmaxf(sr, 0.0f) * cp.delta[row0 + i]);
+            const float alpha = 1.0f - e;
+            SS[i] = q[i] * alpha * TT[i];                 // q_i w_i
+        }
+    }
+    __syncthreads();
+    if (live && lane == 0) {
+        float S = 0.0f;
+        for (int i = np - 1; i >= 0; --i) { const float t = SS[i]; SS[i] = S; S += t; }
+    }
+    __syncthreads();
+    float cs = 0.0f;
+    if (live) {
+        for (int i = lane; i < np; i += 64) {
+            const float sr = cp.sigma_raw[row0 + i];
+            const float sg = fmaxf(sr, 0.0f);
+            const float dl = cp.delta[row0 + i];
+            const float e = expf(-sg * dl);
+            const float alpha = 1.0f - e;
+            const float dalpha = q[i] * TT[i] - SS[i] / xx[i];
+            cp.wglob[row0 + i] = alpha * TT[i];
+            cp.dsig[row0 + i] = sr > 0.0f ? dalpha * dl * e : 0.0f;
+            cs = fmaf(dalpha * sg * e, dl, cs);
+        }
+        // padded tail rows (i >= np) carry no gradient
+        for (int i = np + lane; i < cpr * CHUNK; i += 64) { cp.wglob[row0 + i] = 0.0f; cp.dsig[row0 + i] = 0.0f; }
+    }
+    cs += __shfl_xor(cs, 32);
+    cs += __shfl_xor(cs, 16);
+    cs += __shfl_xor(cs, 8);
+    cs += __shfl_xor(cs, 4);
+    cs += __shfl_xor(cs, 2);
+    cs += __shfl_xor(cs, 1);
+    if (live && lane == 0) cp.csum[ray] = cp.accumulate ? cp.csum[ray] + cs : cs;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dgrad chain
+// ---------------------------------------------------------------------------------------------
+struct BwdParams {
+    GnrProblem prob;
+    int chunks_per_ray;
+    long n_chunks, M;
+    const float* packedT;
+    const float* wsig;        // [H] density weight
+    const float* gT;          // [rays][288]
+    const float* wglob;       // [M]
+    const float* dsig;        // [M]
+    const float* act_h;       // [8][M][H]
+    const float* act_y1;      // [M][H2]
+    const float* enc;         // [M][64]
+    const float* zval;        // [M]
+    float* dY_h;              // [8][M][H]
+    float* dY_r0;             // [M][H]
+    float* dY_r1;             // [M][H2]
+    float* dfeat;             // [M][288]
+    float* geo_chunk;         // [n_chunks][8]: sum dpts (3), sum z*dpts (3)
+    int accumulate_geo;
+};
+
+template <int NT>
+__device__ __forceinline__ void zero_tiles(f32x16 (&acc)[NT_H]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+}
+
+// ReLU mask from the saved post-activation (h > 0), then dump dY row-major
+template <int NT>
+__device__ __forceinline__ void mask_dump(f32x16 (&acc)[NT_H], const float* __restrict__ act,
+                                          float* __restrict__ dY, int C, long row, int h) {
+    const float* ab = act + row * C + 4 * h;
+    float* db = dY + row * C + 4 * h;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const f32x4 a4 = *(const f32x4*)(ab + 32 * t + 8 * rq);
+            f32x4 v;
+            v.x = a4.x > 0.0f ? acc[t][4 * rq + 0] : 0.0f;
+            v.y = a4.y > 0.0f ? acc[t][4 * rq + 1] : 0.0f;
+            v.z = a4.z > 0.0f ? acc[t][4 * rq + 2] : 0.0f;
+            v.w = a4.w > 0.0f ? acc[t][4 * rq + 3] : 0.0f;
+            acc[t][4 * rq + 0] = v.x;
+            acc[t][4 * rq + 1] = v.y;
+            acc[t][4 * rq + 2] = v.z;
+            acc[t][4 * rq + 3] = v.w;
+            *(f32x4*)(db + 32 * t + 8 * rq) = v;
+        }
+}
+
+// d(encoding) held as a 2-tile C/D register file (lane-half h owns the slots it encoded) -> d(pts).
+// Embedder backward: d/dp sin(a p) = a cos(a p), d/dp cos(a p) = -a sin(a p).
+__device__ __forceinline__ void enc_backward(const f32x16 (&E)[NT_H], const float* __restrict__ enc_row, int h,
+                                             float& gx, float& gy, float& gz) {
+    float d[ENC_STEPS];
+#pragma unroll
+    for (int s = 0; s < ENC_STEPS; ++s) d[s] = E[s >> 4][s & 15];
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+    if (h == 0) { ax += d[0]; az += d[1]; } else { ay += d[0]; }
+#pragma unroll
+    for (int fl = 0; fl < 5; ++fl) {
+        const float scale = (float)(1 << fl) * (h ? 32.0f : 1.0f);
+        float acc3[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int si = 2 + 6 * fl + a, ci = si + 3;
+            const float sv = enc_row[2 * si + h], cv = enc_row[2 * ci + h];
+            acc3[a] = scale * (cv * d[si] - sv * d[ci]);
+        }
+        ax += acc3[0]; ay += acc3[1]; az += acc3[2];
+    }
+    ax += __shfl_xor(ax, 32);
+    ay += __shfl_xor(ay, 32);
+    az += __shfl_xor(az, 32);
+    gx += ax; gy += ay; gz += az;
+}
+
+__global__ __launch_bounds__(256, 1) void bwd_chain_kernel(const BwdParams bp) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const long chunk = (long)blockIdx.x * WAVES_PER_WG + wave;
+    if (chunk >= bp.n_chunks) return;
+    const long ray_g = chunk / bp.chunks_per_ray;
+    const long row = chunk * CHUNK + j;
+    const long M = bp.M;
+    const f32x4* PT = (const f32x4*)bp.packedT;
+    auto Pb = [&](int l) { return PT + bl_offset(l) / 4; };
+    const float* enc_row = bp.enc + row * ENC_PAD;
+
+    f32x16 A[NT_H], Bv[NT_H];
+    float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+
+    // d(feat_i) = w_i * g  (9 tiles) -> A
+    {
+        const float w = bp.wglob[row];
+        const float* gr = bp.gT + ray_g * FEAT_PAD + 4 * h;
+        float* df = bp.dfeat + row * FEAT_PAD + 4 * h;
+#pragma unroll
+        for (int t = 0; t < NT_F; ++t)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const f32x4 g4 = *(const f32x4*)(gr + 32 * t + 8 * rq);
+                const f32x4 v = {w * g4.x, w * g4.y, w * g4.z, w * g4.w};
+                A[t][4 * rq + 0] = v.x; A[t][4 * rq + 1] = v.y; A[t][4 * rq + 2] = v.z; A[t][4 * rq + 3] = v.w;
+                *(f32x4*)(df + 32 * t + 8 * rq) = v;
+            }
+    }
+    // RGB2^T: A(9) -> Bv(6), mask y1 > 0
+    zero_tiles<NT_H2>(Bv);
+    mm_h<NT_F, NT_H2>(A, Bv, Pb(0), lane);
+    mask_dump<NT_H2>(Bv, bp.act_y1, bp.dY_r1, H2, row, h);
+    // RGB1^T: Bv(6) -> A(12), no activation on y0
+    zero_tiles<NT_H>(A);
+    mm_h<NT_H2, NT_H>(Bv, A, Pb(1), lane);
+    dump<NT_H>(A, bp.dY_r0, H, row, h);
+    // RGB0^T: A -> Bv, + density head, mask h7
+    zero_tiles<NT_H>(Bv);
+    mm_h<NT_H, NT_H>(A, Bv, Pb(2), lane);
+    {
+        const float ds = bp.dsig[row];
+#pragma unroll
+        for (int t = 0; t < NT_H; ++t)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const f32x4 w4 = *(const f32x4*)(bp.wsig + 32 * t + 8 * rq + 4 * h);
+                Bv[t][4 * rq + 0] = fmaf(w4.x, ds, Bv[t][4 * rq + 0]);
+                Bv[t][4 * rq + 1] = fmaf(w4.y, ds, Bv[t][4 * rq + 1]);
+                Bv[t][4 * rq + 2] = fmaf(w4.z, ds, Bv[t][4 * rq + 2]);
+                Bv[t][4 * rq + 3] = fmaf(w4.w, ds, Bv[t][4 * rq + 3]);
+            }
+    }
+    mask_dump<NT_H>(Bv, bp.act_h + 7 * M * H, bp.dY_h + 7 * M * H, H, row, h);
+    // L7^T: Bv -> A mask h6 ; L6^T: A -> Bv mask h5
+    zero_tiles<NT_H>(A);
+    mm_h<NT_H, NT_H>(Bv, A, Pb(3), lane);
+    mask_dump<NT_H>(A, bp.act_h + 6 * M * H, bp.dY_h + 6 * M * H, H, row, h);
+    zero_tiles<NT_H>(Bv);
+    mm_h<NT_H, NT_H>(A, Bv, Pb(4), lane);
+    mask_dump<NT_H>(Bv, bp.act_h + 5 * M * H, bp.dY_h + 5 * M * H, H, row, h);
+    // L5: encoding columns first (2 tiles, A is dead here), then the hidden columns -> A mask h4
+    zero_tiles<2>(A);
+    mm_h<NT_H, 2>(Bv, A, Pb(6), lane);
+    enc_backward(A, enc_row, h, gx, gy, gz);
+    zero_tiles<NT_H>(A);
+    mm_h<NT_H, NT_H>(Bv, A, Pb(5), lane);
+    mask_dump<NT_H>(A, bp.act_h + 4 * M * H, bp.dY_h + 4 * M * H, H, row, h);
+    // L4^T..L1^T
+#pragma unroll 1
+    for (int rep = 0; rep < 2; ++rep) {
+        const int la = 3 - 2 * rep, lb = 2 - 2 * rep;      // outputs dY_3, dY_2 then dY_1, dY_0
+        zero_tiles<NT_H>(Bv);
+        mm_h<NT_H, NT_H>(A, Bv, PT + (bl_offset(7) + (size_t)(2 * rep) * bl_floats(7)) / 4, lane);
+        mask_dump<NT_H>(Bv, bp.act_h + la * M * H, bp.dY_h + la * M * H, H, row, h);
+        zero_tiles<NT_H>(A);
+        mm_h<NT_H, NT_H>(Bv, A, PT + (bl_offset(7) + (size_t)(2 * rep + 1) * bl_floats(7)) / 4, lane);
+        mask_dump<NT_H>(A, bp.act_h + lb * M * H, bp.dY_h + lb * M * H, H, row, h);
+    }
+    // L0: encoding columns from dY_0 (in A)
+    zero_tiles<2>(Bv);
+    mm_h<NT_H, 2>(A, Bv, Pb(11), lane);
+    enc_backward(Bv, enc_row, h, gx, gy, gz);
+
+    // chunk partials for the geometry gradient: sum dpts, sum z * dpts
+    const float z = bp.zval[row];
+    const float sx = half_sum32(gx), sy = half_sum32(gy), sz = half_sum32(gz);
+    const float zx = half_sum32(gx * z), zy = half_sum32(gy * z), zz = half_sum32(gz * z);
+    if (lane == 0) {
+        float* gc = bp.geo_chunk + chunk * 8;
+        if (bp.accumulate_geo) {
+            gc[0] += sx; gc[1] += sy; gc[2] += sz; gc[3] += zx; gc[4] += zy; gc[5] += zz;
+        } else {
+            gc[0] = sx; gc[1] = sy; gc[2] = sz; gc[3] = zx; gc[4] = zy; gc[5] = zz; gc[6] = 0.0f; gc[7] = 0.0f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// geometry: per-ray partials -> dR, dT.   pts = T + m z, m = -u/u_z, l = -|u|/u_z, u = R Kinv [x y 1]
+// ---------------------------------------------------------------------------------------------
+struct GeoParams {
+    GnrProblem prob;
+    int chunks_per_ray;
+    const float* geo_chunk;   // [n_chunks][8]
+    const float* csum;        // [rays]
+    float* part;              // [B][blocks][12]
+    int blocks_per_image;
+};
+
+__global__ __launch_bounds__(256) void geo_kernel(const GeoParams gp) {
+    __shared__ float red[12][256];
+    const GnrProblem& p = gp.prob;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int ray = blockIdx.x * 256 + tid;
+    float v[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) v[k] = 0.0f;
+    if (ray < p.n_rays) {
+        const long rg = (long)b * p.n_rays + ray;
+        const Ray r = make_ray(p, b, ray);
+        float A0 = 0, A1 = 0, A2 = 0, B0 = 0, B1 = 0;
+        for (int c = 0; c < gp.chunks_per_ray; ++c) {
+            const float* gc = gp.geo_chunk + (rg * gp.chunks_per_ray + c) * 8;
+            A0 += gc[0]; A1 += gc[1]; A2 += gc[2]; B0 += gc[3]; B1 += gc[4];
+        }
+        const float un = 1.0f / r.inv_n;                    // |u|
+        const float iuz = 1.0f / r.uz;
+        const float dLdl = gp.csum[rg] / r.l;               // sum_i dL/ddelta_i (z_{i+1}-z_i)
+        const float mx = -r.ux * iuz, my = -r.uy * iuz;
+        // dL/du
+        const float dux = -B0 * iuz - dLdl * r.ux / (un * r.uz);
+        const float duy = -B1 * iuz - dLdl * r.uy / (un * r.uz);
+        const float duz = (B0 * r.ux + B1 * r.uy) * iuz * iuz + dLdl * (-1.0f / un + un * iuz * iuz);
+        // v = Kinv [x y 1]
+        const float x = p.xy[((long)b * 2 + 0) * p.n_rays + ray], y = p.xy[((long)b * 2 + 1) * p.n_rays + ray];
+        const float* K = p.Kinv + b * 9;
+        const float v0 = fmaf(K[2], 1.0f, fmaf(K[1], y, K[0] * x));
+        const float v1 = fmaf(K[5], 1.0f, fmaf(K[4], y, K[3] * x));
+        const float v2 = fmaf(K[8], 1.0f, fmaf(K[7], y, K[6] * x));
+        v[0] = dux * v0; v[1] = dux * v1; v[2] = dux * v2;
+        v[3] = duy * v0; v[4] = duy * v1; v[5] = duy * v2;
+        v[6] = duz * v0; v[7] = duz * v1; v[8] = duz * v2;
+        v[9] = A0; v[10] = A1;
+        // z edges move with T_z (plane sweep and its jitter): dpts/dT_z += m ; explicit edges do not
+        v[11] = A2 + (p.z_edges ? 0.0f : (mx * A0 + my * A1 - A2));
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) red[k][tid] = v[k];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s)
+#pragma unroll
+            for (int k = 0; k < 12; ++k) red[k][tid] += red[k][tid + s];
+        __syncthreads();
+    }
+    if (tid < 12) gp.part[((long)b * gp.blocks_per_image + blockIdx.x) * 12 + tid] = red[tid][0];
+}
+
+__global__ void geo_final_kernel(const float* part, int blocks_per_image, float* dR, float* dT) {
+    const int b = blockIdx.x, k = threadIdx.x;
+    if (k >= 12) return;
+    float acc = 0.0f;
+    for (int i = 0; i < blocks_per_image; ++i) acc += part[((long)b * blocks_per_image + i) * 12 + k];
+    if (k < 9) { if (dR) dR[b * 9 + k] = acc; }
+    else if (dT) dT[b * 3 + (k - 9)] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// latent codes: per-image bias-gradient sums -> d(shape, gaze, appea), latent columns of dW, biases
+// ---------------------------------------------------------------------------------------------
+struct LatentParams {
+    GnrProblem prob;
+    GnrWeights w;
+    GnrWeightGrads dw;
+    const float* dbias;       // [N_CHAIN + 1][B][H]  per-image column sums of dY (row N_CHAIN: dsig)
+    float* dshape; float* dgaze; float* dappea;
+    int accumulate;           // second stream adds to the first stream's latent gradients
+};
+
+// grid.x = job: 0 -> d(ext codes) from L0 and L5; 1 -> d(appea); 2.. -> weight columns / biases
+__global__ void latent_codes_kernel(const LatentParams lp) {
+    const GnrProblem& p = lp.prob;
+    const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ext = p.shape_dims + p.gaze_dims, vp = ENC_CH + ext;
+    const float* db0 = lp.dbias + ((long)0 * p.batch + b) * H;
+    const float* db5 = lp.dbias + ((long)5 * p.batch + b) * H;
+    const float* dbr1 = lp.dbias + ((long)LR1 * p.batch + b) * H;
+    if (c < ext) {
+        float acc = 0.0f;
+        for (int n = 0; n < H; ++n) {
+            acc = fmaf(lp.w.fea_w[0][(long)n * vp + ENC_CH + c], db0[n], acc);
+            acc = fmaf(lp.w.fea_w[5][(long)n * (vp + H) + ENC_CH + c], db5[n], acc);
+        }
+        float* dst = c < p.shape_dims ? (lp.dshape ? lp.dshape + b * p.shape_dims + c : nullptr)
+                                      : (lp.dgaze ? lp.dgaze + b * p.gaze_dims + (c - p.shape_dims) : nullptr);
+        if (dst) *dst = lp.accumulate ? *dst + acc : acc;
+    }
+    if (c < p.appea_dims && lp.dappea) {
+        float acc = 0.0f;
+        for (int n = 0; n < H2; ++n) acc = fmaf(lp.w.rgb_w[1][(long)n * (H + p.appea_dims) + H + c], dbr1[n], acc);
+        float* dst = lp.dappea + b * p.appea_dims + c;
+        *dst = lp.accumulate ? *dst + acc : acc;
+    }
+}
+
+// latent columns of dW0 / dW5 / dW_r1 (rank-B outer products) and all bias gradients
+__global__ void latent_weights_kernel(const LatentParams lp) {
+    const GnrProblem& p = lp.prob;
+    const int n = blockIdx.x, t = threadIdx.x;               // block per output row n < H
+    const int ext = p.shape_dims + p.gaze_dims, vp = ENC_CH + ext;
+    auto code = [&](int b, int c) {
+        return c < p.shape_dims ? p.shape_code[b * p.shape_dims + c] : p.gaze[b * p.gaze_dims + (c - p.shape_dims)];
+    };
+    for (int c = t; c < ext; c += blockDim.x) {
+        float a0 = 0.0f, a5 = 0.0f;
+        for (int b = 0; b < p.batch; ++b) {
+            const float cv = code(b, c);
+            a0 = fmaf(lp.dbias[((long)0 * p.batch + b) * H + n], cv, a0);
+            a5 = fmaf(lp.dbias[((long)5 * p.batch + b) * H + n], cv, a5);
+        }
+        if (lp.dw.fea_w[0]) lp.dw.fea_w[0][(long)n * vp + ENC_CH + c] = a0;
+        if (lp.dw.fea_w[5]) lp.dw.fea_w[5][(long)n * (vp + H) + ENC_CH + c] = a5;
+    }
+    if (n < H2 && lp.dw.rgb_w[1])
+        for (int c = t; c < p.appea_dims; c += blockDim.x) {
+            float a = 0.0f;
+            for (int b = 0; b < p.batch; ++b)
+                a = fmaf(lp.dbias[((long)LR1 * p.batch + b) * H + n], p.appea_code[b * p.appea_dims + c], a);
+            lp.dw.rgb_w[1][(long)n * (H + p.appea_dims) + H + c] = a;
+        }
+    if (t == 0) {
+        auto bsum = [&](int l) {
+            float a = 0.0f;
+            for (int b = 0; b < p.batch; ++b) a += lp.dbias[((long)l * p.batch + b) * H + n];
+            return a;
+        };
+        for (int l = 0; l < 8; ++l)
+            if (lp.dw.fea_b[l]) lp.dw.fea_b[l][n] = bsum(l);
+        if (lp.dw.rgb_b[0]) lp.dw.rgb_b[0][n] = bsum(LR0);
+        if (n < H2 && lp.dw.rgb_b[1]) lp.dw.rgb_b[1][n] = bsum(LR1);
+        if (n < p.feat_nc && lp.dw.rgb_b[2]) lp.dw.rgb_b[2][n] = bsum(LR2);
+        if (n == 0 && lp.dw.density_b) lp.dw.density_b[0] = bsum(N_CHAIN);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------------------------
+static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct BwdScratch {
+    float *packedT, *gT, *wglob, *dsig, *dY_h, *dY_r0, *dY_r1, *dfeat, *geo_chunk, *csum, *geo_part;
+    float *dbias, *cs_part, *wg_part;
+    int geo_blocks;
+};
+
+static size_t carve_bwd(const GnrProblem* p, char* base, BwdScratch* sc) {
+    const int cpr = (p->n_samples + CHUNK - 1) / CHUNK;
+    const size_t n_rays_total = (size_t)p->batch * p->n_rays;
+    const size_t n_chunks = n_rays_total * cpr, M = n_chunks * CHUNK;
+    size_t off = 0;
+    auto take = [&](size_t floats) {
+        float* ptr = base ? (float*)(base + off) : nullptr;
+        off += align_up(floats * sizeof(float));
+        return ptr;
+    };
+    BwdScratch s{};
+    s.packedT = take(PACKEDT_FLOATS);
+    s.gT = take(n_rays_total * FEAT_PAD);
+    s.wglob = take(M);
+    s.dsig = take(M);
+    s.dY_h = take((size_t)8 * M * H);
+    s.dY_r0 = take(M * H);
+    s.dY_r1 = take(M * H2);
+    s.dfeat = take(M * FEAT_PAD);
+    s.geo_chunk = take(n_chunks * 8);
+    s.csum = take(n_rays_total);
+    s.geo_blocks = (p->n_rays + 255) / 256;
+    s.geo_part = take((size_t)p->batch * s.geo_blocks * 12);
+    s.dbias = take((size_t)(N_CHAIN + 1) * p->batch * H);
+    s.cs_part = take((size_t)p->batch * 512 * H);
+    const size_t wg = (size_t)1024 * 128 * 128;      // splits * tiles <= 1024 partial tiles (gnr_wgrad.hip)
+    s.wg_part = take(wg);
+    if (sc) *sc = s;
+    return off;
+}
+
+size_t bwd_scratch_bytes(const GnrProblem* p, int) { return carve_bwd(p, nullptr, nullptr); }
+
+int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, const GnrOutputGrads* dout,
+            const GnrInputGrads* din, const GnrWeightGrads* const* dw, void* saved, size_t saved_bytes,
+            void* scratch, size_t scratch_bytes, hipStream_t st) {
+    FwdParams fp{};
+    const size_t need_saved = carve_fwd(p, n_streams, true, nullptr, nullptr);
+    if (!saved || saved_bytes < need_saved)
+        return fail("gnr_bwd: saved workspace too small (%zu < %zu bytes); run gnr_fwd with save_for_backward",
+                    saved_bytes, need_saved);
+    const size_t need_scr = carve_bwd(p, nullptr, nullptr);
+    if (!scratch || scratch_bytes < need_scr)
+        return fail("gnr_bwd: scratch too small (%zu < %zu bytes)", scratch_bytes, need_scr);
+    if (((uintptr_t)saved & 255) || ((uintptr_t)scratch & 255)) return fail("gnr_bwd: workspaces must be 256-byte aligned");
+    carve_fwd(p, n_streams, true, (char*)saved, &fp);
+    BwdScratch sc{};
+    carve_bwd(p, (char*)scratch, &sc);
+
+    const int cpr = fp.chunks_per_ray;
+    const long n_rays_total = (long)p->batch * p->n_rays;
+    const long M = fp.M;
+    const long rows_per_image = (long)p->n_rays * cpr * CHUNK;
+    const int vp = ENC_CH + p->shape_dims + p->gaze_dims;
+    GnrInputGrads dinz{};
+    if (din) dinz = *din;
+
+    for (int s = 0; s < n_streams; ++s) {
+        const StreamWs& ws = fp.ws[s];
+        const GnrWeights& W = *w[s];
+        GnrWeightGrads DW{};
+        if (dw[s]) DW = *dw[s];
+
+        // 1. upstream gradient, row-major per ray
+        hipLaunchKernelGGL(gt_kernel, dim3((unsigned)((n_rays_total + 31) / 32), FEAT_PAD / 32), dim3(256), 0, st,
+                           dout->feat[s], p->feat_nc, p->n_rays, n_rays_total, sc.gT);
+        // 2. compositing backward
+        CompBwdParams cb{};
+        cb.prob = *p; cb.chunks_per_ray = cpr; cb.gT = sc.gT; cb.g_bg = dout->bg_alpha[s];
+        cb.act_feat = ws.act_feat; cb.sigma_raw = ws.sigma_raw; cb.delta = fp.delta;
+        cb.wglob = sc.wglob; cb.dsig = sc.dsig; cb.csum = sc.csum; cb.accumulate = s > 0;
+        hipLaunchKernelGGL(comp_bwd_kernel, dim3((unsigned)((n_rays_total + 3) / 4)), dim3(256), 0, st, cb);
+        // 3. transposed weight stream
+        PackTParams pt{};
+        auto setl = [&](int l, const float* wp, int ld, int n_valid, int col0, int k_valid, int enc) {
+            pt.w[l] = wp; pt.ld[l] = ld; pt.n_valid[l] = n_valid; pt.col0[l] = col0; pt.k_valid[l] = k_valid; pt.enc[l] = enc;
+        };
+        setl(0, W.rgb_w[2], H2, p->feat_nc, 0, H2, 0);
+        setl(1, W.rgb_w[1], H + p->appea_dims, H2, 0, H, 0);
+        setl(2, W.rgb_w[0], H, H, 0, H, 0);
+        setl(3, W.fea_w[7], H, H, 0, H, 0);
+        setl(4, W.fea_w[6], H, H, 0, H, 0);
+        setl(5, W.fea_w[5], vp + H, H, vp, H, 0);
+        setl(6, W.fea_w[5], vp + H, H, 0, ENC_PAD, 1);
+        setl(7, W.fea_w[4], H, H, 0, H, 0);
+        setl(8, W.fea_w[3], H, H, 0, H, 0);
+        setl(9, W.fea_w[2], H, H, 0, H, 0);
+        setl(10, W.fea_w[1], H, H, 0, H, 0);
+        setl(11, W.fea_w[0], vp, H, 0, ENC_PAD, 1);
+        pt.packed = sc.packedT;
+        hipLaunchKernelGGL(packT_kernel, dim3(1024), dim3(256), 0, st, pt);
+        // 4. dgrad chain
+        BwdParams bp{};
+        bp.prob = *p; bp.chunks_per_ray = cpr; bp.n_chunks = fp.n_chunks; bp.M = M;
+        bp.packedT = sc.packedT; bp.wsig = ws.wsig; bp.gT = sc.gT; bp.wglob = sc.wglob; bp.dsig = sc.dsig;
+        bp.act_h = ws.act_h; bp.act_y1 = ws.act_y1; bp.enc = fp.enc; bp.zval = fp.zval;
+        bp.dY_h = sc.dY_h; bp.dY_r0 = sc.dY_r0; bp.dY_r1 = sc.dY_r1; bp.dfeat = sc.dfeat;
+        bp.geo_chunk = sc.geo_chunk; bp.accumulate_geo = s > 0;
+        if (g_ev_start && s == 0) hipEventRecord(g_ev_start, st);
+        hipLaunchKernelGGL(bwd_chain_kernel, dim3((unsigned)((fp.n_chunks + WAVES_PER_WG - 1) / WAVES_PER_WG)),
+                           dim3(256), 0, st, bp);
+        if (g_ev_stop && s == 0) hipEventRecord(g_ev_stop, st);
+
+        // 5. weight gradients  dW = dY^T X
+        const float* hact = ws.act_h;
+        auto hptr = [&](int l) { return hact + (size_t)l * M * H; };
+        auto dyh = [&](int l) { return sc.dY_h + (size_t)l * M * H; };
+        if (DW.rgb_w[2]) launch_wgrad(sc.dfeat, FEAT_PAD, p->feat_nc, ws.act_y1, H2, H2, M, DW.rgb_w[2], H2, 0, 0, sc.wg_part, st);
+        if (DW.rgb_w[1]) launch_wgrad(sc.dY_r1, H2, H2, ws.act_y0, H, H, M, DW.rgb_w[1], H + p->appea_dims, 0, 0, sc.wg_part, st);
+        if (DW.rgb_w[0]) launch_wgrad(sc.dY_r0, H, H, hptr(7), H, H, M, DW.rgb_w[0], H, 0, 0, sc.wg_part, st);
+        if (DW.density_w) launch_wgrad(sc.dsig, 1, 1, hptr(7), H, H, M, DW.density_w, H, 0, 0, sc.wg_part, st);
+        for (int l = 7; l >= 1; --l) {
+            if (!DW.fea_w[l]) continue;
+            if (l == 5) {
+                launch_wgrad(dyh(5), H, H, hptr(4), H, H, M, DW.fea_w[5], vp + H, vp, 0, sc.wg_part, st);
+                launch_wgrad(dyh(5), H, H, fp.enc, ENC_PAD, ENC_PAD, M, DW.fea_w[5], vp + H, 0, 1, sc.wg_part, st);
+            } else {
+                launch_wgrad(dyh(l), H, H, hptr(l - 1), H, H, M, DW.fea_w[l], H, 0, 0, sc.wg_part, st);
+            }
+        }
+        if (DW.fea_w[0]) launch_wgrad(dyh(0), H, H, fp.enc, ENC_PAD, ENC_PAD, M, DW.fea_w[0], vp, 0, 1, sc.wg_part, st);
+
+        // 6. per-image bias sums, latent gradients
+        for (int l = 0; l < 8; ++l)
+            launch_colsum(dyh(l), H, H, p->batch, rows_per_image, sc.dbias + (size_t)l * p->batch * H, H, sc.cs_part, st);
+        launch_colsum(sc.dY_r0, H, H, p->batch, rows_per_image, sc.dbias + (size_t)LR0 * p->batch * H, H, sc.cs_part, st);
+        launch_colsum(sc.dY_r1, H2, H2, p->batch, rows_per_image, sc.dbias + (size_t)LR1 * p->batch * H, H, sc.cs_part, st);
+        launch_colsum(sc.dfeat, FEAT_PAD, FEAT_PAD, p->batch, rows_per_image, sc.dbias + (size_t)LR2 * p->batch * H, H, sc.cs_part, st);
+        launch_colsum(sc.dsig, 1, 1, p->batch, rows_per_image, sc.dbias + (size_t)N_CHAIN * p->batch * H, H, sc.cs_part, st);
+        LatentParams lp{};
+        lp.prob = *p; lp.w = W; lp.dw = DW; lp.dbias = sc.dbias;
+        lp.dshape = dinz.shape_code; lp.dgaze = dinz.gaze; lp.dappea = dinz.appea_code; lp.accumulate = s > 0;
+        const int maxc = (p->shape_dims + p->gaze_dims) > p->appea_dims ? (p->shape_dims + p->gaze_dims) : p->appea_dims;
+        if (maxc > 0)
+            hipLaunchKernelGGL(latent_codes_kernel, dim3((maxc + 63) / 64, p->batch), dim3(64), 0, st, lp);
+        hipLaunchKernelGGL(latent_weights_kernel, dim3(H), dim3(64), 0, st, lp);
+    }
+
+    // geometry: dR, dT
+    if (dinz.R || dinz.T) {
+        GeoParams gp{};
+        gp.prob = *p; gp.chunks_per_ray = cpr; gp.geo_chunk = sc.geo_chunk; gp.csum = sc.csum;
+        gp.part = sc.geo_part; gp.blocks_per_image = sc.geo_blocks;
+        hipLaunchKernelGGL(geo_kernel, dim3(sc.geo_blocks, p->batch), dim3(256), 0, st, gp);
+        hipLaunchKernelGGL(geo_final_kernel, dim3(p->batch), dim3(64), 0, st, sc.geo_part, sc.geo_blocks, dinz.R, dinz.T);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("gnr_bwd: launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
 }  // namespace gnr
