@@ -88,6 +88,7 @@ size_t carve_fwd(const GnrProblem* p, int n_streams, bool save, char* base, FwdP
             w.act_y1 = take(M * H2);
             w.act_feat = take(M * FEAT_PAD);
             w.sigma_raw = take(M);
+            w.relu_bits = (unsigned*)take((size_t)9 * n_chunks * 6 * 64);
         }
         if (fp) fp->ws[s] = w;
     }

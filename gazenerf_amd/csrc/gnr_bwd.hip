@@ -16,11 +16,11 @@
 namespace gnr {
 int fail(const char* fmt, ...);
 size_t carve_fwd(const GnrProblem* p, int n_streams, bool save, char* base, FwdParams* fp);
-size_t wgrad_partial_floats(long M, int n_valid, int k_valid, int* splits_out);
-void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, long M,
-                  float* dW, int ldw, int col_off, int enc_map, float* partial, hipStream_t stream);
-void launch_colsum(const float* Y, int ld, int C, int batch, long rows_per_image, float* out, int out_ld,
-                   float* part, hipStream_t stream);
+size_t wgrad_scratch_floats();
+void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, int batch,
+                  long chunks_per_image, float* dW, int ldw, int col_off, int enc_map, float* colsum_out,
+                  int colsum_ld, const float* vec, float* vec_out, float* scratch, hipStream_t stream);
+void launch_vecsum(const float* v, int batch, long per_image, float* out, int out_stride, hipStream_t stream);
 extern thread_local hipEvent_t g_ev_start, g_ev_stop;
 
 // ---------------------------------------------------------------------------------------------
@@ -122,13 +122,14 @@ struct CompBwdParams {
     float* wglob;             // [M]  w_i
     float* dsig;              // [M]  dL/dsigma_raw_i
     float* csum;              // [rays] sum_i dL/ddelta_i * delta_i
+    float* dsig_ray;          // [rays] sum_i dL/dsigma_raw_i  (density bias gradient)
     int accumulate;
 };
 
 constexpr int CB_MAX = 512;
 
 __global__ __launch_bounds__(256) void comp_bwd_kernel(const CompBwdParams cp) {
-    __shared__ float sh_q[4][CB_MAX], sh_x[4][CB_MAX], sh_T[4][CB_MAX], sh_S[4][CB_MAX];
+    __shared__ float sh_q[4][CB_MAX], sh_x[4][CB_MAX], sh_T[4][CB_MAX], sh_S[4][CB_MAX], sh_g[4][FEAT_PAD];
     const GnrProblem& p = cp.prob;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long n_rays_total = (long)p.batch * p.n_rays;
@@ -138,29 +139,24 @@ __global__ __launch_bounds__(256) void comp_bwd_kernel(const CompBwdParams cp) {
     float* q = sh_q[wave]; float* xx = sh_x[wave]; float* TT = sh_T[wave]; float* SS = sh_S[wave];
     const long row0 = live ? ray * cpr * CHUNK : 0;       // padded rows of this ray are contiguous
 
-    float g[5];
-#pragma unroll
-    for (int m = 0; m < 5; ++m) {
-        const int c = lane + 64 * m;
-        g[m] = (live && c < FEAT_PAD) ? cp.gT[ray * FEAT_PAD + c] : 0.0f;
-    }
+    // q_i = g . feat_i - g_bg: the features are CCM ([chunk][288][32]), so a lane owns one sample and
+    // walks the channels; each load instruction covers two full 128-byte rows (two chunks).
+    float* gsh = sh_g[wave];
+    if (live)
+        for (int c = lane; c < FEAT_PAD; c += 64) gsh[c] = cp.gT[ray * FEAT_PAD + c];
     const float gbg = (live && cp.g_bg) ? cp.g_bg[ray] : 0.0f;
+    __syncthreads();
     if (live) {
-        for (int i = 0; i < np; ++i) {
-            const float* fr = cp.act_feat + (row0 + i) * FEAT_PAD;
-            float v = 0.0f;
-#pragma unroll
-            for (int m = 0; m < 5; ++m) {
-                const int c = lane + 64 * m;
-                if (c < FEAT_PAD) v = fmaf(fr[c], g[m], v);
+        for (int i = lane; i < cpr * CHUNK; i += 64) {
+            const float* fr = cp.act_feat + (row0 / CHUNK + i / CHUNK) * (long)(CHUNK * FEAT_PAD) + (i % CHUNK);
+            float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+            for (int n = 0; n < FEAT_PAD; n += 4) {
+                v0 = fmaf(fr[(n + 0) * CHUNK], gsh[n + 0], v0);
+                v1 = fmaf(fr[(n + 1) * CHUNK], gsh[n + 1], v1);
+                v2 = fmaf(fr[(n + 2) * CHUNK], gsh[n + 2], v2);
+                v3 = fmaf(fr[(n + 3) * CHUNK], gsh[n + 3], v3);
             }
-            v += __shfl_xor(v, 32);
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 8);
-            v += __shfl_xor(v, 4);
-            v += __shfl_xor(v, 2);
-            v += __shfl_xor(v, 1);
-            if (lane == 0) q[i] = v - gbg;
+            if (i < np) q[i] = ((v0 + v1) + (v2 + v3)) - gbg;
         }
     }
     __syncthreads();
@@ -192,7 +188,7 @@ __global__ __launch_bounds__(256) void comp_bwd_kernel(const CompBwdParams cp) {
         for (int i = np - 1; i >= 0; --i) { const float t = SS[i]; SS[i] = S; S += t; }
     }
     __syncthreads();
-    float cs = 0.0f;
+    float cs = 0.0f, dsum = 0.0f;
     if (live) {
         for (int i = lane; i < np; i += 64) {
             const float sr = cp.sigma_raw[row0 + i];
@@ -202,7 +198,9 @@ __global__ __launch_bounds__(256) void comp_bwd_kernel(const CompBwdParams cp) {
             const float alpha = 1.0f - e;
             const float dalpha = q[i] * TT[i] - SS[i] / xx[i];
             cp.wglob[row0 + i] = alpha * TT[i];
-            cp.dsig[row0 + i] = sr > 0.0f ? dalpha * dl * e : 0.0f;
+            const float dsr = sr > 0.0f ? dalpha * dl * e : 0.0f;
+            cp.dsig[row0 + i] = dsr;
+            dsum += dsr;
             cs = fmaf(dalpha * sg * e, dl, cs);
         }
         // padded tail rows (i >= np) carry no gradient
@@ -214,7 +212,16 @@ __global__ __launch_bounds__(256) void comp_bwd_kernel(const CompBwdParams cp) {
     cs += __shfl_xor(cs, 4);
     cs += __shfl_xor(cs, 2);
     cs += __shfl_xor(cs, 1);
-    if (live && lane == 0) cp.csum[ray] = cp.accumulate ? cp.csum[ray] + cs : cs;
+    dsum += __shfl_xor(dsum, 32);
+    dsum += __shfl_xor(dsum, 16);
+    dsum += __shfl_xor(dsum, 8);
+    dsum += __shfl_xor(dsum, 4);
+    dsum += __shfl_xor(dsum, 2);
+    dsum += __shfl_xor(dsum, 1);
+    if (live && lane == 0) {
+        cp.csum[ray] = cp.accumulate ? cp.csum[ray] + cs : cs;
+        cp.dsig_ray[ray] = dsum;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -229,9 +236,8 @@ struct BwdParams {
     const float* gT;          // [rays][288]
     const float* wglob;       // [M]
     const float* dsig;        // [M]
-    const float* act_h;       // [8][M][H]
-    const float* act_y1;      // [M][H2]
-    const float* enc;         // [M][64]
+    const unsigned* relu_bits;  // [9][n_chunks][6][64]
+    const float* enc;         // [M][64] CCM
     const float* zval;        // [M]
     float* dY_h;              // [8][M][H]
     float* dY_r0;             // [M][H]
@@ -247,30 +253,6 @@ __device__ __forceinline__ void zero_tiles(f32x16 (&acc)[NT_H]) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-}
-
-// ReLU mask from the saved post-activation (h > 0), then dump dY row-major
-template <int NT>
-__device__ __forceinline__ void mask_dump(f32x16 (&acc)[NT_H], const float* __restrict__ act,
-                                          float* __restrict__ dY, int C, long row, int h) {
-    const float* ab = act + row * C + 4 * h;
-    float* db = dY + row * C + 4 * h;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            const f32x4 a4 = *(const f32x4*)(ab + 32 * t + 8 * rq);
-            f32x4 v;
-            v.x = a4.x > 0.0f ? acc[t][4 * rq + 0] : 0.0f;
-            v.y = a4.y > 0.0f ? acc[t][4 * rq + 1] : 0.0f;
-            v.z = a4.z > 0.0f ? acc[t][4 * rq + 2] : 0.0f;
-            v.w = a4.w > 0.0f ? acc[t][4 * rq + 3] : 0.0f;
-            acc[t][4 * rq + 0] = v.x;
-            acc[t][4 * rq + 1] = v.y;
-            acc[t][4 * rq + 2] = v.z;
-            acc[t][4 * rq + 3] = v.w;
-            *(f32x4*)(db + 32 * t + 8 * rq) = v;
-        }
 }
 
 // d(encoding) held as a 2-tile C/D register file (lane-half h owns the slots it encoded) -> d(pts).
@@ -289,7 +271,7 @@ __device__ __forceinline__ void enc_backward(const f32x16 (&E)[NT_H], const floa
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const int si = 2 + 6 * fl + a, ci = si + 3;
-            const float sv = enc_row[2 * si + h], cv = enc_row[2 * ci + h];
+            const float sv = enc_row[(2 * si + h) * CHUNK], cv = enc_row[(2 * ci + h) * CHUNK];
             acc3[a] = scale * (cv * d[si] - sv * d[ci]);
         }
         ax += acc3[0]; ay += acc3[1]; az += acc3[2];
@@ -310,7 +292,7 @@ __global__ __launch_bounds__(256, 1) void bwd_chain_kernel(const BwdParams bp) {
     const long M = bp.M;
     const f32x4* PT = (const f32x4*)bp.packedT;
     auto Pb = [&](int l) { return PT + bl_offset(l) / 4; };
-    const float* enc_row = bp.enc + row * ENC_PAD;
+    const float* enc_row = bp.enc + chunk * (CHUNK * ENC_PAD) + j;     // CCM: slot stride 32
 
     f32x16 A[NT_H], Bv[NT_H];
     float gx = 0.0f, gy = 0.0f, gz = 0.0f;
@@ -319,28 +301,31 @@ __global__ __launch_bounds__(256, 1) void bwd_chain_kernel(const BwdParams bp) {
     {
         const float w = bp.wglob[row];
         const float* gr = bp.gT + ray_g * FEAT_PAD + 4 * h;
-        float* df = bp.dfeat + row * FEAT_PAD + 4 * h;
 #pragma unroll
         for (int t = 0; t < NT_F; ++t)
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
                 const f32x4 g4 = *(const f32x4*)(gr + 32 * t + 8 * rq);
-                const f32x4 v = {w * g4.x, w * g4.y, w * g4.z, w * g4.w};
-                A[t][4 * rq + 0] = v.x; A[t][4 * rq + 1] = v.y; A[t][4 * rq + 2] = v.z; A[t][4 * rq + 3] = v.w;
-                *(f32x4*)(df + 32 * t + 8 * rq) = v;
+                A[t][4 * rq + 0] = w * g4.x; A[t][4 * rq + 1] = w * g4.y;
+                A[t][4 * rq + 2] = w * g4.z; A[t][4 * rq + 3] = w * g4.w;
             }
     }
-    // RGB2^T: A(9) -> Bv(6), mask y1 > 0
+    unsigned mk[RELU_WORDS];
+    auto bits = [&](int layer) { return bp.relu_bits + relu_bits_offset(layer, bp.n_chunks, chunk); };
+    auto dyh = [&](int l) { return dump_ptr(bp.dY_h + l * M * H, H, chunk, j, h); };
+    // Each mm_h dumps ITS INPUT (the dY of the layer above) while its MFMAs run.
+    // RGB2^T: A(9) -> Bv(6), mask y1 > 0            (dumps dfeat)
+    load_relu_bits<NT_H2>(mk, bits(8), lane);
     zero_tiles<NT_H2>(Bv);
-    mm_h<NT_F, NT_H2>(A, Bv, Pb(0), lane);
-    mask_dump<NT_H2>(Bv, bp.act_y1, bp.dY_r1, H2, row, h);
-    // RGB1^T: Bv(6) -> A(12), no activation on y0
+    mm_h<NT_F, NT_H2, true>(A, Bv, Pb(0), lane, dump_ptr(bp.dfeat, FEAT_PAD, chunk, j, h));
+    apply_relu_bits<NT_H2>(Bv, mk);
+    // RGB1^T: Bv(6) -> A(12), no activation on y0   (dumps dY_r1)
     zero_tiles<NT_H>(A);
-    mm_h<NT_H2, NT_H>(Bv, A, Pb(1), lane);
-    dump<NT_H>(A, bp.dY_r0, H, row, h);
-    // RGB0^T: A -> Bv, + density head, mask h7
+    mm_h<NT_H2, NT_H, true>(Bv, A, Pb(1), lane, dump_ptr(bp.dY_r1, H2, chunk, j, h));
+    // RGB0^T: A -> Bv, + density head, mask h7      (dumps dY_r0)
+    load_relu_bits<NT_H>(mk, bits(7), lane);
     zero_tiles<NT_H>(Bv);
-    mm_h<NT_H, NT_H>(A, Bv, Pb(2), lane);
+    mm_h<NT_H, NT_H, true>(A, Bv, Pb(2), lane, dump_ptr(bp.dY_r0, H, chunk, j, h));
     {
         const float ds = bp.dsig[row];
 #pragma unroll
@@ -354,35 +339,40 @@ __global__ __launch_bounds__(256, 1) void bwd_chain_kernel(const BwdParams bp) {
                 Bv[t][4 * rq + 3] = fmaf(w4.w, ds, Bv[t][4 * rq + 3]);
             }
     }
-    mask_dump<NT_H>(Bv, bp.act_h + 7 * M * H, bp.dY_h + 7 * M * H, H, row, h);
-    // L7^T: Bv -> A mask h6 ; L6^T: A -> Bv mask h5
+    apply_relu_bits<NT_H>(Bv, mk);
+    // L7^T: Bv -> A mask h6 (dumps dY_7); L6^T: A -> Bv mask h5 (dumps dY_6)
+    load_relu_bits<NT_H>(mk, bits(6), lane);
     zero_tiles<NT_H>(A);
-    mm_h<NT_H, NT_H>(Bv, A, Pb(3), lane);
-    mask_dump<NT_H>(A, bp.act_h + 6 * M * H, bp.dY_h + 6 * M * H, H, row, h);
+    mm_h<NT_H, NT_H, true>(Bv, A, Pb(3), lane, dyh(7));
+    apply_relu_bits<NT_H>(A, mk);
+    load_relu_bits<NT_H>(mk, bits(5), lane);
     zero_tiles<NT_H>(Bv);
-    mm_h<NT_H, NT_H>(A, Bv, Pb(4), lane);
-    mask_dump<NT_H>(Bv, bp.act_h + 5 * M * H, bp.dY_h + 5 * M * H, H, row, h);
-    // L5: encoding columns first (2 tiles, A is dead here), then the hidden columns -> A mask h4
+    mm_h<NT_H, NT_H, true>(A, Bv, Pb(4), lane, dyh(6));
+    apply_relu_bits<NT_H>(Bv, mk);
+    // L5: encoding columns first (2 tiles, A is dead here; dumps dY_5), then the hidden columns -> A mask h4
     zero_tiles<2>(A);
-    mm_h<NT_H, 2>(Bv, A, Pb(6), lane);
+    mm_h<NT_H, 2, true>(Bv, A, Pb(6), lane, dyh(5));
     enc_backward(A, enc_row, h, gx, gy, gz);
+    load_relu_bits<NT_H>(mk, bits(4), lane);
     zero_tiles<NT_H>(A);
     mm_h<NT_H, NT_H>(Bv, A, Pb(5), lane);
-    mask_dump<NT_H>(A, bp.act_h + 4 * M * H, bp.dY_h + 4 * M * H, H, row, h);
-    // L4^T..L1^T
+    apply_relu_bits<NT_H>(A, mk);
+    // L4^T..L1^T (dump dY_4 .. dY_1)
 #pragma unroll 1
     for (int rep = 0; rep < 2; ++rep) {
         const int la = 3 - 2 * rep, lb = 2 - 2 * rep;      // outputs dY_3, dY_2 then dY_1, dY_0
+        load_relu_bits<NT_H>(mk, bits(la), lane);
         zero_tiles<NT_H>(Bv);
-        mm_h<NT_H, NT_H>(A, Bv, PT + (bl_offset(7) + (size_t)(2 * rep) * bl_floats(7)) / 4, lane);
-        mask_dump<NT_H>(Bv, bp.act_h + la * M * H, bp.dY_h + la * M * H, H, row, h);
+        mm_h<NT_H, NT_H, true>(A, Bv, PT + (bl_offset(7) + (size_t)(2 * rep) * bl_floats(7)) / 4, lane, dyh(la + 1));
+        apply_relu_bits<NT_H>(Bv, mk);
+        load_relu_bits<NT_H>(mk, bits(lb), lane);
         zero_tiles<NT_H>(A);
-        mm_h<NT_H, NT_H>(Bv, A, PT + (bl_offset(7) + (size_t)(2 * rep + 1) * bl_floats(7)) / 4, lane);
-        mask_dump<NT_H>(A, bp.act_h + lb * M * H, bp.dY_h + lb * M * H, H, row, h);
+        mm_h<NT_H, NT_H, true>(Bv, A, PT + (bl_offset(7) + (size_t)(2 * rep + 1) * bl_floats(7)) / 4, lane, dyh(lb + 1));
+        apply_relu_bits<NT_H>(A, mk);
     }
-    // L0: encoding columns from dY_0 (in A)
+    // L0: encoding columns from dY_0 (in A; dumps dY_0)
     zero_tiles<2>(Bv);
-    mm_h<NT_H, 2>(A, Bv, Pb(11), lane);
+    mm_h<NT_H, 2, true>(A, Bv, Pb(11), lane, dyh(0));
     enc_backward(Bv, enc_row, h, gx, gy, gz);
 
     // chunk partials for the geometry gradient: sum dpts, sum z * dpts
@@ -553,7 +543,7 @@ __global__ void latent_weights_kernel(const LatentParams lp) {
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct BwdScratch {
-    float *packedT, *gT, *wglob, *dsig, *dY_h, *dY_r0, *dY_r1, *dfeat, *geo_chunk, *csum, *geo_part;
+    float *dsig_ray, *packedT, *gT, *wglob, *dsig, *dY_h, *dY_r0, *dY_r1, *dfeat, *geo_chunk, *csum, *geo_part;
     float *dbias, *cs_part, *wg_part;
     int geo_blocks;
 };
@@ -579,12 +569,12 @@ static size_t carve_bwd(const GnrProblem* p, char* base, BwdScratch* sc) {
     s.dfeat = take(M * FEAT_PAD);
     s.geo_chunk = take(n_chunks * 8);
     s.csum = take(n_rays_total);
+    s.dsig_ray = take(n_rays_total);
     s.geo_blocks = (p->n_rays + 255) / 256;
     s.geo_part = take((size_t)p->batch * s.geo_blocks * 12);
     s.dbias = take((size_t)(N_CHAIN + 1) * p->batch * H);
-    s.cs_part = take((size_t)p->batch * 512 * H);
-    const size_t wg = (size_t)1024 * 128 * 128;      // splits * tiles <= 1024 partial tiles (gnr_wgrad.hip)
-    s.wg_part = take(wg);
+    s.cs_part = nullptr;
+    s.wg_part = take(wgrad_scratch_floats());
     if (sc) *sc = s;
     return off;
 }
@@ -628,7 +618,7 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         CompBwdParams cb{};
         cb.prob = *p; cb.chunks_per_ray = cpr; cb.gT = sc.gT; cb.g_bg = dout->bg_alpha[s];
         cb.act_feat = ws.act_feat; cb.sigma_raw = ws.sigma_raw; cb.delta = fp.delta;
-        cb.wglob = sc.wglob; cb.dsig = sc.dsig; cb.csum = sc.csum; cb.accumulate = s > 0;
+        cb.wglob = sc.wglob; cb.dsig = sc.dsig; cb.csum = sc.csum; cb.dsig_ray = sc.dsig_ray; cb.accumulate = s > 0;
         hipLaunchKernelGGL(comp_bwd_kernel, dim3((unsigned)((n_rays_total + 3) / 4)), dim3(256), 0, st, cb);
         // 3. transposed weight stream
         PackTParams pt{};
@@ -653,7 +643,7 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         BwdParams bp{};
         bp.prob = *p; bp.chunks_per_ray = cpr; bp.n_chunks = fp.n_chunks; bp.M = M;
         bp.packedT = sc.packedT; bp.wsig = ws.wsig; bp.gT = sc.gT; bp.wglob = sc.wglob; bp.dsig = sc.dsig;
-        bp.act_h = ws.act_h; bp.act_y1 = ws.act_y1; bp.enc = fp.enc; bp.zval = fp.zval;
+        bp.relu_bits = ws.relu_bits; bp.enc = fp.enc; bp.zval = fp.zval;
         bp.dY_h = sc.dY_h; bp.dY_r0 = sc.dY_r0; bp.dY_r1 = sc.dY_r1; bp.dfeat = sc.dfeat;
         bp.geo_chunk = sc.geo_chunk; bp.accumulate_geo = s > 0;
         if (g_ev_start && s == 0) hipEventRecord(g_ev_start, st);
@@ -661,32 +651,36 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
                            dim3(256), 0, st, bp);
         if (g_ev_stop && s == 0) hipEventRecord(g_ev_stop, st);
 
-        // 5. weight gradients  dW = dY^T X
+        // 5. weight gradients dW = dY^T X; the same kernels emit the per-image column sums of dY
+        //    (bias / latent gradients) and, for RGB_layer_0, the density-head gradient dsig^T h7.
         const float* hact = ws.act_h;
         auto hptr = [&](int l) { return hact + (size_t)l * M * H; };
         auto dyh = [&](int l) { return sc.dY_h + (size_t)l * M * H; };
-        if (DW.rgb_w[2]) launch_wgrad(sc.dfeat, FEAT_PAD, p->feat_nc, ws.act_y1, H2, H2, M, DW.rgb_w[2], H2, 0, 0, sc.wg_part, st);
-        if (DW.rgb_w[1]) launch_wgrad(sc.dY_r1, H2, H2, ws.act_y0, H, H, M, DW.rgb_w[1], H + p->appea_dims, 0, 0, sc.wg_part, st);
-        if (DW.rgb_w[0]) launch_wgrad(sc.dY_r0, H, H, hptr(7), H, H, M, DW.rgb_w[0], H, 0, 0, sc.wg_part, st);
-        if (DW.density_w) launch_wgrad(sc.dsig, 1, 1, hptr(7), H, H, M, DW.density_w, H, 0, 0, sc.wg_part, st);
+        auto dbl = [&](int l) { return sc.dbias + (size_t)l * p->batch * H; };
+        const long cpi = (long)p->n_rays * cpr;                       // chunks per image
+        launch_wgrad(sc.dfeat, FEAT_PAD, p->feat_nc, ws.act_y1, H2, H2, p->batch, cpi, DW.rgb_w[2], H2, 0, 0,
+                     dbl(LR2), H, nullptr, nullptr, sc.wg_part, st);
+        launch_wgrad(sc.dY_r1, H2, H2, ws.act_y0, H, H, p->batch, cpi, DW.rgb_w[1], H + p->appea_dims, 0, 0,
+                     dbl(LR1), H, nullptr, nullptr, sc.wg_part, st);
+        launch_wgrad(sc.dY_r0, H, H, hptr(7), H, H, p->batch, cpi, DW.rgb_w[0], H, 0, 0, dbl(LR0), H,
+                     sc.dsig, DW.density_w, sc.wg_part, st);
         for (int l = 7; l >= 1; --l) {
-            if (!DW.fea_w[l]) continue;
             if (l == 5) {
-                launch_wgrad(dyh(5), H, H, hptr(4), H, H, M, DW.fea_w[5], vp + H, vp, 0, sc.wg_part, st);
-                launch_wgrad(dyh(5), H, H, fp.enc, ENC_PAD, ENC_PAD, M, DW.fea_w[5], vp + H, 0, 1, sc.wg_part, st);
+                launch_wgrad(dyh(5), H, H, hptr(4), H, H, p->batch, cpi, DW.fea_w[5], vp + H, vp, 0, dbl(5), H,
+                             nullptr, nullptr, sc.wg_part, st);
+                if (DW.fea_w[5])
+                    launch_wgrad(dyh(5), H, H, fp.enc, ENC_PAD, ENC_PAD, p->batch, cpi, DW.fea_w[5], vp + H, 0, 1,
+                                 nullptr, 0, nullptr, nullptr, sc.wg_part, st);
             } else {
-                launch_wgrad(dyh(l), H, H, hptr(l - 1), H, H, M, DW.fea_w[l], H, 0, 0, sc.wg_part, st);
+                launch_wgrad(dyh(l), H, H, hptr(l - 1), H, H, p->batch, cpi, DW.fea_w[l], H, 0, 0, dbl(l), H,
+                             nullptr, nullptr, sc.wg_part, st);
             }
         }
-        if (DW.fea_w[0]) launch_wgrad(dyh(0), H, H, fp.enc, ENC_PAD, ENC_PAD, M, DW.fea_w[0], vp, 0, 1, sc.wg_part, st);
+        launch_wgrad(dyh(0), H, H, fp.enc, ENC_PAD, ENC_PAD, p->batch, cpi, DW.fea_w[0], vp, 0, 1, dbl(0), H,
+                     nullptr, nullptr, sc.wg_part, st);
+        launch_vecsum(sc.dsig_ray, p->batch, p->n_rays, dbl(N_CHAIN), H, st);
 
-        // 6. per-image bias sums, latent gradients
-        for (int l = 0; l < 8; ++l)
-            launch_colsum(dyh(l), H, H, p->batch, rows_per_image, sc.dbias + (size_t)l * p->batch * H, H, sc.cs_part, st);
-        launch_colsum(sc.dY_r0, H, H, p->batch, rows_per_image, sc.dbias + (size_t)LR0 * p->batch * H, H, sc.cs_part, st);
-        launch_colsum(sc.dY_r1, H2, H2, p->batch, rows_per_image, sc.dbias + (size_t)LR1 * p->batch * H, H, sc.cs_part, st);
-        launch_colsum(sc.dfeat, FEAT_PAD, FEAT_PAD, p->batch, rows_per_image, sc.dbias + (size_t)LR2 * p->batch * H, H, sc.cs_part, st);
-        launch_colsum(sc.dsig, 1, 1, p->batch, rows_per_image, sc.dbias + (size_t)N_CHAIN * p->batch * H, H, sc.cs_part, st);
+        // 6. latent gradients from the per-image bias sums
         LatentParams lp{};
         lp.prob = *p; lp.w = W; lp.dw = DW; lp.dbias = sc.dbias;
         lp.dshape = dinz.shape_code; lp.dgaze = dinz.gaze; lp.dappea = dinz.appea_code; lp.accumulate = s > 0;

@@ -16,10 +16,15 @@ namespace gnr {
 constexpr int RING = 8;
 
 // ---- one dense layer: acc[nt] += sum over the channels held in hin[0..NT_IN) --------------------
-template <int NT_IN, int NT_OUT>
+// If `dump_base` is non-null the layer also writes its INPUT registers (the previous layer's output)
+// to HBM in the CCM layout, one or two 4-byte stores per weight row, so that the activation dump of
+// the training forward / the dY dump of the backward trickles out under the MFMAs instead of hitting
+// HBM as a chip-wide burst at every layer boundary.  dump_base = dst + chunk*32*C + 4h*32 + j.
+template <int NT_IN, int NT_OUT, bool DUMP = false>
 __device__ __forceinline__ void mm_h(const f32x16 (&hin)[NT_H], f32x16 (&acc)[NT_H],
-                                     const f32x4* __restrict__ P, int lane) {
+                                     const f32x4* __restrict__ P, int lane, float* __restrict__ dump_base = nullptr) {
     constexpr int NROW = NT_IN * 4 * NT_OUT;        // (k-group, n-tile) rows, k-group outer
+    constexpr int NREG = NT_IN * 16;                // input registers to dump
     const f32x4* Pl = P + lane;
     f32x4 ring[RING];
 #pragma unroll
@@ -36,6 +41,13 @@ __device__ __forceinline__ void mm_h(const f32x16 (&hin)[NT_H], f32x16 (&acc)[NT
                 acc[nt] = mfma32(ring[i % RING].z, hin[t][4 * rq + 2], acc[nt]);
                 acc[nt] = mfma32(ring[i % RING].w, hin[t][4 * rq + 3], acc[nt]);
                 if (i + RING < NROW) ring[i % RING] = Pl[(i + RING) * 64];
+                if (DUMP) {
+#pragma unroll
+                    for (int q = (i * NREG) / NROW; q < ((i + 1) * NREG) / NROW; ++q) {
+                        const int dt = q >> 4, dr = q & 15;
+                        dump_base[(32 * dt + (dr & 3) + 8 * (dr >> 2)) * CHUNK] = hin[dt][dr];
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -93,18 +105,58 @@ __device__ __forceinline__ void relu(f32x16 (&acc)[NT_H]) {
         for (int r = 0; r < 16; ++r) acc[t][r] = fmaxf(acc[t][r], 0.0f);
 }
 
-// row-major [M][C] dump of a register tile set (16 B per lane; used by the training forward)
+// Chunk-channel-major ("CCM") dump of a register tile set: element (chunk c, channel n, sample j)
+// lives at c*32*C + n*32 + j.  Register r of tile t is one channel per lane-half, so every store /
+// load instruction moves two full 128-byte segments (32 samples x 4 B per half-wave), and the
+// wgrad kernel can read a lane's 16 consecutive samples of one channel as 4 float4.
 template <int NT>
 __device__ __forceinline__ void dump(const f32x16 (&acc)[NT_H], float* __restrict__ dst, int C,
-                                     long row, int h) {
-    float* base = dst + row * C + 4 * h;
+                                     long chunk, int j, int h) {
+    float* base = dst + chunk * (CHUNK * (long)C) + (4 * h) * CHUNK + j;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            f32x4 v = {acc[t][4 * rq], acc[t][4 * rq + 1], acc[t][4 * rq + 2], acc[t][4 * rq + 3]};
-            *(f32x4*)(base + 32 * t + 8 * rq) = v;
-        }
+        for (int r = 0; r < 16; ++r) base[(32 * t + (r & 3) + 8 * (r >> 2)) * CHUNK] = acc[t][r];
+}
+
+__device__ __forceinline__ float* dump_ptr(float* dst, int C, long chunk, int j, int h) {
+    return dst + chunk * (CHUNK * (long)C) + (4 * h) * CHUNK + j;
+}
+
+// ReLU masks as bits: lane l keeps the signs of its own registers, tile pair (2w, 2w+1) -> word w,
+// bit 16*(t&1) + r.  Stored lane-major ([word][64 lanes]) so a wave moves 256 contiguous bytes per word.
+constexpr int RELU_WORDS = NT_H / 2;     // 6
+__host__ __device__ constexpr size_t relu_bits_offset(int layer, long n_chunks, long chunk) {
+    return ((size_t)layer * n_chunks + chunk) * RELU_WORDS * 64;
+}
+
+template <int NT>
+__device__ __forceinline__ void store_relu_bits(const f32x16 (&acc)[NT_H], unsigned* __restrict__ dst, int lane) {
+#pragma unroll
+    for (int w = 0; w < NT / 2; ++w) {
+        unsigned bits = 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bits |= (acc[2 * w + q][r] > 0.0f ? 1u : 0u) << (16 * q + r);
+        dst[w * 64 + lane] = bits;
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void load_relu_bits(unsigned (&mk)[RELU_WORDS], const unsigned* __restrict__ src, int lane) {
+#pragma unroll
+    for (int w = 0; w < NT / 2; ++w) mk[w] = src[w * 64 + lane];
+}
+
+// zero the gradient where the forward activation was clamped
+template <int NT>
+__device__ __forceinline__ void apply_relu_bits(f32x16 (&acc)[NT_H], const unsigned (&mk)[RELU_WORDS]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc[t][r] = ((mk[t >> 1] >> (16 * (t & 1) + r)) & 1u) ? acc[t][r] : 0.0f;
 }
 
 }  // namespace gnr

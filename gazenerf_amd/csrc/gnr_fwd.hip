@@ -54,9 +54,10 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel(const FwdParams fp) {
 #pragma unroll
         for (int s = 0; s < ENC_STEPS; ++s) enc_col[s * 256] = e[s];
         if (SAVE) {
-            // [M][64] in our k-order: channel slot 2*step + h
+            // CCM [chunk][64][32] in our k-order: channel slot 2*step + h
 #pragma unroll
-            for (int s = 0; s < ENC_STEPS; ++s) fp.enc[row * ENC_PAD + 2 * s + h] = e[s];
+            for (int s = 0; s < ENC_STEPS; ++s)
+                fp.enc[chunk * (CHUNK * ENC_PAD) + (2 * s + h) * CHUNK + j] = e[s];
             if (h == 0) {
                 fp.delta[row] = delta;
                 fp.zval[row] = z0;
@@ -78,42 +79,49 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel(const FwdParams fp) {
         auto Pl = [&](int l) { return Pk + packed_offset(l) / 4; };
         float* acth = ws.act_h;
 
+        auto dp = [&](float* dst, int C) -> float* { return SAVE ? dump_ptr(dst, C, chunk, j, h) : nullptr; };
+        auto sb = [&](int layer) { return ws.relu_bits + relu_bits_offset(layer, fp.n_chunks, chunk); };
+        // Every layer's output is dumped (training forward) by the NEXT layer's mm_h, spread over its
+        // MFMA loop; only the sign bits are written at the layer boundary.
+
         // L0: enc -> A
         init_bias<NT_H>(A, bias_b + 0 * bstride, h);
         mm_enc<NT_H>(enc_col, A, Pl(0), lane);
         relu<NT_H>(A);
-        if (SAVE) dump<NT_H>(A, acth + 0 * fp.M * H, H, row, h);
+        if (SAVE) store_relu_bits<NT_H>(A, sb(0), lane);
 
-        // L1..L4: A -> Bv -> A -> Bv -> A
+        // L1..L4: A -> Bv -> A -> Bv -> A   (each mm_h dumps its input h_{l-1})
 #pragma unroll 1
         for (int rep = 0; rep < 2; ++rep) {
             const int la = 1 + 2 * rep, lb = 2 + 2 * rep;
             init_bias<NT_H>(Bv, bias_b + la * bstride, h);
-            mm_h<NT_H, NT_H>(A, Bv, Pk + (packed_offset(1) + (size_t)(la - 1) * layer_packed_floats(1)) / 4, lane);
+            mm_h<NT_H, NT_H, SAVE>(A, Bv, Pk + (packed_offset(1) + (size_t)(la - 1) * layer_packed_floats(1)) / 4, lane,
+                                   dp(acth + (la - 1) * fp.M * H, H));
             relu<NT_H>(Bv);
-            if (SAVE) dump<NT_H>(Bv, acth + la * fp.M * H, H, row, h);
+            if (SAVE) store_relu_bits<NT_H>(Bv, sb(la), lane);
             init_bias<NT_H>(A, bias_b + lb * bstride, h);
-            mm_h<NT_H, NT_H>(Bv, A, Pk + (packed_offset(1) + (size_t)(lb - 1) * layer_packed_floats(1)) / 4, lane);
+            mm_h<NT_H, NT_H, SAVE>(Bv, A, Pk + (packed_offset(1) + (size_t)(lb - 1) * layer_packed_floats(1)) / 4, lane,
+                                   dp(acth + (lb - 1) * fp.M * H, H));
             relu<NT_H>(A);
-            if (SAVE) dump<NT_H>(A, acth + lb * fp.M * H, H, row, h);
+            if (SAVE) store_relu_bits<NT_H>(A, sb(lb), lane);
         }
 
-        // L5: [enc | A] -> Bv   (skip connection, models/mlp_nerf.py:107)
+        // L5: [enc | A] -> Bv   (skip connection, models/mlp_nerf.py:107); dumps h4
         init_bias<NT_H>(Bv, bias_b + 5 * bstride, h);
         mm_enc<NT_H>(enc_col, Bv, Pl(5), lane);
-        mm_h<NT_H, NT_H>(A, Bv, Pl(5) + (size_t)ENC_STEPS * NT_H * 64 / 4, lane);
+        mm_h<NT_H, NT_H, SAVE>(A, Bv, Pl(5) + (size_t)ENC_STEPS * NT_H * 64 / 4, lane, dp(acth + 4 * fp.M * H, H));
         relu<NT_H>(Bv);
-        if (SAVE) dump<NT_H>(Bv, acth + 5 * fp.M * H, H, row, h);
+        if (SAVE) store_relu_bits<NT_H>(Bv, sb(5), lane);
 
-        // L6: Bv -> A, L7: A -> Bv
+        // L6: Bv -> A (dumps h5), L7: A -> Bv (dumps h6)
         init_bias<NT_H>(A, bias_b + 6 * bstride, h);
-        mm_h<NT_H, NT_H>(Bv, A, Pl(6), lane);
+        mm_h<NT_H, NT_H, SAVE>(Bv, A, Pl(6), lane, dp(acth + 5 * fp.M * H, H));
         relu<NT_H>(A);
-        if (SAVE) dump<NT_H>(A, acth + 6 * fp.M * H, H, row, h);
+        if (SAVE) store_relu_bits<NT_H>(A, sb(6), lane);
         init_bias<NT_H>(Bv, bias_b + 7 * bstride, h);
-        mm_h<NT_H, NT_H>(A, Bv, Pl(7), lane);
+        mm_h<NT_H, NT_H, SAVE>(A, Bv, Pl(7), lane, dp(acth + 6 * fp.M * H, H));
         relu<NT_H>(Bv);
-        if (SAVE) dump<NT_H>(Bv, acth + 7 * fp.M * H, H, row, h);
+        if (SAVE) store_relu_bits<NT_H>(Bv, sb(7), lane);
 
         // density head on h7 (models/mlp_nerf.py:109): 384-long dot, split over the two lane halves
         float sig = 0.0f;
@@ -131,19 +139,18 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel(const FwdParams fp) {
         sig += ws.wsig[H];
         if (SAVE && h == 0) ws.sigma_raw[row] = sig;
 
-        // RGB0: Bv -> A (no activation, mlp_nerf.py:110)
+        // RGB0: Bv -> A (no activation, mlp_nerf.py:110); dumps h7
         init_bias<NT_H>(A, bias_b + LR0 * bstride, h);
-        mm_h<NT_H, NT_H>(Bv, A, Pl(LR0), lane);
-        if (SAVE) dump<NT_H>(A, ws.act_y0, H, row, h);
-        // RGB1: A -> Bv[0..6) (+ folded appearance code), ReLU
+        mm_h<NT_H, NT_H, SAVE>(Bv, A, Pl(LR0), lane, dp(acth + 7 * fp.M * H, H));
+        // RGB1: A -> Bv[0..6) (+ folded appearance code), ReLU; dumps y0
         init_bias<NT_H2>(Bv, bias_b + LR1 * bstride, h);
-        mm_h<NT_H, NT_H2>(A, Bv, Pl(LR1), lane);
+        mm_h<NT_H, NT_H2, SAVE>(A, Bv, Pl(LR1), lane, dp(ws.act_y0, H));
         relu<NT_H2>(Bv);
-        if (SAVE) dump<NT_H2>(Bv, ws.act_y1, H2, row, h);
-        // RGB2: Bv[0..6) -> A[0..9)  (258 channels padded to 288; no sigmoid, mlp_nerf.py:116)
+        if (SAVE) store_relu_bits<NT_H2>(Bv, sb(8), lane);
+        // RGB2: Bv[0..6) -> A[0..9)  (258 channels padded to 288; no sigmoid, mlp_nerf.py:116); dumps y1
         init_bias<NT_F>(A, bias_b + LR2 * bstride, h);
-        mm_h<NT_H2, NT_F>(Bv, A, Pl(LR2), lane);
-        if (SAVE) dump<NT_F>(A, ws.act_feat, FEAT_PAD, row, h);
+        mm_h<NT_H2, NT_F, SAVE>(Bv, A, Pl(LR2), lane, dp(ws.act_y1, H2));
+        if (SAVE) dump<NT_F>(A, ws.act_feat, FEAT_PAD, chunk, j, h);
 
         // ---- A5: chunk-local compositing (utils/model_utils.py:498-534) ----
         const float sigma = fmaxf(sig, 0.0f);

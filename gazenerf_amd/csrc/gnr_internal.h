@@ -82,6 +82,7 @@ struct StreamWs {
     float* act_y1;        // [M][H2]    RGB_layer_1 output (post-ReLU)
     float* act_feat;      // [M][FEAT_PAD]
     float* sigma_raw;     // [M]
+    unsigned* relu_bits;  // [9][n_chunks][6][64]: sign bits of h0..h7, y1 in register order (lane-major)
 };
 
 struct FwdParams {

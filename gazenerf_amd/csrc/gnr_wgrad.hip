@@ -2,218 +2,293 @@
 //
 //   dW[n][k] = sum_s dY[s][n] * X[s][k]      (s over all M samples of the call)
 //
-// dY and X are the row-major [M][C] dumps of the dgrad chain / training forward.  This is a plain
-// "TN" GEMM whose contraction index is the sample: both MFMA operands want the sample on the
-// k-slot (lane>>5) and 32 consecutive channels across lanes, which is exactly a row segment of the
-// dumps -> coalesced global loads, conflict-free ds_read_b32.
+// dY and X are the chunk-channel-major ("CCM") dumps of the dgrad chain / training forward:
+// element (chunk c, channel n, sample j) at c*32*C + n*32 + j, so the [128 channels][32 samples]
+// operand tile of one chunk is ONE contiguous 16 KiB block: 256 threads stream it with four fully
+// coalesced float4 loads each.  The contraction index is the sample; its order is free, so lane-half
+// h of v_mfma_f32_32x32x2_f32 takes samples 16h..16h+15 of the chunk and a lane reads its operand
+// values for 4 consecutive MFMA steps with one ds_read_b128.  The LDS image keeps the 128-byte rows
+// but XORs the 16-byte piece index with (row/2)%8, which makes both the ds_write_b128 of the staging
+// pass and the ds_read_b128 of the MFMA pass bank-conflict free (MI355X LDS: 64 banks for b128,
+// non-contiguous 16-lane groups).
 //
-// Tiling: 128(n) x 128(k) per 256-thread workgroup, 2x2 waves of 64x64 (2x2 v_mfma_f32_32x32x2_f32
-// tiles, 64 accumulator registers), sample slabs of 32 double-buffered through LDS, the sample
-// range split over gridDim.z with per-split partial tiles summed in a fixed order by
-// wgrad_reduce_kernel (deterministic: the reference trains with cudnn.deterministic, train.py:57).
+// Tiling: 128(n) x 128(k) per 256-thread workgroup = 2x2 waves of 64x64 (2x2 MFMA tiles, 64
+// accumulator registers), chunks double-buffered through 64 KiB of LDS (next chunk's global loads
+// are in flight during the current chunk's 64 MFMAs per wave), two workgroups per CU.  The sample
+// range is split (per image) over workgroups; the 3x3 tiles of one split are placed on one XCD
+// back-to-back so the operand rows they share hit that XCD's L2.  Per-split partial tiles are summed
+// in a fixed order by wgrad_reduce_kernel (deterministic; the reference trains with
+// cudnn.deterministic, train.py:57).
+//
+// Riding along on otherwise idle VALU slots:
+//   * column sums of dY (bias gradients, per image)            -- waves with tile-k == 0
+//   * vec^T X for a per-sample vector (density-head gradient)  -- waves with tile-n == 0
 #include "gnr_device.h"
 
 namespace gnr {
 
-constexpr int WG_TN = 128, WG_TK = 128, WG_SLAB = 32, WG_LD = 132;   // LDS row stride (floats)
+constexpr int WG_TN = 128, WG_TK = 128;    // workgroup tile: 2x2 waves of 64x64
 
 struct WgradParams {
-    const float* A;      // dY [M][lda]
-    const float* B;      // X  [M][ldb]
+    const float* A;      // dY, CCM with C = lda
+    const float* B;      // X,  CCM with C = ldb
     int lda, ldb;
-    int n_valid, k_valid;     // columns of A / B that exist (others read as zero)
-    long M;
-    long rows_per_split;      // multiple of WG_SLAB
-    float* partial;           // [splits][tiles_n][tiles_k][128][128]
+    int n_valid, k_valid;
+    int tiles_n, tiles_k;
+    int batch, spi;               // splits per image
+    long chunks_per_image;
+    long chunks_per_split;
+    float* partial;               // [batch*spi][tiles_n][tiles_k][128][128]
+    float* colsum_part;           // [batch*spi][tiles_n*128]
+    const float* vec;             // [M] or NULL
+    float* vec_part;              // [batch*spi][tiles_k*128]
 };
 
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams wp) {
-    __shared__ float lds[2][2][WG_SLAB][WG_LD];      // [buffer][A/B][sample][channel]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave >> 1, wk = wave & 1;          // wave tile position (64x64 each)
-    const int tn = blockIdx.x, tk = blockIdx.y, sp = blockIdx.z;
-    const long s_begin = (long)sp * wp.rows_per_split;
-    long s_end = s_begin + wp.rows_per_split;
-    if (s_end > wp.M) s_end = wp.M;
-    const int n0 = tn * WG_TN, k0 = tk * WG_TK;
+// LDS position (in floats) of 16-byte piece `c` (0..7) of tile row `n` (0..127)
+__device__ __forceinline__ int swz(int n, int c) { return n * CHUNK + ((c ^ ((n >> 1) & 7)) << 2); }
 
-    // staging: thread loads 4 float4 of A and 4 of B per slab: row = q*8 + tid/32, col4 = tid%32
-    const int lr = tid >> 5, lc = (tid & 31) * 4;
+template <bool VEC>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams wp) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][WG_TN * CHUNK];     // [buffer][A/B][row*32 + sample]
+    // XCD-aware placement: workgroup id -> (xcd, slot); an XCD runs the tiles of one split back-to-back
+    const int tiles = wp.tiles_n * wp.tiles_k;
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int split = xcd + 8 * (slot / tiles);
+    const int tile = slot % tiles;
+    if (split >= wp.batch * wp.spi) return;
+    const int tn = tile / wp.tiles_k, tk = tile - tn * wp.tiles_k;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int b = split / wp.spi, sp = split - b * wp.spi;
+    const long c0 = (long)b * wp.chunks_per_image + (long)sp * wp.chunks_per_split;
+    long c1 = c0 + wp.chunks_per_split;
+    const long cmax = (long)(b + 1) * wp.chunks_per_image;
+    if (c1 > cmax) c1 = cmax;
+
+    // staging: float4 piece f = tid + 256 q: tile row f/8, piece f%8 (rows clamped into the buffer:
+    // rows/cols beyond it only feed outputs that are dropped)
+    const float* ga[4];
+    const float* gb[4];
+    int lpos[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int f = tid + 256 * q, r = f >> 3, c = f & 7;
+        int n = tn * WG_TN + r; if (n >= wp.lda) n = wp.lda - 1;
+        int k = tk * WG_TK + r; if (k >= wp.ldb) k = wp.ldb - 1;
+        ga[q] = wp.A + (long)n * CHUNK + 4 * c;
+        gb[q] = wp.B + (long)k * CHUNK + 4 * c;
+        lpos[q] = swz(r, c);
+    }
+    const long strideA = (long)CHUNK * wp.lda, strideB = (long)CHUNK * wp.ldb;
     f32x4 ra[4], rb[4];
-    auto gload = [&](long s0) {
+    auto gload = [&](long c) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const long s = s0 + q * 8 + lr;
-            f32x4 va = {0, 0, 0, 0}, vb = {0, 0, 0, 0};
-            if (s < s_end) {
-                const int ca = n0 + lc, cb = k0 + lc;
-                if (ca + 3 < wp.n_valid) va = *(const f32x4*)(wp.A + s * wp.lda + ca);
-                else {
-                    if (ca + 0 < wp.n_valid) va.x = wp.A[s * wp.lda + ca + 0];
-                    if (ca + 1 < wp.n_valid) va.y = wp.A[s * wp.lda + ca + 1];
-                    if (ca + 2 < wp.n_valid) va.z = wp.A[s * wp.lda + ca + 2];
-                }
-                if (cb + 3 < wp.k_valid) vb = *(const f32x4*)(wp.B + s * wp.ldb + cb);
-                else {
-                    if (cb + 0 < wp.k_valid) vb.x = wp.B[s * wp.ldb + cb + 0];
-                    if (cb + 1 < wp.k_valid) vb.y = wp.B[s * wp.ldb + cb + 1];
-                    if (cb + 2 < wp.k_valid) vb.z = wp.B[s * wp.ldb + cb + 2];
-                }
-            }
-            ra[q] = va;
-            rb[q] = vb;
+            ra[q] = *(const f32x4*)(ga[q] + c * strideA);
+            rb[q] = *(const f32x4*)(gb[q] + c * strideB);
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            *(f32x4*)&lds[buf][0][q * 8 + lr][lc] = ra[q];
-            *(f32x4*)&lds[buf][1][q * 8 + lr][lc] = rb[q];
+            *(f32x4*)&lds[buf][0][lpos[q]] = ra[q];
+            *(f32x4*)&lds[buf][1][lpos[q]] = rb[q];
         }
     };
 
     f32x16 acc[2][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int y = 0; y < 2; ++y)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.0f;
+    float cs[2] = {0.0f, 0.0f}, vs[2] = {0.0f, 0.0f};
+    const float* pv = VEC ? wp.vec + 16 * lh : nullptr;
 
-    const long n_slabs = (s_end - s_begin + WG_SLAB - 1) / WG_SLAB;
-    if (n_slabs > 0) {
-        gload(s_begin);
+    // operand read positions of this lane: rows wn*64 + 32x + li (A) / wk*64 + 32y + li (B), pieces 4lh + g
+    int apos[2][4], bpos[2][4];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            apos[x][g] = swz(wn * 64 + 32 * x + li, 4 * lh + g);
+            bpos[x][g] = swz(wk * 64 + 32 * x + li, 4 * lh + g);
+        }
+
+    if (c0 < c1) {
+        gload(c0);
         lstore(0);
     }
     __syncthreads();
-    const int li = lane & 31, lh = lane >> 5;
-    for (long sl = 0; sl < n_slabs; ++sl) {
-        const int buf = (int)(sl & 1);
-        if (sl + 1 < n_slabs) gload(s_begin + (sl + 1) * WG_SLAB);
+    for (long c = c0; c < c1; ++c) {
+        const int buf = (int)((c - c0) & 1);
+        if (c + 1 < c1) gload(c + 1);
+        f32x4 v4[4];
+        if (VEC) {
 #pragma unroll
-        for (int st = 0; st < WG_SLAB / 2; ++st) {
-            const int s = 2 * st + lh;
-            const float a0 = lds[buf][0][s][wn * 64 + li];
-            const float a1 = lds[buf][0][s][wn * 64 + 32 + li];
-            const float b0 = lds[buf][1][s][wk * 64 + li];
-            const float b1 = lds[buf][1][s][wk * 64 + 32 + li];
-            acc[0][0] = mfma32(a0, b0, acc[0][0]);
-            acc[0][1] = mfma32(a0, b1, acc[0][1]);
-            acc[1][0] = mfma32(a1, b0, acc[1][0]);
-            acc[1][1] = mfma32(a1, b1, acc[1][1]);
+            for (int g = 0; g < 4; ++g) v4[g] = *(const f32x4*)(pv + c * CHUNK + 4 * g);
         }
-        if (sl + 1 < n_slabs) lstore(buf ^ 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 a0 = *(const f32x4*)&lds[buf][0][apos[0][g]];
+            const f32x4 a1 = *(const f32x4*)&lds[buf][0][apos[1][g]];
+            const f32x4 b0 = *(const f32x4*)&lds[buf][1][bpos[0][g]];
+            const f32x4 b1 = *(const f32x4*)&lds[buf][1][bpos[1][g]];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][0] = mfma32(a0[e], b0[e], acc[0][0]);
+                acc[0][1] = mfma32(a0[e], b1[e], acc[0][1]);
+                acc[1][0] = mfma32(a1[e], b0[e], acc[1][0]);
+                acc[1][1] = mfma32(a1[e], b1[e], acc[1][1]);
+                cs[0] += a0[e];
+                cs[1] += a1[e];
+                if (VEC) {
+                    vs[0] = fmaf(v4[g][e], b0[e], vs[0]);
+                    vs[1] = fmaf(v4[g][e], b1[e], vs[1]);
+                }
+            }
+        }
+        if (c + 1 < c1) lstore(buf ^ 1);
         __syncthreads();
     }
-    // partial tile: row i (n) = (r&3) + 8(r>>2) + 4 lh, col j (k) = li
-    float* pt = wp.partial + (((long)sp * gridDim.x + tn) * gridDim.y + tk) * (WG_TN * WG_TK);
+
+    float* pt = wp.partial + (((long)split * wp.tiles_n + tn) * wp.tiles_k + tk) * (long)(WG_TN * WG_TK);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int y = 0; y < 2; ++y)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int i = wn * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int j = wk * 64 + b * 32 + li;
-                pt[i * WG_TK + j] = acc[a][b][r];
+                const int i = wn * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int jx = wk * 64 + y * 32 + li;
+                pt[i * WG_TK + jx] = acc[x][y][r];
             }
+    if (tk == 0 && wk == 0) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const float t = cs[x] + __shfl_xor(cs[x], 32);
+            if (lh == 0) wp.colsum_part[(long)split * (wp.tiles_n * WG_TN) + tn * WG_TN + wn * 64 + 32 * x + li] = t;
+        }
+    }
+    if (VEC && tn == 0 && wn == 0) {
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const float t = vs[y] + __shfl_xor(vs[y], 32);
+            if (lh == 0) wp.vec_part[(long)split * (wp.tiles_k * WG_TK) + tk * WG_TK + wk * 64 + 32 * y + li] = t;
+        }
+    }
 }
 
 struct WgradReduceParams {
     const float* partial;
     int splits, tiles_n, tiles_k;
     int n_valid, k_valid;
-    float* dW;          // destination matrix
+    float* dW;          // destination matrix (NULL: skip)
     int ldw, col_off;
     int enc_map;        // 1: column k is an encoding slot (2*step+h) -> reference channel
+    // optional extras
+    const float* colsum_part; float* colsum_out; int colsum_ld; int batch, spi;   // out[b][n]
+    const float* vec_part; float* vec_out;                                         // out[k]
 };
 
 __global__ void wgrad_reduce_kernel(const WgradReduceParams rp) {
-    const long total = (long)rp.tiles_n * WG_TN * rp.tiles_k * WG_TK;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int n = (int)(e / (rp.tiles_k * WG_TK)), k = (int)(e % (rp.tiles_k * WG_TK));
-        if (n >= rp.n_valid || k >= rp.k_valid) continue;
-        const int tn = n / WG_TN, i = n % WG_TN, tk = k / WG_TK, j = k % WG_TK;
-        float acc = 0.0f;
-        for (int sp = 0; sp < rp.splits; ++sp)
-            acc += rp.partial[(((long)sp * rp.tiles_n + tn) * rp.tiles_k + tk) * (WG_TN * WG_TK) + i * WG_TK + j];
-        int col = k;
-        if (rp.enc_map) {
-            col = enc_channel(k >> 1, k & 1);
-            if (col < 0) continue;
+    const long total = (long)rp.n_valid * rp.k_valid;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x, gsz = (long)gridDim.x * blockDim.x;
+    if (rp.dW)
+        for (long e = gid; e < total; e += gsz) {
+            const int n = (int)(e / rp.k_valid), k = (int)(e % rp.k_valid);
+            const int tn = n / WG_TN, i = n % WG_TN, tk = k / WG_TK, j = k % WG_TK;
+            float acc = 0.0f;
+            for (int sp = 0; sp < rp.splits; ++sp)
+                acc += rp.partial[(((long)sp * rp.tiles_n + tn) * rp.tiles_k + tk) * (long)(WG_TN * WG_TK) + i * WG_TK + j];
+            int col = k;
+            if (rp.enc_map) {
+                col = enc_channel(k >> 1, k & 1);
+                if (col < 0) continue;
+            }
+            rp.dW[(long)n * rp.ldw + rp.col_off + col] = acc;
         }
-        rp.dW[(long)n * rp.ldw + rp.col_off + col] = acc;
-    }
+    if (rp.colsum_out)
+        for (long e = gid; e < (long)rp.batch * rp.n_valid; e += gsz) {
+            const int b = (int)(e / rp.n_valid), n = (int)(e % rp.n_valid);
+            float acc = 0.0f;
+            for (int sp = 0; sp < rp.spi; ++sp)
+                acc += rp.colsum_part[((long)b * rp.spi + sp) * (rp.tiles_n * WG_TN) + n];
+            rp.colsum_out[(long)b * rp.colsum_ld + n] = acc;
+        }
+    if (rp.vec_out)
+        for (long e = gid; e < rp.k_valid; e += gsz) {
+            float acc = 0.0f;
+            for (int sp = 0; sp < rp.splits; ++sp) acc += rp.vec_part[(long)sp * (rp.tiles_k * WG_TK) + e];
+            rp.vec_out[e] = acc;
+        }
 }
 
-// dW = A^T B over all M samples.  scratch_partial must hold splits*tiles_n*tiles_k*16384 floats.
-size_t wgrad_partial_floats(long M, int n_valid, int k_valid, int* splits_out) {
-    const int tiles_n = (n_valid + WG_TN - 1) / WG_TN, tiles_k = (k_valid + WG_TK - 1) / WG_TK;
-    const long slabs = (M + WG_SLAB - 1) / WG_SLAB;
-    long splits = 1024 / (tiles_n * tiles_k);          // ~4 workgroups per CU in flight
-    if (splits < 1) splits = 1;
-    if (splits > slabs) splits = slabs;
-    if (splits_out) *splits_out = (int)splits;
-    return (size_t)splits * tiles_n * tiles_k * WG_TN * WG_TK;
+constexpr int WG_MAX_BLOCKS = 1024;       // splits * tiles bound: ~2 rounds of 2 workgroups per CU
+
+size_t wgrad_scratch_floats() {
+    return (size_t)WG_MAX_BLOCKS * WG_TN * WG_TK + (size_t)WG_MAX_BLOCKS * WG_TN + (size_t)WG_MAX_BLOCKS * WG_TK;
 }
 
-void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, long M,
-                  float* dW, int ldw, int col_off, int enc_map, float* partial, hipStream_t stream) {
-    int splits = 1;
-    wgrad_partial_floats(M, n_valid, k_valid, &splits);
-    const int tiles_n = (n_valid + WG_TN - 1) / WG_TN, tiles_k = (k_valid + WG_TK - 1) / WG_TK;
-    const long slabs = (M + WG_SLAB - 1) / WG_SLAB;
-    WgradParams wp;
-    wp.A = A; wp.B = B; wp.lda = lda; wp.ldb = ldb; wp.n_valid = n_valid; wp.k_valid = k_valid; wp.M = M;
-    wp.rows_per_split = ((slabs + splits - 1) / splits) * WG_SLAB;
-    wp.partial = partial;
-    hipLaunchKernelGGL(wgrad_kernel, dim3(tiles_n, tiles_k, splits), dim3(256), 0, stream, wp);
-    WgradReduceParams rp;
-    rp.partial = partial; rp.splits = splits; rp.tiles_n = tiles_n; rp.tiles_k = tiles_k;
+// dW[n_valid x k_valid] (+ col_off, optional encoding-slot map) = A^T B over all chunks.
+// Optional: colsum_out[b][n] = per-image column sums of A; vec_out[k] = vec^T B.
+void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, int batch,
+                  long chunks_per_image, float* dW, int ldw, int col_off, int enc_map, float* colsum_out,
+                  int colsum_ld, const float* vec, float* vec_out, float* scratch, hipStream_t stream) {
+    WgradParams wp{};
+    wp.A = A; wp.B = B; wp.lda = lda; wp.ldb = ldb; wp.n_valid = n_valid; wp.k_valid = k_valid;
+    wp.tiles_n = (n_valid + WG_TN - 1) / WG_TN;
+    wp.tiles_k = (k_valid + WG_TK - 1) / WG_TK;
+    const int tiles = wp.tiles_n * wp.tiles_k;
+    long spi = (WG_MAX_BLOCKS / tiles) / batch;
+    if (spi < 1) spi = 1;
+    if (spi > chunks_per_image) spi = chunks_per_image;
+    wp.batch = batch; wp.spi = (int)spi;
+    wp.chunks_per_image = chunks_per_image;
+    wp.chunks_per_split = (chunks_per_image + spi - 1) / spi;
+    wp.partial = scratch;
+    float* cs_part = scratch + (size_t)WG_MAX_BLOCKS * WG_TN * WG_TK;
+    float* vec_part = cs_part + (size_t)WG_MAX_BLOCKS * WG_TN;
+    wp.colsum_part = cs_part;
+    wp.vec = vec_out ? vec : nullptr;
+    wp.vec_part = vec_part;
+    const int splits = batch * (int)spi;
+    const unsigned blocks = (unsigned)(8 * ((splits + 7) / 8) * tiles);
+    if (wp.vec) hipLaunchKernelGGL((wgrad_kernel<true>), dim3(blocks), dim3(256), 0, stream, wp);
+    else hipLaunchKernelGGL((wgrad_kernel<false>), dim3(blocks), dim3(256), 0, stream, wp);
+    WgradReduceParams rp{};
+    rp.partial = scratch; rp.splits = splits; rp.tiles_n = wp.tiles_n; rp.tiles_k = wp.tiles_k;
     rp.n_valid = n_valid; rp.k_valid = k_valid; rp.dW = dW; rp.ldw = ldw; rp.col_off = col_off; rp.enc_map = enc_map;
-    const long total = (long)tiles_n * WG_TN * tiles_k * WG_TK;
+    rp.colsum_part = cs_part; rp.colsum_out = colsum_out; rp.colsum_ld = colsum_ld; rp.batch = batch; rp.spi = (int)spi;
+    rp.vec_part = vec_part; rp.vec_out = vec_out ? vec_out : nullptr;
+    const long total = (long)n_valid * k_valid;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, rp);
 }
 
-// ---------------------------------------------------------------------------------------------
-// column sums of a row-major [rows][C] matrix per image: out[b][c] = sum_{s in image b} Y[s][c]
-// (bias gradients; for the layers that see latent codes the per-image sums also give the latent
-// and latent-column weight gradients).  Two deterministic stages.
-// ---------------------------------------------------------------------------------------------
-constexpr int CS_SPLITS = 512;
-
-__global__ void colsum_stage1(const float* __restrict__ Y, int ld, int C, long rows_per_image, int splits,
-                              float* __restrict__ part) {
-    const int b = blockIdx.y, sp = blockIdx.x, c = threadIdx.x;
-    if (c >= C) return;
-    const long per = (rows_per_image + splits - 1) / splits;
-    const long r0 = (long)b * rows_per_image + sp * per;
-    long r1 = r0 + per;
-    const long rmax = (long)(b + 1) * rows_per_image;
-    if (r1 > rmax) r1 = rmax;
+// per-image sum of a per-sample vector: out[b] = sum_{s in image b} v[s]   (density bias gradient)
+__global__ __launch_bounds__(256) void vecsum_kernel(const float* __restrict__ v, long per_image, float* __restrict__ out) {
+    __shared__ float red[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
     float acc = 0.0f;
-    for (long r = r0; r < r1; ++r) acc += Y[r * ld + c];
-    part[((long)b * splits + sp) * C + c] = acc;
+    for (long i = tid; i < per_image; i += 256) acc += v[(long)b * per_image + i];
+    red[tid] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) out[b] = red[0];
 }
 
-__global__ void colsum_stage2(const float* __restrict__ part, int C, int splits, float* __restrict__ out,
-                              int out_ld) {
-    const int b = blockIdx.x, c = threadIdx.x;
-    if (c >= C) return;
-    float acc = 0.0f;
-    for (int sp = 0; sp < splits; ++sp) acc += part[((long)b * splits + sp) * C + c];
-    out[(long)b * out_ld + c] = acc;
-}
-
-// out[b][0..C) (row stride out_ld) = per-image column sums.  part: B*CS_SPLITS*C floats.
-void launch_colsum(const float* Y, int ld, int C, int batch, long rows_per_image, float* out, int out_ld,
-                   float* part, hipStream_t stream) {
-    int splits = CS_SPLITS;
-    if (rows_per_image < splits) splits = (int)rows_per_image;
-    const int threads = ((C + 63) / 64) * 64;
-    hipLaunchKernelGGL(colsum_stage1, dim3(splits, batch), dim3(threads), 0, stream, Y, ld, C, rows_per_image,
-                       splits, part);
-    hipLaunchKernelGGL(colsum_stage2, dim3(batch), dim3(threads), 0, stream, part, C, splits, out, out_ld);
+void launch_vecsum(const float* v, int batch, long per_image, float* out, int out_stride, hipStream_t stream) {
+    // out[b * out_stride]: written through a strided view by launching per image
+    for (int b = 0; b < batch; ++b)
+        hipLaunchKernelGGL(vecsum_kernel, dim3(1), dim3(256), 0, stream, v + (long)b * per_image, per_image,
+                           out + (long)b * out_stride);
 }
 
 }  // namespace gnr
