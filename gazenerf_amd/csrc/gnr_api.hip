@@ -74,9 +74,12 @@ size_t carve_fwd(const GnrProblem* p, int n_streams, bool save, char* base, FwdP
         fp->M = (long)M;
         fp->save = save ? 1 : 0;
     }
+    // the packed weight streams of all MLPs are contiguous (+ one ring of padding): the kernel's
+    // prefetch ring runs straight from the last layer of one stream into the first of the next
+    float* packed_all = take((size_t)n_streams * PACKED_FLOATS + 16 * 256);
     for (int s = 0; s < n_streams; ++s) {
         StreamWs w{};
-        w.packed = take(PACKED_FLOATS);
+        w.packed = packed_all ? packed_all + (size_t)s * PACKED_FLOATS : nullptr;
         w.bias = take((size_t)N_CHAIN * p->batch * H);
         w.wsig = take(H + 4);
         w.part_feat = take(n_chunks * FEAT_PAD);

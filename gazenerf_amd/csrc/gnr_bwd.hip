@@ -26,11 +26,12 @@ extern thread_local hipEvent_t g_ev_start, g_ev_stop;
 // ---------------------------------------------------------------------------------------------
 // transposed weight stream.  Backward "layer" ids, in execution order:
 //   0: RGB2^T (in 9 tiles -> out 6)   1: RGB1^T (6 -> 12)   2: RGB0^T (12 -> 12)
-//   3..5: L7^T, L6^T, L5h^T (12 -> 12)   6: L5e^T (12 -> 2)   7..10: L4^T..L1^T   11: L0e^T (12 -> 2)
+//   3,4: L7^T, L6^T (12 -> 12)   5: L5e^T (12 -> 2)   6: L5h^T (12 -> 12)   7..10: L4^T..L1^T
+//   11: L0e^T (12 -> 2).  Memory order == execution order: the kernel reads one linear row stream.
 // ---------------------------------------------------------------------------------------------
 constexpr int N_BL = 12;
 __host__ __device__ constexpr int bl_in_tiles(int l) { return l == 0 ? NT_F : (l == 1 ? NT_H2 : NT_H); }
-__host__ __device__ constexpr int bl_out_tiles(int l) { return l == 0 ? NT_H2 : ((l == 6 || l == 11) ? 2 : NT_H); }
+__host__ __device__ constexpr int bl_out_tiles(int l) { return l == 0 ? NT_H2 : ((l == 5 || l == 11) ? 2 : NT_H); }
 __host__ __device__ constexpr size_t bl_floats(int l) { return (size_t)bl_in_tiles(l) * 16 * bl_out_tiles(l) * 64; }
 __host__ __device__ constexpr size_t bl_offset(int l) {
     size_t o = 0;
@@ -290,10 +291,9 @@ __global__ __launch_bounds__(256, 1) void bwd_chain_kernel(const BwdParams bp) {
     const long ray_g = chunk / bp.chunks_per_ray;
     const long row = chunk * CHUNK + j;
     const long M = bp.M;
-    const f32x4* PT = (const f32x4*)bp.packedT;
-    auto Pb = [&](int l) { return PT + bl_offset(l) / 4; };
+    WStream w;
+    wstream_init(w, bp.packedT, lane);
     const float* enc_row = bp.enc + chunk * (CHUNK * ENC_PAD) + j;     // CCM: slot stride 32
-
     f32x16 A[NT_H], Bv[NT_H];
     float gx = 0.0f, gy = 0.0f, gz = 0.0f;
 
@@ -313,66 +313,51 @@ __global__ __launch_bounds__(256, 1) void bwd_chain_kernel(const BwdParams bp) {
     unsigned mk[RELU_WORDS];
     auto bits = [&](int layer) { return bp.relu_bits + relu_bits_offset(layer, bp.n_chunks, chunk); };
     auto dyh = [&](int l) { return dump_ptr(bp.dY_h + l * M * H, H, chunk, j, h); };
-    // Each mm_h dumps ITS INPUT (the dY of the layer above) while its MFMAs run.
+    // Each mm_h dumps ITS INPUT (the dY of the layer above) while its MFMAs run; accumulators start
+    // from an inline-zero C operand; the ReLU mask of each output tile is applied in the loop tail.
+#define GNR_MASK(X) [&](int t) { apply_relu_bits_tile(X[t], mk[t >> 1], t); }
     // RGB2^T: A(9) -> Bv(6), mask y1 > 0            (dumps dfeat)
     load_relu_bits<NT_H2>(mk, bits(8), lane);
-    zero_tiles<NT_H2>(Bv);
-    mm_h<NT_F, NT_H2, true>(A, Bv, Pb(0), lane, dump_ptr(bp.dfeat, FEAT_PAD, chunk, j, h));
-    apply_relu_bits<NT_H2>(Bv, mk);
+    mm_h<NT_F, NT_H2, true, true>(A, Bv, w, dump_ptr(bp.dfeat, FEAT_PAD, chunk, j, h), GNR_MASK(Bv));
     // RGB1^T: Bv(6) -> A(12), no activation on y0   (dumps dY_r1)
-    zero_tiles<NT_H>(A);
-    mm_h<NT_H2, NT_H, true>(Bv, A, Pb(1), lane, dump_ptr(bp.dY_r1, H2, chunk, j, h));
+    mm_h<NT_H2, NT_H, true, true>(Bv, A, w, dump_ptr(bp.dY_r1, H2, chunk, j, h));
     // RGB0^T: A -> Bv, + density head, mask h7      (dumps dY_r0)
     load_relu_bits<NT_H>(mk, bits(7), lane);
-    zero_tiles<NT_H>(Bv);
-    mm_h<NT_H, NT_H, true>(A, Bv, Pb(2), lane, dump_ptr(bp.dY_r0, H, chunk, j, h));
     {
         const float ds = bp.dsig[row];
-#pragma unroll
-        for (int t = 0; t < NT_H; ++t)
+        const float* wsg = bp.wsig + 4 * h;
+        mm_h<NT_H, NT_H, true, true>(A, Bv, w, dump_ptr(bp.dY_r0, H, chunk, j, h), [&](int t) {
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
-                const f32x4 w4 = *(const f32x4*)(bp.wsig + 32 * t + 8 * rq + 4 * h);
-                Bv[t][4 * rq + 0] = fmaf(w4.x, ds, Bv[t][4 * rq + 0]);
-                Bv[t][4 * rq + 1] = fmaf(w4.y, ds, Bv[t][4 * rq + 1]);
-                Bv[t][4 * rq + 2] = fmaf(w4.z, ds, Bv[t][4 * rq + 2]);
-                Bv[t][4 * rq + 3] = fmaf(w4.w, ds, Bv[t][4 * rq + 3]);
+                const f32x4 w4 = *(const f32x4*)(wsg + 32 * t + 8 * rq);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Bv[t][4 * rq + e] = fmaf(w4[e], ds, Bv[t][4 * rq + e]);
             }
+            apply_relu_bits_tile(Bv[t], mk[t >> 1], t);
+        });
     }
-    apply_relu_bits<NT_H>(Bv, mk);
     // L7^T: Bv -> A mask h6 (dumps dY_7); L6^T: A -> Bv mask h5 (dumps dY_6)
     load_relu_bits<NT_H>(mk, bits(6), lane);
-    zero_tiles<NT_H>(A);
-    mm_h<NT_H, NT_H, true>(Bv, A, Pb(3), lane, dyh(7));
-    apply_relu_bits<NT_H>(A, mk);
+    mm_h<NT_H, NT_H, true, true>(Bv, A, w, dyh(7), GNR_MASK(A));
     load_relu_bits<NT_H>(mk, bits(5), lane);
-    zero_tiles<NT_H>(Bv);
-    mm_h<NT_H, NT_H, true>(A, Bv, Pb(4), lane, dyh(6));
-    apply_relu_bits<NT_H>(Bv, mk);
+    mm_h<NT_H, NT_H, true, true>(A, Bv, w, dyh(6), GNR_MASK(Bv));
     // L5: encoding columns first (2 tiles, A is dead here; dumps dY_5), then the hidden columns -> A mask h4
-    zero_tiles<2>(A);
-    mm_h<NT_H, 2, true>(Bv, A, Pb(6), lane, dyh(5));
+    mm_h<NT_H, 2, true, true>(Bv, A, w, dyh(5));
     enc_backward(A, enc_row, h, gx, gy, gz);
     load_relu_bits<NT_H>(mk, bits(4), lane);
-    zero_tiles<NT_H>(A);
-    mm_h<NT_H, NT_H>(Bv, A, Pb(5), lane);
-    apply_relu_bits<NT_H>(A, mk);
+    mm_h<NT_H, NT_H, true, false>(Bv, A, w, nullptr, GNR_MASK(A));
     // L4^T..L1^T (dump dY_4 .. dY_1)
 #pragma unroll 1
     for (int rep = 0; rep < 2; ++rep) {
         const int la = 3 - 2 * rep, lb = 2 - 2 * rep;      // outputs dY_3, dY_2 then dY_1, dY_0
         load_relu_bits<NT_H>(mk, bits(la), lane);
-        zero_tiles<NT_H>(Bv);
-        mm_h<NT_H, NT_H, true>(A, Bv, PT + (bl_offset(7) + (size_t)(2 * rep) * bl_floats(7)) / 4, lane, dyh(la + 1));
-        apply_relu_bits<NT_H>(Bv, mk);
+        mm_h<NT_H, NT_H, true, true>(A, Bv, w, dyh(la + 1), GNR_MASK(Bv));
         load_relu_bits<NT_H>(mk, bits(lb), lane);
-        zero_tiles<NT_H>(A);
-        mm_h<NT_H, NT_H, true>(Bv, A, PT + (bl_offset(7) + (size_t)(2 * rep + 1) * bl_floats(7)) / 4, lane, dyh(lb + 1));
-        apply_relu_bits<NT_H>(A, mk);
+        mm_h<NT_H, NT_H, true, true>(Bv, A, w, dyh(lb + 1), GNR_MASK(A));
     }
+#undef GNR_MASK
     // L0: encoding columns from dY_0 (in A; dumps dY_0)
-    zero_tiles<2>(Bv);
-    mm_h<NT_H, 2, true>(A, Bv, Pb(11), lane, dyh(0));
+    mm_h<NT_H, 2, true, true>(A, Bv, w, dyh(0));
     enc_backward(Bv, enc_row, h, gx, gy, gz);
 
     // chunk partials for the geometry gradient: sum dpts, sum z * dpts
@@ -559,7 +544,7 @@ static size_t carve_bwd(const GnrProblem* p, char* base, BwdScratch* sc) {
         return ptr;
     };
     BwdScratch s{};
-    s.packedT = take(PACKEDT_FLOATS);
+    s.packedT = take(PACKEDT_FLOATS + 16 * 256);      // + one ring of padding past the last row
     s.gT = take(n_rays_total * FEAT_PAD);
     s.wglob = take(M);
     s.dsig = take(M);
@@ -630,8 +615,8 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         setl(2, W.rgb_w[0], H, H, 0, H, 0);
         setl(3, W.fea_w[7], H, H, 0, H, 0);
         setl(4, W.fea_w[6], H, H, 0, H, 0);
-        setl(5, W.fea_w[5], vp + H, H, vp, H, 0);
-        setl(6, W.fea_w[5], vp + H, H, 0, ENC_PAD, 1);
+        setl(5, W.fea_w[5], vp + H, H, 0, ENC_PAD, 1);
+        setl(6, W.fea_w[5], vp + H, H, vp, H, 0);
         setl(7, W.fea_w[4], H, H, 0, H, 0);
         setl(8, W.fea_w[3], H, H, 0, H, 0);
         setl(9, W.fea_w[2], H, H, 0, H, 0);

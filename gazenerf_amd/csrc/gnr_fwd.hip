@@ -16,13 +16,19 @@
 
 namespace gnr {
 
+// per-wave LDS bias table: rows L0..L7, RGB0 (384 each), RGB1 (192), RGB2 (288)
+constexpr int BIAS_ROW = H;
+constexpr int BIAS_FLOATS = N_CHAIN * BIAS_ROW;                       // 4224 floats = 16.5 KiB per wave
+constexpr size_t FWD_LDS_BYTES = (size_t)(ENC_STEPS * 256 + WAVES_PER_WG * BIAS_FLOATS) * sizeof(float);
+
 template <bool SAVE>
 __global__ __launch_bounds__(256, 1) void fwd_kernel(const FwdParams fp) {
-    __shared__ float enc_lds[ENC_STEPS * 256];      // [step][thread]: each thread owns a column
-
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* enc_lds = smem;                              // [step][thread]: each thread owns a column
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    float* bias_lds = smem + ENC_STEPS * 256 + wave * BIAS_FLOATS;     // this wave's table
     const int j = lane & 31, h = lane >> 5;
     const long chunk = (long)blockIdx.x * WAVES_PER_WG + wave;
     if (chunk >= fp.n_chunks) return;               // wave-uniform; no barriers below
@@ -35,6 +41,10 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel(const FwdParams fp) {
     const int i = c_in * CHUNK + j;
     const bool valid = i < p.n_samples;
     const long row = chunk * CHUNK + j;             // padded global sample index
+
+    // the weight stream starts now: its first rows land while the geometry / encoding is computed
+    WStream w;
+    wstream_init(w, fp.ws[0].packed, lane);
 
     // ---- A1: ray + sample ----
     const Ray r = make_ray(p, b, ray);
@@ -73,55 +83,69 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel(const FwdParams fp) {
 #pragma unroll 1
     for (int s = 0; s < fp.n_streams; ++s) {
         const StreamWs& ws = fp.ws[s];
-        const float* bias_b = ws.bias + (long)b * H;                 // + layer * B * H
-        const long bstride = (long)p.batch * H;
-        const f32x4* Pk = (const f32x4*)ws.packed;
-        auto Pl = [&](int l) { return Pk + packed_offset(l) / 4; };
         float* acth = ws.act_h;
-
+        // this image's biases (latent codes folded in) -> the wave's LDS table; wave-private, so an
+        // LDS wait is all the synchronisation needed
+        {
+            const long bstride = (long)p.batch * H;
+            const float* bsrc = ws.bias + (long)b * H;
+            for (int q = lane; q < N_CHAIN * (H / 4); q += 64) {
+                const int l = q / (H / 4), c4 = q - l * (H / 4);
+                *(f32x4*)(bias_lds + l * BIAS_ROW + 4 * c4) = *(const f32x4*)(bsrc + l * bstride + 4 * c4);
+            }
+        }
+        auto bl = [&](int l) { return bias_lds + l * BIAS_ROW; };
         auto dp = [&](float* dst, int C) -> float* { return SAVE ? dump_ptr(dst, C, chunk, j, h) : nullptr; };
         auto sb = [&](int layer) { return ws.relu_bits + relu_bits_offset(layer, fp.n_chunks, chunk); };
         // Every layer's output is dumped (training forward) by the NEXT layer's mm_h, spread over its
         // MFMA loop; only the sign bits are written at the layer boundary.
 
+        // Layer epilogue (bias + activation, sign bits in training) runs per output tile inside the
+        // tail of the producing mm_h.  mkw collects the ReLU bit words of the layer.
+        unsigned mkw[RELU_WORDS];
+#define GNR_EPI(X, L, RELU)                                                                              \
+    [&](int t) {                                                                                         \
+        const unsigned bt = bias_act_tile<RELU>(X[t], bl(L) + 32 * t, h);                                \
+        if (SAVE) mkw[t >> 1] = (t & 1) ? (mkw[t >> 1] | (bt << 16)) : bt;                               \
+    }
+        auto put_bits = [&](int layer, int words) {
+            if (SAVE) {
+                unsigned* dst = sb(layer);
+#pragma unroll
+                for (int q = 0; q < RELU_WORDS; ++q)
+                    if (q < words) dst[q * 64 + lane] = mkw[q];
+            }
+        };
+
         // L0: enc -> A
-        init_bias<NT_H>(A, bias_b + 0 * bstride, h);
-        mm_enc<NT_H>(enc_col, A, Pl(0), lane);
-        relu<NT_H>(A);
-        if (SAVE) store_relu_bits<NT_H>(A, sb(0), lane);
+        mm_enc<NT_H>(enc_col, A, w);
+        {
+            auto epi = GNR_EPI(A, 0, true);
+#pragma unroll
+            for (int t = 0; t < NT_H; ++t) epi(t);
+        }
+        put_bits(0, 6);
 
         // L1..L4: A -> Bv -> A -> Bv -> A   (each mm_h dumps its input h_{l-1})
 #pragma unroll 1
         for (int rep = 0; rep < 2; ++rep) {
             const int la = 1 + 2 * rep, lb = 2 + 2 * rep;
-            init_bias<NT_H>(Bv, bias_b + la * bstride, h);
-            mm_h<NT_H, NT_H, SAVE>(A, Bv, Pk + (packed_offset(1) + (size_t)(la - 1) * layer_packed_floats(1)) / 4, lane,
-                                   dp(acth + (la - 1) * fp.M * H, H));
-            relu<NT_H>(Bv);
-            if (SAVE) store_relu_bits<NT_H>(Bv, sb(la), lane);
-            init_bias<NT_H>(A, bias_b + lb * bstride, h);
-            mm_h<NT_H, NT_H, SAVE>(Bv, A, Pk + (packed_offset(1) + (size_t)(lb - 1) * layer_packed_floats(1)) / 4, lane,
-                                   dp(acth + (lb - 1) * fp.M * H, H));
-            relu<NT_H>(A);
-            if (SAVE) store_relu_bits<NT_H>(A, sb(lb), lane);
+            mm_h<NT_H, NT_H, true, SAVE>(A, Bv, w, dp(acth + (la - 1) * fp.M * H, H), GNR_EPI(Bv, la, true));
+            put_bits(la, 6);
+            mm_h<NT_H, NT_H, true, SAVE>(Bv, A, w, dp(acth + (lb - 1) * fp.M * H, H), GNR_EPI(A, lb, true));
+            put_bits(lb, 6);
         }
 
         // L5: [enc | A] -> Bv   (skip connection, models/mlp_nerf.py:107); dumps h4
-        init_bias<NT_H>(Bv, bias_b + 5 * bstride, h);
-        mm_enc<NT_H>(enc_col, Bv, Pl(5), lane);
-        mm_h<NT_H, NT_H, SAVE>(A, Bv, Pl(5) + (size_t)ENC_STEPS * NT_H * 64 / 4, lane, dp(acth + 4 * fp.M * H, H));
-        relu<NT_H>(Bv);
-        if (SAVE) store_relu_bits<NT_H>(Bv, sb(5), lane);
+        mm_enc<NT_H>(enc_col, Bv, w);
+        mm_h<NT_H, NT_H, false, SAVE>(A, Bv, w, dp(acth + 4 * fp.M * H, H), GNR_EPI(Bv, 5, true));
+        put_bits(5, 6);
 
         // L6: Bv -> A (dumps h5), L7: A -> Bv (dumps h6)
-        init_bias<NT_H>(A, bias_b + 6 * bstride, h);
-        mm_h<NT_H, NT_H, SAVE>(Bv, A, Pl(6), lane, dp(acth + 5 * fp.M * H, H));
-        relu<NT_H>(A);
-        if (SAVE) store_relu_bits<NT_H>(A, sb(6), lane);
-        init_bias<NT_H>(Bv, bias_b + 7 * bstride, h);
-        mm_h<NT_H, NT_H, SAVE>(A, Bv, Pl(7), lane, dp(acth + 6 * fp.M * H, H));
-        relu<NT_H>(Bv);
-        if (SAVE) store_relu_bits<NT_H>(Bv, sb(7), lane);
+        mm_h<NT_H, NT_H, true, SAVE>(Bv, A, w, dp(acth + 5 * fp.M * H, H), GNR_EPI(A, 6, true));
+        put_bits(6, 6);
+        mm_h<NT_H, NT_H, true, SAVE>(A, Bv, w, dp(acth + 6 * fp.M * H, H), GNR_EPI(Bv, 7, true));
+        put_bits(7, 6);
 
         // density head on h7 (models/mlp_nerf.py:109): 384-long dot, split over the two lane halves
         float sig = 0.0f;
@@ -140,16 +164,13 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel(const FwdParams fp) {
         if (SAVE && h == 0) ws.sigma_raw[row] = sig;
 
         // RGB0: Bv -> A (no activation, mlp_nerf.py:110); dumps h7
-        init_bias<NT_H>(A, bias_b + LR0 * bstride, h);
-        mm_h<NT_H, NT_H, SAVE>(Bv, A, Pl(LR0), lane, dp(acth + 7 * fp.M * H, H));
+        mm_h<NT_H, NT_H, true, SAVE>(Bv, A, w, dp(acth + 7 * fp.M * H, H), GNR_EPI(A, LR0, false));
         // RGB1: A -> Bv[0..6) (+ folded appearance code), ReLU; dumps y0
-        init_bias<NT_H2>(Bv, bias_b + LR1 * bstride, h);
-        mm_h<NT_H, NT_H2, SAVE>(A, Bv, Pl(LR1), lane, dp(ws.act_y0, H));
-        relu<NT_H2>(Bv);
-        if (SAVE) store_relu_bits<NT_H2>(Bv, sb(8), lane);
+        mm_h<NT_H, NT_H2, true, SAVE>(A, Bv, w, dp(ws.act_y0, H), GNR_EPI(Bv, LR1, true));
+        put_bits(8, 3);
         // RGB2: Bv[0..6) -> A[0..9)  (258 channels padded to 288; no sigmoid, mlp_nerf.py:116); dumps y1
-        init_bias<NT_F>(A, bias_b + LR2 * bstride, h);
-        mm_h<NT_H2, NT_F, SAVE>(Bv, A, Pl(LR2), lane, dp(ws.act_y1, H2));
+        mm_h<NT_H2, NT_F, true, SAVE>(Bv, A, w, dp(ws.act_y1, H2), GNR_EPI(A, LR2, false));
+#undef GNR_EPI
         if (SAVE) dump<NT_F>(A, ws.act_feat, FEAT_PAD, chunk, j, h);
 
         // ---- A5: chunk-local compositing (utils/model_utils.py:498-534) ----
@@ -189,10 +210,17 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel(const FwdParams fp) {
 
 void launch_fwd(const FwdParams& fp, hipStream_t stream) {
     const unsigned grid = (unsigned)((fp.n_chunks + WAVES_PER_WG - 1) / WAVES_PER_WG);
+    // 98 KiB of dynamic LDS (> the 64 KiB default): opt in once per process
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_LDS_BYTES);
+        attr_set = true;
+    }
     if (fp.save)
-        hipLaunchKernelGGL(fwd_kernel<true>, dim3(grid), dim3(256), 0, stream, fp);
+        hipLaunchKernelGGL(fwd_kernel<true>, dim3(grid), dim3(256), FWD_LDS_BYTES, stream, fp);
     else
-        hipLaunchKernelGGL(fwd_kernel<false>, dim3(grid), dim3(256), 0, stream, fp);
+        hipLaunchKernelGGL(fwd_kernel<false>, dim3(grid), dim3(256), FWD_LDS_BYTES, stream, fp);
 }
 
 }  // namespace gnr

@@ -59,6 +59,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams wp) {
     if (split >= wp.batch * wp.spi) return;
     const int tn = tile / wp.tiles_k, tk = tile - tn * wp.tiles_k;
 
+    // Two workgroups share each SIMD's matrix pipe.  With equal priority they advance in lock-step
+    // and reach their per-chunk barrier together, idling the pipe; a static priority for the wave
+    // in the odd hardware slot (HW_ID.wave_id, scalar) lets one stream MFMAs while the other
+    // stages/syncs, and the roles alternate by themselves.
+    if (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) __builtin_amdgcn_s_setprio(1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wk = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
@@ -132,23 +137,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams wp) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) v4[g] = *(const f32x4*)(pv + c * CHUNK + 4 * g);
         }
+        // all 16 operand reads of the chunk first (one exposed LDS latency per 64 MFMAs, not four)
+        f32x4 av[2][4], bv[2][4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 a0 = *(const f32x4*)&lds[buf][0][apos[0][g]];
-            const f32x4 a1 = *(const f32x4*)&lds[buf][0][apos[1][g]];
-            const f32x4 b0 = *(const f32x4*)&lds[buf][1][bpos[0][g]];
-            const f32x4 b1 = *(const f32x4*)&lds[buf][1][bpos[1][g]];
+            av[0][g] = *(const f32x4*)&lds[buf][0][apos[0][g]];
+            av[1][g] = *(const f32x4*)&lds[buf][0][apos[1][g]];
+            bv[0][g] = *(const f32x4*)&lds[buf][1][bpos[0][g]];
+            bv[1][g] = *(const f32x4*)&lds[buf][1][bpos[1][g]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                acc[0][0] = mfma32(a0[e], b0[e], acc[0][0]);
-                acc[0][1] = mfma32(a0[e], b1[e], acc[0][1]);
-                acc[1][0] = mfma32(a1[e], b0[e], acc[1][0]);
-                acc[1][1] = mfma32(a1[e], b1[e], acc[1][1]);
-                cs[0] += a0[e];
-                cs[1] += a1[e];
+                const float a0 = av[0][g][e], a1 = av[1][g][e], b0 = bv[0][g][e], b1 = bv[1][g][e];
+                acc[0][0] = mfma32(a0, b0, acc[0][0]);
+                acc[0][1] = mfma32(a0, b1, acc[0][1]);
+                acc[1][0] = mfma32(a1, b0, acc[1][0]);
+                acc[1][1] = mfma32(a1, b1, acc[1][1]);
+                cs[0] += a0;
+                cs[1] += a1;
                 if (VEC) {
-                    vs[0] = fmaf(v4[g][e], b0[e], vs[0]);
-                    vs[1] = fmaf(v4[g][e], b1[e], vs[1]);
+                    vs[0] = fmaf(v4[g][e], b0, vs[0]);
+                    vs[1] = fmaf(v4[g][e], b1, vs[1]);
                 }
             }
         }
