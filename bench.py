@@ -188,6 +188,16 @@ def main():
         flop_per_launch = rays_per_launch * n_p * 2 * FLOP_PER_SAMPLE_STREAM
         avg_ms = sum(kernel_ms) / max(1, len(kernel_ms))
         achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        # HBM-side bytes per launch: PMC FETCH_SIZE/WRITE_SIZE of this kernel, collected with rocprofv3
+        # in separate passes and committed under profiles/ (counters cannot be read from inside this
+        # process); scaled per ray to this launch size.  Inference variant only.
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r1_pmc_fwd.json")
+        if args.mode == "fwd" and os.path.exists(pmc):
+            with open(pmc) as f:
+                pj = json.load(f)
+            traffic = pj["hbm_bytes_per_ray"] * rays_per_launch
+            traffic_src = "profiles/r1_pmc_fwd.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, per ray x rays per launch)"
         res = {
             "metric": "rays/sec (512x512, 64 samples/ray) %s" % ("fwd+bwd" if args.mode == "fwdbwd" else "fwd"),
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -198,9 +208,9 @@ def main():
                                                           ", %d-ray micro-batches" % micro if args.mode == "fwdbwd" else ""),
                        "rays_per_step_per_gpu": n_rays, "samples_per_ray": n_p,
                        "parallelism": "dp%d (images sharded)" % world},
-            "roofline": {"bound": "mfma", "kernel": "gnr::fwd_kernel", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "gnr::fwd_kernel<%s>" % ("true" if args.mode == "fwdbwd" else "false"), "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "flop_per_launch": flop_per_launch, "avg_launch_ms": avg_ms,
                          "launches_timed": len(kernel_ms)},
         }

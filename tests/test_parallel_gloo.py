@@ -1,0 +1,99 @@
+"""CPU, world_size 2 over gloo: the multi-GPU plumbing of gazenerf_amd.parallel.
+The render op itself needs no collective (rays/images are independent); these tests cover the
+sharding helpers and the one exchange the training path adds: the flat-bucket gradient all-reduce."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gazenerf_amd import parallel, synth
+from gazenerf_amd.render import PARAM_ORDER
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, fn, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(fn, world=2):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, fn, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return dict(ret)
+
+
+def _allreduce_case(rank, world):
+    torch.manual_seed(0)
+    params = [v.reshape(v.shape[0], -1).clone() if v.dim() == 4 else v.clone()
+              for v in synth.hash_mlp_params("face", seed=1).values()]
+    expected = []
+    for i, p in enumerate(params):
+        g = [torch.full_like(p, float(r + 1)) * (i + 1) for r in range(world)]
+        p.grad = g[rank].clone()
+        expected.append(sum(g) / world)
+    red = parallel.GradAllReducer(params, world, bucket_numel=400000)
+    assert len(red.buckets) >= 3
+    red.all_reduce()
+    return all(torch.equal(p.grad, e) for p, e in zip(params, expected))
+
+
+def test_grad_all_reduce_two_ranks():
+    res = _run(_allreduce_case)
+    assert res == {0: True, 1: True}
+
+
+def _shard_case(rank, world):
+    xy = synth.pixel_grid(9)                      # 81 rays: not divisible by 2
+    local = parallel.shard_rays(xy, rank, world)
+    lo, hi = parallel.shard_range(81, rank, world)
+    assert local.shape[-1] == hi - lo and torch.equal(local, xy[:, :, lo:hi])
+    feat = local[:, :1, :] * 2.0 + rank          # stand-in for a rendered [B,C,N_r_local] slice
+    full = parallel.gather_rays(feat, 81, world)
+    exp = torch.cat([xy[:, :1, slice(*parallel.shard_range(81, r, world))] * 2.0 + r for r in range(world)], -1)
+    return bool(torch.equal(full, exp))
+
+
+def test_ray_shard_and_gather_two_ranks():
+    res = _run(_shard_case)
+    assert res == {0: True, 1: True}
+
+
+def test_shard_ranges_cover_everything():
+    for n in (1, 7, 16, 4096, 262144):
+        for world in (1, 2, 4, 8):
+            spans = [parallel.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert parallel.shard_images(16, 3, 8) == (6, 8)       # cfg4: 2 images per rank
+
+
+def test_world_size_one_is_a_noop():
+    p = torch.ones(4, requires_grad=True)
+    p.grad = torch.full((4,), 3.0)
+    parallel.GradAllReducer([p], 1).all_reduce()
+    assert torch.equal(p.grad, torch.full((4,), 3.0))
+    assert len(PARAM_ORDER) == 24
