@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel(const FwdParams fp) {
         };
 
         // L0: enc -> A
-        mm_enc<NT_H>(enc_col, A, w);
+        mm_enc<NT_H, SAVE>(enc_col, A, w);
         {
             auto epi = GNR_EPI(A, 0, true);
 #pragma unroll
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel(const FwdParams fp) {
         }
 
         // L5: [enc | A] -> Bv   (skip connection, models/mlp_nerf.py:107); dumps h4
-        mm_enc<NT_H>(enc_col, Bv, w);
+        mm_enc<NT_H, SAVE>(enc_col, Bv, w);
         mm_h<NT_H, NT_H, false, SAVE>(A, Bv, w, dp(acth + 4 * fp.M * H, H), GNR_EPI(Bv, 5, true));
         put_bits(5, 6);
 
