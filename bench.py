@@ -212,7 +212,13 @@ def main():
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "flop_per_launch": flop_per_launch, "avg_launch_ms": avg_ms,
-                         "launches_timed": len(kernel_ms)},
+                         "launches_timed": len(kernel_ms),
+                         # whole step against the same peak: algorithmic FLOPs of the step (fwd, or
+                         # 3x fwd for fwd+bwd: dgrad + wgrad) / wall time of the step
+                         "step_achieved": (3 if args.mode == "fwdbwd" else 1) * n_rays * n_p * 2
+                                          * FLOP_PER_SAMPLE_STREAM / (ms * 1e-3) / 1e12,
+                         "step_frac": (3 if args.mode == "fwdbwd" else 1) * n_rays * n_p * 2
+                                      * FLOP_PER_SAMPLE_STREAM / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.mode, args.cpu_rays, n_p)
