@@ -135,7 +135,8 @@ def main():
     t_rand = synth.synth_jitter(1, micro, n_p, seed=7).to(dev) if args.mode == "fwdbwd" else None
     reducer = GradAllReducer(plist, world) if (args.mode == "fwdbwd") else None
     timer = KernelTimer()
-    kernel_ms = []
+    aux_timer = KernelTimer(aux=True)
+    kernel_ms, aux_ms = [], []
 
     def step(timed):
         if args.mode == "fwd":
@@ -158,7 +159,10 @@ def main():
             if timed:
                 kernel_ms.append(timer.elapsed_ms())
             loss = sum((out["feat_" + t] ** 2).mean() + out["bg_alpha_" + t].mean() for t in ("face", "eyes"))
-            loss.backward()
+            with aux_timer:
+                loss.backward()
+            if timed:
+                aux_ms.append(aux_timer.elapsed_ms())
         reducer.all_reduce()
 
     for _ in range(args.warmup):
@@ -220,6 +224,16 @@ def main():
                          "step_frac": (3 if args.mode == "fwdbwd" else 1) * n_rays * n_p * 2
                                       * FLOP_PER_SAMPLE_STREAM / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
         }
+        if aux_ms:
+            # HBM-bound compositing pass (CalcRayColor backward): algorithmic bytes per sample =
+            # 288 saved features + sigma_raw + delta read, w_i + dL/dsigma written
+            m = micro * n_p
+            nbytes = m * (288 * 4 + 8 + 8) + micro * (288 * 4 + 4 + 8)
+            a = sum(aux_ms) / len(aux_ms)
+            gbs = nbytes / (a * 1e-3) / 1e9
+            res["roofline_hbm"] = {"bound": "hbm", "kernel": "gnr::comp_bwd_kernel", "achieved": gbs, "peak": 8000.0,
+                                   "unit": "GB/s", "frac": gbs / 8000.0, "bytes_per_launch": nbytes,
+                                   "avg_launch_ms": a, "launches_timed": len(aux_ms), "traffic": None}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.mode, args.cpu_rays, n_p)
         print(json.dumps(res), flush=True)

@@ -45,12 +45,19 @@ class GnrOutputGrads(C.Structure):
     _fields_ = [("feat", _p * 2), ("bg_alpha", _p * 2)]
 
 
+class GnrMergeProblem(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("n_pix", C.c_int32), ("feat_nc", C.c_int32),
+                ("feat_face", _p), ("bg_alpha_face", _p), ("feat_eyes", _p), ("bg_alpha_eyes", _p),
+                ("bg_featmap", _p), ("gaze", _p)]
+
+
 class GnrInputGrads(C.Structure):
     _fields_ = [("R", _p), ("T", _p), ("shape_code", _p), ("gaze", _p), ("appea_code", _p)]
 
 
 EXPORTS = ("gnr_abi_version", "gnr_workspace_bytes", "gnr_fwd", "gnr_bwd", "gnr_resample",
-           "gnr_sample_zvals", "gnr_set_kernel_timing", "gnr_last_error")
+           "gnr_sample_zvals", "gnr_set_kernel_timing", "gnr_set_aux_timing", "gnr_merge_scratch_bytes",
+           "gnr_merge_fwd", "gnr_merge_bwd", "gnr_last_error")
 
 _lib = None
 
@@ -87,6 +94,14 @@ def load():
     lib.gnr_sample_zvals.argtypes = [C.POINTER(GnrProblem), _p, _p]
     lib.gnr_set_kernel_timing.restype = C.c_int
     lib.gnr_set_kernel_timing.argtypes = [_p, _p]
+    lib.gnr_merge_scratch_bytes.restype = C.c_size_t
+    lib.gnr_merge_scratch_bytes.argtypes = [C.POINTER(GnrMergeProblem)]
+    lib.gnr_merge_fwd.restype = C.c_int
+    lib.gnr_merge_fwd.argtypes = [C.POINTER(GnrMergeProblem), _p, _p, _p, _p]
+    lib.gnr_merge_bwd.restype = C.c_int
+    lib.gnr_merge_bwd.argtypes = [C.POINTER(GnrMergeProblem)] + [_p] * 10 + [C.c_size_t, _p]
+    lib.gnr_set_aux_timing.restype = C.c_int
+    lib.gnr_set_aux_timing.argtypes = [_p, _p]
     if lib.gnr_abi_version() != ABI_VERSION:
         raise RuntimeError("libgnr.so ABI %d != binding ABI %d; rebuild" % (lib.gnr_abi_version(), ABI_VERSION))
     _lib = lib

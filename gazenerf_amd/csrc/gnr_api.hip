@@ -1,5 +1,7 @@
 // gnr_api.hip -- the C ABI of libgnr.so (include/gnr.h): validation, workspace carving, launches.
-// No torch types, no allocation, no global state besides the thread-local error string.
+// No torch types, no allocation, no global state besides the thread-local error string and the
+// (result-neutral) measurement hooks.
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <string>
@@ -16,7 +18,8 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
 size_t bwd_scratch_bytes(const GnrProblem* p, int n_streams);
 
 static thread_local std::string g_err;
-thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+// measurement hooks: process-wide on purpose (see include/gnr.h)
+std::atomic<hipEvent_t> g_ev_start{nullptr}, g_ev_stop{nullptr}, g_aux_start{nullptr}, g_aux_stop{nullptr};
 
 int fail(const char* fmt, ...) {
     char buf[512];
@@ -112,6 +115,12 @@ int gnr_abi_version(void) { return GNR_ABI_VERSION; }
 
 const char* gnr_last_error(void) { return g_err.c_str(); }
 
+int gnr_set_aux_timing(void* ev_start, void* ev_stop) {
+    g_aux_start = (hipEvent_t)ev_start;
+    g_aux_stop = (hipEvent_t)ev_stop;
+    return 0;
+}
+
 int gnr_set_kernel_timing(void* ev_start, void* ev_stop) {
     g_ev_start = (hipEvent_t)ev_start;
     g_ev_stop = (hipEvent_t)ev_stop;
@@ -148,9 +157,9 @@ int gnr_fwd(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes,
     fp.want_wl = (out->weights[0] || (n_streams > 1 && out->weights[1])) ? 1 : 0;
     const GnrWeights* ws_in[2] = {face, eyes};
     launch_prep(*p, n_streams, ws_in, fp.ws, st);
-    if (g_ev_start) hipEventRecord(g_ev_start, st);
+    if (hipEvent_t e0 = g_ev_start.load()) (void)hipEventRecord(e0, st);
     launch_fwd(fp, st);
-    if (g_ev_stop) hipEventRecord(g_ev_stop, st);
+    if (hipEvent_t e1 = g_ev_stop.load()) (void)hipEventRecord(e1, st);
 
     CombineParams cp{};
     cp.prob = *p;

@@ -11,6 +11,8 @@
 //   5. launch_wgrad x12   dW = dY^T X  (gnr_wgrad.hip), colsum for the biases
 //   6. latent_kernel      per-image bias sums -> d(shape,gaze,appea) and the latent columns of dW
 // Once per call: geo_kernel  d(pts), dL/dl partials -> dR, dT (GenSamplePoints backward).
+#include <atomic>
+
 #include "gnr_chain.h"
 
 namespace gnr {
@@ -21,7 +23,7 @@ void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb,
                   long chunks_per_image, float* dW, int ldw, int col_off, int enc_map, float* colsum_out,
                   int colsum_ld, const float* vec, float* vec_out, float* scratch, hipStream_t stream);
 void launch_vecsum(const float* v, int batch, long per_image, float* out, int out_stride, hipStream_t stream);
-extern thread_local hipEvent_t g_ev_start, g_ev_stop;
+extern std::atomic<hipEvent_t> g_ev_start, g_ev_stop, g_aux_start, g_aux_stop;
 
 // ---------------------------------------------------------------------------------------------
 // transposed weight stream.  Backward "layer" ids, in execution order:
@@ -604,7 +606,9 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         cb.prob = *p; cb.chunks_per_ray = cpr; cb.gT = sc.gT; cb.g_bg = dout->bg_alpha[s];
         cb.act_feat = ws.act_feat; cb.sigma_raw = ws.sigma_raw; cb.delta = fp.delta;
         cb.wglob = sc.wglob; cb.dsig = sc.dsig; cb.csum = sc.csum; cb.dsig_ray = sc.dsig_ray; cb.accumulate = s > 0;
+        if (hipEvent_t e = g_aux_start.load(); e && s == 0) (void)hipEventRecord(e, st);
         hipLaunchKernelGGL(comp_bwd_kernel, dim3((unsigned)((n_rays_total + 3) / 4)), dim3(256), 0, st, cb);
+        if (hipEvent_t e = g_aux_stop.load(); e && s == 0) (void)hipEventRecord(e, st);
         // 3. transposed weight stream
         PackTParams pt{};
         auto setl = [&](int l, const float* wp, int ld, int n_valid, int col0, int k_valid, int enc) {
@@ -631,10 +635,10 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         bp.relu_bits = ws.relu_bits; bp.enc = fp.enc; bp.zval = fp.zval;
         bp.dY_h = sc.dY_h; bp.dY_r0 = sc.dY_r0; bp.dY_r1 = sc.dY_r1; bp.dfeat = sc.dfeat;
         bp.geo_chunk = sc.geo_chunk; bp.accumulate_geo = s > 0;
-        if (g_ev_start && s == 0) hipEventRecord(g_ev_start, st);
+        if (hipEvent_t e = g_ev_start.load(); e && s == 0) (void)hipEventRecord(e, st);
         hipLaunchKernelGGL(bwd_chain_kernel, dim3((unsigned)((fp.n_chunks + WAVES_PER_WG - 1) / WAVES_PER_WG)),
                            dim3(256), 0, st, bp);
-        if (g_ev_stop && s == 0) hipEventRecord(g_ev_stop, st);
+        if (hipEvent_t e = g_ev_stop.load(); e && s == 0) (void)hipEventRecord(e, st);
 
         // 5. weight gradients dW = dY^T X; the same kernels emit the per-image column sums of dY
         //    (bias / latent gradients) and, for RGB_layer_0, the density-head gradient dsig^T h7.

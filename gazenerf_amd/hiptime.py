@@ -11,7 +11,11 @@ from . import _lib
 
 
 class KernelTimer:
-    def __init__(self):
+    """aux=False: the dominant kernel (gnr_set_kernel_timing); aux=True: the HBM-bound compositing
+    pass of gnr_bwd (gnr_set_aux_timing)."""
+
+    def __init__(self, aux: bool = False):
+        self.aux = aux
         self.hip = C.CDLL("libamdhip64.so")
         self.start, self.stop = C.c_void_p(), C.c_void_p()
         assert self.hip.hipEventCreate(C.byref(self.start)) == 0
@@ -19,11 +23,11 @@ class KernelTimer:
         self.lib = _lib.load()
 
     def __enter__(self):
-        self.lib.gnr_set_kernel_timing(self.start, self.stop)
+        (self.lib.gnr_set_aux_timing if self.aux else self.lib.gnr_set_kernel_timing)(self.start, self.stop)
         return self
 
     def __exit__(self, *exc):
-        self.lib.gnr_set_kernel_timing(None, None)
+        (self.lib.gnr_set_aux_timing if self.aux else self.lib.gnr_set_kernel_timing)(None, None)
 
     def elapsed_ms(self) -> float:
         """Duration of the most recent bracketed kernel (synchronises on the stop event)."""

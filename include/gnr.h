@@ -154,11 +154,40 @@ int gnr_resample(const float* weights, const float* coarse_z, const float* u,
  * (utils/model_utils.py:312-313).  Honours p->t_rand / p->z_edges. */
 int gnr_sample_zvals(const GnrProblem* p, float* zvals_out, void* stream);
 
-/* Measurement hook: subsequent gnr_fwd / gnr_bwd calls made by THIS thread record the two
+/* Measurement hook (process-wide: a framework may run gnr_bwd on another thread than the one that
+ * armed the hook, e.g. PyTorch's autograd engine): subsequent gnr_fwd / gnr_bwd calls record the two
  * hipEvent_t (passed as void*) on their stream immediately before / after the dominant kernel of
- * the call (the fused MLP kernel in gnr_fwd; the dgrad-chain kernel in gnr_bwd), so a harness can
- * time that kernel alone.  Pass NULLs to switch it off (the default). */
+ * the call (the fused MLP kernel in gnr_fwd; the dgrad-chain kernel of the first weight set in
+ * gnr_bwd), so a harness can time that kernel alone.  Pass NULLs to switch it off (the default).
+ * This is the only process-wide state in the library; it never affects results. */
 int gnr_set_kernel_timing(void* ev_start, void* ev_stop);
+
+/* Same, for the HBM-bound compositing pass of gnr_bwd (CalcRayColor backward over the saved per-sample
+ * features, first weight set): lets a harness report achieved GB/s for that pass. */
+int gnr_set_aux_timing(void* ev_start, void* ev_stop);
+
+/* ---- first "next" row: feature-map merge, the step right after the hot path ----
+ * Replaces models/gaze_nerf.py:175-203 and rotate()/rotation_matrix_2d (utils/model_utils.py:11-46):
+ *   merge_face = feat_face + bg_alpha_face * bg_featmap;  merge_eyes likewise;
+ *   eyes_planes = merge_eyes with every channel triplet rotated by Rot(gaze) = M2(yaw) M1(pitch);
+ *   merge = max(merge_face, eyes_planes).
+ * Maps are channels-first [B, feat_nc, n_pix] (n_pix = featmap_size^2), exactly what gnr_fwd writes. */
+typedef struct GnrMergeProblem {
+    int32_t batch, n_pix, feat_nc;           /* feat_nc % 3 == 0 (258 = 3 * 86)                 */
+    const float* feat_face;     const float* bg_alpha_face;    /* [B,feat_nc,n_pix], [B,1,n_pix] */
+    const float* feat_eyes;     const float* bg_alpha_eyes;
+    const float* bg_featmap;    /* [1,feat_nc,n_pix]: NeuralRenderer.bg_featmap (neural_renderer.py:37-57) */
+    const float* gaze;          /* [B,2] (pitch, yaw)                                              */
+} GnrMergeProblem;
+
+size_t gnr_merge_scratch_bytes(const GnrMergeProblem* p);
+/* Outputs [B,feat_nc,n_pix]; any may be NULL. */
+int gnr_merge_fwd(const GnrMergeProblem* p, float* merge_face, float* eyes_planes, float* merge, void* stream);
+/* Upstream gradients (NULL == zero) -> gradients of the six inputs (NULL == not wanted; written). */
+int gnr_merge_bwd(const GnrMergeProblem* p, const float* g_merge_face, const float* g_eyes_planes,
+                  const float* g_merge, float* d_feat_face, float* d_bg_alpha_face, float* d_feat_eyes,
+                  float* d_bg_alpha_eyes, float* d_bg_featmap, float* d_gaze,
+                  void* scratch, size_t scratch_bytes, void* stream);
 
 const char* gnr_last_error(void);
 

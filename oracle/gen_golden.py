@@ -243,6 +243,29 @@ def main():
         check("net feat_" + tag, otest["feat_" + tag], captured[i][0], 1e-6)
         check("net bg_alpha_" + tag, otest["bg_alpha_" + tag], captured[i][1], 1e-6)
 
+    # ---------------------------------------------------------------- G7: feature-map merge (N2)
+    print("[g7_merge] GazeNeRFNet.calc_color_with_code tail: hooks on NeuralRenderer inputs")
+    torch.manual_seed(3)
+    net.neural_render.bg_featmap.data = torch.rand_like(net.neural_render.bg_featmap.data)
+    captured, rendered = [], []
+    h1 = net.calc_color_func.register_forward_hook(lambda m, i, o: captured.append(o))
+    h2 = net.neural_render.register_forward_pre_hook(lambda m, i: rendered.append(i[0].detach().clone()))
+    with torch.no_grad():
+        net("test", prob["xy"], None, None, prob["shape_code"], prob["appea_code"], prob["gaze"],
+            prob["R"], prob["T"], prob["Kinv"])
+    h1.remove(); h2.remove()
+    S = side
+    ff, af = captured[0][0].view(2, 258, S, S), captured[0][1].view(2, 1, S, S)
+    fe, ae = captured[1][0].view(2, 258, S, S), captured[1][1].view(2, 1, S, S)
+    bgm = net.neural_render.bg_featmap.data
+    omf, oep, om = O.merge_featmaps(ff, af, fe, ae, bgm, prob["gaze"])
+    # NeuralRenderer is called on: bg_featmap, merge_face, eyes_planes, merge (gaze_nerf.py:176,200,201,205)
+    check("merge_featmap_face", omf, rendered[1], 1e-6)
+    check("eyes_planes", oep, rendered[2], 1e-6)
+    check("merge_featmap", om, rendered[3], 1e-6)
+    save("g7_merge", feat_face=ff, bg_alpha_face=af, feat_eyes=fe, bg_alpha_eyes=ae, bg_featmap=bgm,
+         gaze=prob["gaze"], out_merge_face=rendered[1], out_eyes_planes=rendered[2], out_merge=rendered[3])
+
     # ---------------------------------------------------------------- G2/G3/G4: full width
     hidden = synth.HIDDEN
     sub = torch.arange(0, 4096, 32) + (torch.arange(128) % 32)       # 128 rays, all rows/cols hit

@@ -198,6 +198,31 @@ def hier_fine_pass(coarse, shape_code, gaze, appea_code, fine_params, n_fine, u=
     return {"feat_fine": f, "bg_alpha_fine": a, "depth_fine": d, "w_fine": w, "samples": fs}
 
 
+# --------------------------------------------------------------------------- N2
+def rotation_matrix_2d(label):
+    """utils/model_utils.py:11-29: [B,2] (pitch, yaw) -> [B,3,3] = M2(yaw) @ M1(pitch)."""
+    cos, sin = torch.cos(label), torch.sin(label)
+    ones, zeros = torch.ones_like(cos[:, 0]), torch.zeros_like(cos[:, 0])
+    m1 = torch.stack([ones, zeros, zeros, zeros, cos[:, 0], -sin[:, 0], zeros, sin[:, 0], cos[:, 0]], dim=1).view(-1, 3, 3)
+    m2 = torch.stack([cos[:, 1], zeros, sin[:, 1], zeros, ones, zeros, -sin[:, 1], zeros, cos[:, 1]], dim=1).view(-1, 3, 3)
+    return torch.matmul(m2, m1)
+
+
+def merge_featmaps(feat_face, bg_alpha_face, feat_eyes, bg_alpha_eyes, bg_featmap, gaze):
+    """models/gaze_nerf.py:175-203 with utils/model_utils.py:32-46 (rotate): background blend, rotation
+    of the eye feature triplets by the gaze, elementwise max.  Maps are [B,C,H,W] (C = 3*86),
+    bg_alpha [B,1,H,W], bg_featmap [1,C,H,W], gaze [B,2].  Returns (merge_face, eyes_planes, merge)."""
+    merge_face = feat_face + bg_alpha_face * bg_featmap                                 # :178
+    merge_eyes = feat_eyes + bg_alpha_eyes * bg_featmap                                 # :179
+    B, C, H, W = merge_eyes.shape
+    emb = merge_eyes.clone().reshape(B, C // 3, 3, H, W)                                # :181-190
+    rot = rotation_matrix_2d(gaze.reshape(-1, 2))                                       # model_utils.py:37-39
+    x = torch.transpose(torch.transpose(emb, 2, 3), 3, 4)                               # [B,G,H,W,3]
+    x = torch.matmul(x, rot.view(B, 1, 1, 3, 3))                                        # model_utils.py:42-44
+    eyes_planes = torch.transpose(torch.transpose(x, 4, 3), 3, 2).reshape(B, C, H, W)   # :181-197
+    return merge_face, eyes_planes, torch.maximum(merge_face, eyes_planes)             # :203
+
+
 def synthetic_loss(out):
     """loss = sum_streams(mean(feat^2) + mean(bg_alpha))."""
     return sum((out["feat_" + t] ** 2).mean() + out["bg_alpha_" + t].mean() for t in ("face", "eyes"))

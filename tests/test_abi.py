@@ -30,6 +30,7 @@ def test_binding_matches_header(lib_built):
     assert ctypes.sizeof(_lib.GnrProblem) == 8 * 4 + 2 * 4 + 9 * 8
     assert ctypes.sizeof(_lib.GnrWeights) == 24 * 8
     assert ctypes.sizeof(_lib.GnrOutputs) == 8 * 8
+    assert ctypes.sizeof(_lib.GnrMergeProblem) == 16 + 6 * 8        # 3 ints (+pad) + 6 pointers
 
 
 def test_validation_errors_without_gpu(lib_built):

@@ -97,3 +97,13 @@ def test_synth_is_deterministic():
     assert torch.equal(a, b) and a.shape == (384, 628, 1, 1)
     n = sum(v.numel() for v in synth.hash_mlp_params("eyes").values())
     assert n == 1518979                      # params per stream
+
+
+def test_merge_fixture():
+    """N2: oracle merge vs the maps the reference's GazeNeRFNet handed to its NeuralRenderer."""
+    g = load_golden("g7_merge")
+    mf, ep, m = O.merge_featmaps(g["feat_face"], g["bg_alpha_face"], g["feat_eyes"], g["bg_alpha_eyes"],
+                                 g["bg_featmap"], g["gaze"])
+    assert _maxabs(mf, g["out_merge_face"]) <= 1e-6
+    assert _maxabs(ep, g["out_eyes_planes"]) <= 1e-6
+    assert _maxabs(m, g["out_merge"]) <= 1e-6
