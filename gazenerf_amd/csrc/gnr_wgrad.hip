@@ -256,9 +256,16 @@ void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb,
     wp.tiles_n = (n_valid + WG_TN - 1) / WG_TN;
     wp.tiles_k = (k_valid + WG_TK - 1) / WG_TK;
     const int tiles = wp.tiles_n * wp.tiles_k;
-    long spi = (WG_MAX_BLOCKS / tiles) / batch;
+    // Split count: the kernel places split s on XCD s % 8 (32 CUs x 2 resident workgroups = 64 slots
+    // per XCD).  Every XCD must get the SAME number of workgroups and fill whole rounds, otherwise
+    // the launch waits for one XCD's straggler round (113 splits instead of 112 cost 40 %):
+    // splits = 8 * floor(2 rounds * 64 slots / tiles), made divisible by the batch.
+    long splits_total = 8L * ((2 * 64) / tiles);
+    if (splits_total < 8) splits_total = 8;
+    long spi = splits_total / batch;
     if (spi < 1) spi = 1;
     if (spi > chunks_per_image) spi = chunks_per_image;
+    while ((long)batch * spi * tiles > WG_MAX_BLOCKS && spi > 1) --spi;
     wp.batch = batch; wp.spi = (int)spi;
     wp.chunks_per_image = chunks_per_image;
     wp.chunks_per_split = (chunks_per_image + spi - 1) / spi;
