@@ -382,3 +382,55 @@ def test_merge_end_to_end_with_render_op():
     assert m.shape == (1, 258, 4096) and bool((m >= mf).all()) and bool((m >= ep).all())
     (m ** 2).mean().backward()
     assert torch.isfinite(gaze.grad).all() and float(gaze.grad.abs().sum()) > 0 and torch.isfinite(bg.grad).all()
+
+
+# ----------------------------------------------------------------------------- edge cases
+@pytest.mark.parametrize("n_samples,n_rays,batch", [(2, 1, 1), (512, 3, 1), (33, 5, 2), (64, 1, 4)])
+def test_edge_sizes_forward_and_backward(n_samples, n_rays, batch):
+    """Minimum (2) and maximum (512) sample counts, a single ray, one sample past a chunk boundary
+    (33), more images than rays: forward vs the oracle on its own edges, gradients finite and equal
+    to the oracle's within the fp32 noise bound."""
+    dev = _dev()
+    sub = (torch.arange(n_rays) * 911 + 17) % 4096
+    p = synth.synth_problem(64, batch=batch, camera="11", seed=77, ray_subset=sub)
+    face = synth.hash_mlp_params("face", seed=6, density_scale=10.0)
+    eyes = synth.hash_mlp_params("eyes", seed=6, density_scale=10.0)
+    t_rand = synth.synth_jitter(batch, n_rays, n_samples, seed=8)
+    edges = O.sample_edges(p["xy"], p["R"], p["T"], p["Kinv"], n_samples, t_rand=t_rand)[0]
+    leaves = {k: p[k].clone().requires_grad_(True) for k in ("R", "T", "shape_code", "gaze", "appea_code")}
+    fo = {k: v.clone().requires_grad_(True) for k, v in face.items()}
+    eo = {k: v.clone().requires_grad_(True) for k, v in eyes.items()}
+    ref = O.render_two_stream(p["xy"], leaves["R"], leaves["T"], p["Kinv"], leaves["shape_code"], leaves["gaze"],
+                              leaves["appea_code"], fo, eo, n_samples, t_rand=t_rand)
+    O.synthetic_loss(ref).backward()
+    with torch.no_grad():
+        out_e = _hip(p, face, eyes, n_samples, dev, z_edges=edges, return_weights=True)
+    for tag in ("face", "eyes"):
+        assert _maxabs(out_e["feat_" + tag], ref["feat_" + tag]) <= TOL
+        assert _maxabs(out_e["bg_alpha_" + tag], ref["bg_alpha_" + tag]) <= TOL
+        assert _maxabs(out_e["w_" + tag], ref["w_" + tag]) <= W_TOL
+    out, hl, fp, ep = _grads_hip(p, face, eyes, n_samples, t_rand, dev)
+    for k in leaves:
+        assert torch.isfinite(hl[k].grad).all()
+    if (n_samples & (n_samples - 1)) == 0:          # power-of-two counts: same z as the oracle's sweep
+        for tag, hp, op in (("face", fp, fo), ("eyes", ep, eo)):
+            for name in ("RGB_layer_2.weight", "RGB_layer_0.weight", "density_module.weight", "FeaExt_module_7.bias"):
+                _check_grad("%s.%s" % (tag, name), hp[name].grad, op[name].grad)
+
+
+def test_empty_and_invalid_inputs_are_rejected():
+    """The reference would fail inside PyTorch on empty tensors; the C ABI rejects them up front."""
+    dev = _dev()
+    from gazenerf_amd import _lib
+    p = _to(synth.synth_problem(8), dev)
+    face = _to(synth.hash_mlp_params("face"), dev)
+    empty_xy = p["xy"][:, :, :0].contiguous()
+    with pytest.raises(_lib.GnrError, match="empty problem"):
+        render.render_two_stream(empty_xy, p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"], p["appea_code"],
+                                 face, face, n_samples=32)
+    with pytest.raises(_lib.GnrError, match="hidden=384"):
+        render.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"], p["appea_code"],
+                                 _to(synth.hash_mlp_params("face", hidden=32), dev), None, n_samples=32, hidden=32)
+    with pytest.raises(TypeError):
+        render.render_two_stream(p["xy"].double(), p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"],
+                                 p["appea_code"], face, face, n_samples=32)
