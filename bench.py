@@ -111,13 +111,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the render op)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # GNR_BENCH_DEVICE: test-only override (several ranks on one device to exercise the launcher path)
+    dev_index = int(os.environ.get("GNR_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # backend "nccl" is RCCL on ROCm; GNR_BENCH_BACKEND=gloo is a test-only override (two ranks on
+        # one GPU cannot form an RCCL communicator)
+        backend = os.environ.get("GNR_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from gazenerf_amd import render, synth
     from gazenerf_amd.hiptime import KernelTimer
@@ -207,8 +215,8 @@ def main():
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cfg2b: %dx%d rays x %d samples/ray, two streams (face+eyes), %s, "
-                                   "1 image per GPU%s" % (side, side, n_p, args.mode,
+            "config": {"workload": "%s: %dx%d rays x %d samples/ray, two streams (face+eyes), %s, "
+                                   "1 image per GPU%s" % ("cfg2b" if (side, n_p) == (512, 64) else "custom", side, side, n_p, args.mode,
                                                           ", %d-ray micro-batches" % micro if args.mode == "fwdbwd" else ""),
                        "rays_per_step_per_gpu": n_rays, "samples_per_ray": n_p,
                        "parallelism": "dp%d (images sharded)" % world},
