@@ -266,6 +266,45 @@ def main():
     save("g7_merge", feat_face=ff, bg_alpha_face=af, feat_eyes=fe, bg_alpha_eyes=ae, bg_featmap=bgm,
          gaze=prob["gaze"], out_merge_face=rendered[1], out_eyes_planes=rendered[2], out_merge=rendered[3])
 
+    # ---------------------------------------------------------------- N3: checkpoint format
+    print("[ref_checkpoint_tiny] a checkpoint written the way trainer/gazenerf_trainer.py:156-191 does")
+    import random as _random
+    import numpy as _np
+    from gazenerf_amd import checkpoint as CK
+    from gazenerf_amd import HotPathRenderer
+    o6 = ref["BaseOptions"]({"featmap_size": 8, "featmap_nc": 6, "pred_img_size": 32})
+    o6.num_sample_coarse, o6.mlp_hidden_nchannels = 8, 32
+    torch.manual_seed(5)
+    net6 = ref["GazeNeRFNet"](o6, False, False)
+    opt6 = torch.optim.Adam(net6.parameters(), lr=1e-4)
+    state = {"torch_random_state": torch.get_rng_state(), "numpy_random_state": _np.random.get_state(),
+             "random_random_state": _random.getstate(), "checkpoint_epoch": 3, "checkpoint_loss": 0.25,
+             "resume_epoch": 4, "net": net6.state_dict(), "para": o6, "optimizer": opt6.state_dict(),
+             "iden_offset": torch.nn.Parameter(torch.zeros(4, 100)), "expr_offset": torch.nn.Parameter(torch.zeros(4, 79)),
+             "appea_offset": torch.nn.Parameter(torch.zeros(4, 127)),
+             "delta_EulurAngles": torch.nn.Parameter(torch.zeros(4, 3)), "delta_Tvecs": torch.nn.Parameter(torch.zeros(4, 3, 1))}
+    ck_path = os.path.join(GOLD, "ref_checkpoint_tiny.json")          # the reference names it *.json too
+    torch.save(state, ck_path)
+    print("  wrote %s (%.0f KB)" % (os.path.relpath(ck_path, ROOT), os.path.getsize(ck_path) / 1024))
+    save("ref_checkpoint_tiny_expect", **{k: v for k, v in net6.state_dict().items() if k.startswith("fg_CD_predictor")},
+         num_sample_coarse=o6.num_sample_coarse, featmap_nc=o6.featmap_nc, hidden=o6.mlp_hidden_nchannels)
+    # our writer -> the reference's own resume path (torch.load + load_state_dict, gazenerf_trainer.py:102,116)
+    ck = CK.load_reference_checkpoint(ck_path)
+    ren = HotPathRenderer(**CK.renderer_kwargs_from_options(ck["para"]))
+    missing, _ = CK.apply_to_renderer(ren, ck)
+    assert not missing
+    with torch.no_grad():
+        ren.fg_CD_predictor_face.RGB_layer_2.bias.add_(1.0)
+    CK.update_from_renderer(ck, ren)
+    tmp = "/tmp/gnr_roundtrip_ckpt.json"
+    CK.save_reference_checkpoint(tmp, ck)
+    back = torch.load(tmp, map_location=torch.device("cpu"), weights_only=False)      # reference-side load
+    assert type(back["para"]).__module__ == "configs.gazenerf_options" and back["para"].featmap_nc == 6
+    net6b = ref["GazeNeRFNet"](back["para"], False, False)
+    net6b.load_state_dict(back["net"])
+    check("reference resumes from our checkpoint", net6b.fg_CD_predictor_face.RGB_layer_2.bias,
+          net6.fg_CD_predictor_face.RGB_layer_2.bias + 1.0, 0.0)
+
     # ---------------------------------------------------------------- G2/G3/G4: full width
     hidden = synth.HIDDEN
     sub = torch.arange(0, 4096, 32) + (torch.arange(128) % 32)       # 128 rays, all rows/cols hit
