@@ -137,8 +137,8 @@ size_t gnr_workspace_bytes(const GnrProblem* p, int n_streams, int kind) {
     }
 }
 
-int gnr_fwd(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes, const GnrOutputs* out,
-            int save_for_backward, void* workspace, size_t ws_bytes, void* stream) {
+static int fwd_impl(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes, const GnrOutputs* out,
+                    int save_for_backward, void* workspace, size_t ws_bytes, void* stream, bool bf16x3) {
     const int n_streams = eyes ? 2 : 1;
     if (check_problem(p, n_streams)) return 1;
     if (check_weights(face, "first-stream")) return 1;
@@ -156,9 +156,11 @@ int gnr_fwd(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes,
     carve_fwd(p, n_streams, save, (char*)workspace, &fp);
     fp.want_wl = (out->weights[0] || (n_streams > 1 && out->weights[1])) ? 1 : 0;
     const GnrWeights* ws_in[2] = {face, eyes};
-    launch_prep(*p, n_streams, ws_in, fp.ws, st);
+    launch_prep(*p, n_streams, ws_in, fp.ws, st, !bf16x3);
+    if (bf16x3) launch_prep3(*p, n_streams, ws_in, fp.ws, st);
     if (hipEvent_t e0 = g_ev_start.load()) (void)hipEventRecord(e0, st);
-    launch_fwd(fp, st);
+    if (bf16x3) launch_fwd3(fp, st);
+    else launch_fwd(fp, st);
     if (hipEvent_t e1 = g_ev_stop.load()) (void)hipEventRecord(e1, st);
 
     CombineParams cp{};
@@ -175,6 +177,16 @@ int gnr_fwd(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes,
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("gnr_fwd: launch failed: %s", hipGetErrorString(e));
     return 0;
+}
+
+int gnr_fwd(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes, const GnrOutputs* out,
+            int save_for_backward, void* workspace, size_t ws_bytes, void* stream) {
+    return fwd_impl(p, face, eyes, out, save_for_backward, workspace, ws_bytes, stream, false);
+}
+
+int gnr_fwd_bf16x3(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes, const GnrOutputs* out,
+                   void* workspace, size_t ws_bytes, void* stream) {
+    return fwd_impl(p, face, eyes, out, 0, workspace, ws_bytes, stream, true);
 }
 
 int gnr_bwd(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes, const GnrOutputGrads* dout,

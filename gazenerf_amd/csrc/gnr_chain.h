@@ -210,6 +210,44 @@ __device__ __forceinline__ float* dump_ptr(float* dst, int C, long chunk, int j,
     return dst + chunk * (CHUNK * (long)C) + (4 * h) * CHUNK + j;
 }
 
+// Chunk-local alpha compositing (CalcRayColor, utils/model_utils.py:498-534) of the 32 samples a wave
+// owns: alpha_i = 1 - exp(-relu(sigma_raw_i) delta_i); T_i = exclusive product of (1 - alpha + 1e-10)
+// WITHIN the chunk; w_i = alpha_i T_i.  Writes the chunk's weighted feature sum (288 floats), its
+// total transmittance, sum w and sum w z; combine_kernel applies the cross-chunk prefix products.
+__device__ __forceinline__ void composite_chunk(const f32x16 (&feat)[NT_H], float sigma_raw, float delta, float z0,
+                                                const StreamWs& ws, long chunk, long row, int lane, bool keep_wl) {
+    const int j = lane & 31, h = lane >> 5;
+    const float sigma = fmaxf(sigma_raw, 0.0f);
+    const float alpha = 1.0f - expf(-sigma * delta);
+    const float x = (1.0f - alpha) + 1e-10f;
+    float incl = x;                                  // inclusive prefix product over the 32 samples
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+        const float o = __shfl_up(incl, d, 32);
+        if (j >= d) incl *= o;
+    }
+    float excl = __shfl_up(incl, 1, 32);
+    if (j == 0) excl = 1.0f;
+    const float wl = alpha * excl;
+    const float ptot = __shfl(incl, 31, 32);
+    const float accw = half_sum32(wl);
+    const float dsum = half_sum32(wl * z0);
+    if (lane == 0) *(f32x4*)(ws.part_sc + chunk * 4) = f32x4{ptot, accw, dsum, 0.0f};
+    if (keep_wl && h == 0) ws.wl[row] = wl;
+    float* pf = ws.part_feat + chunk * FEAT_PAD + 4 * h;
+#pragma unroll
+    for (int t = 0; t < NT_F; ++t)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            f32x4 v;
+            v.x = half_sum32(wl * feat[t][4 * rq + 0]);
+            v.y = half_sum32(wl * feat[t][4 * rq + 1]);
+            v.z = half_sum32(wl * feat[t][4 * rq + 2]);
+            v.w = half_sum32(wl * feat[t][4 * rq + 3]);
+            if (j == 0) *(f32x4*)(pf + 32 * t + 8 * rq) = v;
+        }
+}
+
 // ReLU masks as bits: lane l keeps the signs of its own registers, tile pair (2w, 2w+1) -> word w,
 // bit 16*(t&1) + r.  Stored lane-major ([word][64 lanes]) so a wave moves 256 contiguous bytes per word.
 constexpr int RELU_WORDS = NT_H / 2;     // 6

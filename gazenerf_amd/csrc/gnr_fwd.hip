@@ -174,37 +174,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel(const FwdParams fp) {
         if (SAVE) dump<NT_F>(A, ws.act_feat, FEAT_PAD, chunk, j, h);
 
         // ---- A5: chunk-local compositing (utils/model_utils.py:498-534) ----
-        const float sigma = fmaxf(sig, 0.0f);
-        const float alpha = 1.0f - expf(-sigma * delta);
-        const float x = (1.0f - alpha) + 1e-10f;
-        // inclusive prefix product over the 32 samples of the chunk
-        float incl = x;
-#pragma unroll
-        for (int d = 1; d < 32; d <<= 1) {
-            const float o = __shfl_up(incl, d, 32);
-            if (j >= d) incl *= o;
-        }
-        float excl = __shfl_up(incl, 1, 32);
-        if (j == 0) excl = 1.0f;
-        const float wl = alpha * excl;
-        const float ptot = __shfl(incl, 31, 32);
-        const float accw = half_sum32(wl);
-        const float dsum = half_sum32(wl * z0);
-        if (lane == 0) *(f32x4*)(ws.part_sc + chunk * 4) = f32x4{ptot, accw, dsum, 0.0f};
-        if ((SAVE || fp.want_wl) && h == 0) ws.wl[row] = wl;
-
-        float* pf = ws.part_feat + chunk * FEAT_PAD + 4 * h;
-#pragma unroll
-        for (int t = 0; t < NT_F; ++t)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                f32x4 v;
-                v.x = half_sum32(wl * A[t][4 * rq + 0]);
-                v.y = half_sum32(wl * A[t][4 * rq + 1]);
-                v.z = half_sum32(wl * A[t][4 * rq + 2]);
-                v.w = half_sum32(wl * A[t][4 * rq + 3]);
-                if (j == 0) *(f32x4*)(pf + 32 * t + 8 * rq) = v;
-            }
+        composite_chunk(A, sig, delta, z0, ws, chunk, row, lane, SAVE || fp.want_wl);
     }
 }
 

@@ -113,7 +113,10 @@ struct CombineParams {
 
 // host-side launchers (defined in the .hip translation units)
 void launch_prep(const GnrProblem& p, int n_streams, const GnrWeights* const* w, StreamWs* ws,
-                 hipStream_t stream);
+                 hipStream_t stream, bool pack_fp32 = true);
+void launch_prep3(const GnrProblem& p, int n_streams, const GnrWeights* const* w, StreamWs* ws,
+                  hipStream_t stream);
+void launch_fwd3(const FwdParams& fp, hipStream_t stream);
 void launch_fwd(const FwdParams& fp, hipStream_t stream);
 void launch_combine(const CombineParams& cp, hipStream_t stream);
 

@@ -85,7 +85,7 @@ __global__ void bias_kernel(const BiasParams bp) {
 }
 
 void launch_prep(const GnrProblem& p, int n_streams, const GnrWeights* const* w, StreamWs* ws,
-                 hipStream_t stream) {
+                 hipStream_t stream, bool pack_fp32) {
     const int vp = ENC_CH + p.shape_dims + p.gaze_dims;
     for (int s = 0; s < n_streams; ++s) {
         PackParams pp;
@@ -105,7 +105,7 @@ void launch_prep(const GnrProblem& p, int n_streams, const GnrWeights* const* w,
             }
         }
         pp.packed = ws[s].packed;
-        hipLaunchKernelGGL(pack_kernel, dim3(1024), dim3(256), 0, stream, pp);
+        if (pack_fp32) hipLaunchKernelGGL(pack_kernel, dim3(1024), dim3(256), 0, stream, pp);
         BiasParams bp;
         bp.prob = p; bp.w = *w[s]; bp.bias = ws[s].bias; bp.wsig = ws[s].wsig;
         hipLaunchKernelGGL(bias_kernel, dim3(N_CHAIN, p.batch), dim3(H), 0, stream, bp);

@@ -142,7 +142,7 @@ def _alloc_ws(nbytes, device):
     return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
 
 
-def _run_forward(prob: _Problem, streams, save: bool, want_depth: bool, want_weights: bool):
+def _run_forward(prob: _Problem, streams, save: bool, want_depth: bool, want_weights: bool, bf16x3: bool = False):
     lib = _lib.load()
     dev = prob.device
     n_streams = len(streams)
@@ -167,9 +167,13 @@ def _run_forward(prob: _Problem, streams, save: bool, want_depth: bool, want_wei
             res.append((feat, bga, dep, wts))
         w0 = _weights_struct(streams[0])
         w1 = _weights_struct(streams[1]) if n_streams > 1 else None
-        rc = lib.gnr_fwd(C.byref(prob.c), C.byref(w0), C.byref(w1) if w1 is not None else None,
-                         C.byref(outs), 1 if save else 0, C.c_void_p(ws.data_ptr()), ws.numel(),
-                         _stream_ptr(dev))
+        if bf16x3:
+            rc = lib.gnr_fwd_bf16x3(C.byref(prob.c), C.byref(w0), C.byref(w1) if w1 is not None else None,
+                                    C.byref(outs), C.c_void_p(ws.data_ptr()), ws.numel(), _stream_ptr(dev))
+        else:
+            rc = lib.gnr_fwd(C.byref(prob.c), C.byref(w0), C.byref(w1) if w1 is not None else None,
+                             C.byref(outs), 1 if save else 0, C.c_void_p(ws.data_ptr()), ws.numel(),
+                             _stream_ptr(dev))
         _lib.check(rc, lib)
     return res, ws
 
@@ -188,7 +192,10 @@ class _RenderFn(torch.autograd.Function):
                                 prob.c.appea_dims, cfg["feat_nc"], "stream%d" % s)
                    for s in range(n_streams)]
         need_grad = any(ctx.needs_input_grad[1:])
-        res, ws = _run_forward(prob, streams, need_grad, cfg["want_depth"], cfg["want_weights"])
+        bf16x3 = cfg.get("precision", "fp32") == "bf16x3"
+        if bf16x3 and need_grad:
+            raise RuntimeError("precision='bf16x3' is inference-only; run it under torch.no_grad() or use 'fp32'")
+        res, ws = _run_forward(prob, streams, need_grad, cfg["want_depth"], cfg["want_weights"], bf16x3)
         ctx.cfg, ctx.prob, ctx.streams = cfg, prob, streams
         ctx.saved_ws = ws if need_grad else None
         ctx.param_shapes = [tuple(t.shape) for t in flat_params]
@@ -258,19 +265,25 @@ def render_two_stream(batch_xy, R, T, Kinv, shape_code, gaze, appea_code, face_p
                       *, n_samples: int, world_z1: float = 2.5, world_z2: float = -3.5,
                       t_rand: Optional[torch.Tensor] = None, z_edges: Optional[torch.Tensor] = None,
                       return_depth: bool = False, return_weights: bool = False,
-                      hidden: int = 384, feat_nc: int = 258):
+                      hidden: int = 384, feat_nc: int = 258, precision: str = "fp32"):
     """Run the hot path.  Returns a dict with feat_face [B,feat_nc,N_r], bg_alpha_face [B,1,N_r]
     (and *_eyes when ``eyes_params`` is given; depth_* / w_* [B,1,N_r,N_p] on request).
 
     ``eyes_params=None`` evaluates a single MLP -- the hierarchical fine pass with the third
     network (models/gaze_nerf.py:102-108); its results come back under the "face" keys.
+
+    ``precision="bf16x3"`` (inference only) runs the dense layers on bf16 MFMA with a 3-term hi/lo
+    split of both operands; it agrees with the default exact-fp32 path to that path's own rounding
+    noise (see gnr_fwd_bf16x3 in include/gnr.h).
     """
+    if precision not in ("fp32", "bf16x3"):
+        raise ValueError("precision must be 'fp32' or 'bf16x3'")
     streams = [params_to_list(face_params)]
     if eyes_params is not None:
         streams.append(params_to_list(eyes_params))
     cfg = dict(xy=batch_xy, Kinv=Kinv, n_samples=int(n_samples), world_z1=world_z1, world_z2=world_z2,
                t_rand=t_rand, z_edges=z_edges, hidden=hidden, feat_nc=feat_nc, n_streams=len(streams),
-               want_depth=return_depth, want_weights=return_weights)
+               want_depth=return_depth, want_weights=return_weights, precision=precision)
     flat = [t for st in streams for t in st]
     outs = _RenderFn.apply(cfg, R, T, shape_code, gaze, appea_code, *flat)
     res: Dict[str, torch.Tensor] = {}

@@ -10,7 +10,7 @@ from conftest import ROOT
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "gnr.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(gnr_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(gnr_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_symbols_exported(lib_built):

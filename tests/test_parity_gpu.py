@@ -50,25 +50,30 @@ def _hip(p, face, eyes, n_samples, dev, **kw):
                                     n_samples=n_samples, **kw)
 
 
+PRECISIONS = ["fp32", "bf16x3"]   # bf16x3: gnr_fwd_bf16x3, the split-bf16 inference kernel -- same bound
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", ["g2_np32_frontal", "g2_np64_frontal", "g2_np64_orbit3",
                                   "g3_np64_train", "g4_np64_opaque"])
-def test_forward_vs_reference_fixture(name):
+def test_forward_vs_reference_fixture(name, precision):
     dev = _dev()
     g = load_golden(name)
     face, eyes = _weights(g)
     with torch.no_grad():
         out = _hip(golden_problem(g), face, eyes, int(g["n_samples"]), dev, t_rand=g.get("t_rand"),
-                   return_depth=True)
+                   return_depth=True, precision=precision)
     for tag in ("face", "eyes"):
         assert _maxabs(out["feat_" + tag], g["out_feat_" + tag]) <= TOL
         assert _maxabs(out["bg_alpha_" + tag], g["out_bg_alpha_" + tag]) <= TOL
         assert _maxabs(out["depth_" + tag], g["out_depth_" + tag]) <= DEPTH_TOL
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("n_samples,n_rays,batch,train", [(64, 96, 2, True), (32, 50, 1, False),
                                                           (40, 33, 1, True), (192, 16, 1, False),
                                                           (8, 7, 3, True)])
-def test_forward_vs_oracle_live(n_samples, n_rays, batch, train):
+def test_forward_vs_oracle_live(n_samples, n_rays, batch, train, precision):
     """Ragged sizes: ray counts that do not fill a workgroup, sample counts that do not fill a
     32-sample chunk (40, 8) and the 192-sample fine-pass width.
 
@@ -88,9 +93,11 @@ def test_forward_vs_oracle_live(n_samples, n_rays, batch, train):
     with torch.no_grad():
         ref = O.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"],
                                   p["appea_code"], face, eyes, n_samples, t_rand=t_rand)
-        out = _hip(p, face, eyes, n_samples, dev, t_rand=t_rand, return_depth=True, return_weights=True)
+        out = _hip(p, face, eyes, n_samples, dev, t_rand=t_rand, return_depth=True, return_weights=True,
+                   precision=precision)
         edges = O.sample_edges(p["xy"], p["R"], p["T"], p["Kinv"], n_samples, t_rand=t_rand)[0]
-        out_e = _hip(p, face, eyes, n_samples, dev, z_edges=edges, return_depth=True, return_weights=True)
+        out_e = _hip(p, face, eyes, n_samples, dev, z_edges=edges, return_depth=True, return_weights=True,
+                     precision=precision)
     for tag in ("face", "eyes"):
         for o, wtol in ((out, W_TOL if pow2 else 5 * TOL), (out_e, W_TOL)):
             assert _maxabs(o["feat_" + tag], ref["feat_" + tag]) <= TOL
@@ -102,14 +109,15 @@ def test_forward_vs_oracle_live(n_samples, n_rays, batch, train):
     assert _maxabs(zv, ref["samples"]["zvals"]) <= 4e-6
 
 
-def test_single_stream_equals_two_stream():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_single_stream_equals_two_stream(precision):
     dev = _dev()
     p = synth.synth_problem(64, batch=1, seed=3, ray_subset=torch.arange(64))
     face = synth.hash_mlp_params("face", seed=1, density_scale=30.0)
     eyes = synth.hash_mlp_params("eyes", seed=1, density_scale=30.0)
     with torch.no_grad():
-        two = _hip(p, face, eyes, 64, dev)
-        one = _hip(p, eyes, None, 64, dev)
+        two = _hip(p, face, eyes, 64, dev, precision=precision)
+        one = _hip(p, eyes, None, 64, dev, precision=precision)
     assert torch.equal(two["feat_eyes"], one["feat_face"])
     assert torch.equal(two["bg_alpha_eyes"], one["bg_alpha_face"])
 
@@ -185,6 +193,14 @@ def test_errors_are_exceptions():
     with pytest.raises(_lib.GnrError, match="n_samples"):
         render.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"],
                                  p["appea_code"], face, face, n_samples=1000)
+    # the split-bf16 kernel is inference-only: asking it for gradients is an error, not a fallback
+    sc = p["shape_code"].clone().requires_grad_(True)
+    with pytest.raises(RuntimeError, match="inference-only"):
+        render.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], sc, p["gaze"],
+                                 p["appea_code"], face, face, n_samples=32, precision="bf16x3")
+    with pytest.raises(ValueError, match="precision"):
+        render.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"],
+                                 p["appea_code"], face, face, n_samples=32, precision="fp16")
 
 
 # ----------------------------------------------------------------------------- backward
