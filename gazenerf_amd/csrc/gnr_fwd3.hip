@@ -40,11 +40,16 @@ __host__ __device__ __forceinline__ unsigned bf16_rne(float x) {
 }
 __host__ __device__ __forceinline__ float bf16_to_f32(unsigned b) { return __builtin_bit_cast(float, b << 16); }
 
-// split a pair of fp32 values into packed {hi(a), hi(b)} and {lo(a), lo(b)}
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// split a pair of fp32 values into packed {hi(a), hi(b)} and {lo(a), lo(b)}: v_cvt_pk_bf16_f32 (RNE),
+// shift/mask back to fp32, one packed subtract, v_cvt_pk_bf16_f32 -- 5 VALU instructions per pair
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
-    const unsigned ha = bf16_rne(a), hb = bf16_rne(b);
-    hi = ha | (hb << 16);
-    lo = bf16_rne(a - bf16_to_f32(ha)) | (bf16_rne(b - bf16_to_f32(hb)) << 16);
+    const f32x2 v = {a, b};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    const f32x2 hf = {__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, bf16x2));
 }
 
 // k-order of a K=16 bf16 step s = 2t + u over an activation tile held in the C/D layout: lane-half h
@@ -104,33 +109,135 @@ __global__ void pack3_kernel(const Pack3Params pp) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// weight stream: batches of WB3 rows (hi + lo = 2 buffer loads per row), NBUF batches in registers
+// weight ring: the workgroup's four waves consume the SAME rows, so the stream goes through LDS once
+// per workgroup instead of four times through the vector L1 (which at 2 KiB per 96 matrix-pipe cycles
+// per wave is past the 64 B/clk the texture path delivers).  LDS-DMA (buffer_load_dwordx4 ... lds)
+// fills a ring of NSLOT batches of RB_ROWS rows; wave w fetches row w of each batch (2 KiB = 2 pieces).
+//
+// Per batch k ("phase"), every wave:
+//   s_waitcnt vmcnt(2 (DEPTH-1))   its own share of batch k+1 has landed
+//   s_barrier                      -> batch k+1 is complete and visible; every wave has issued (hence
+//                                     fetched the operands of) all MFMAs of batch k-1
+//   request batch k+DEPTH+1        into the slot batch k-1 occupied            (NSLOT = DEPTH + 2)
+//   ds_read rows 2,3 of batch k;  MFMAs of rows 0,1;  ds_read rows 0,1 of batch k+1;  MFMAs of rows 2,3
+// The DMA is inline asm (hipcc would otherwise put a vmcnt(0) in front of every LDS read that might
+// alias it); hipcc's own vmcnt bookkeeping stays correct because extra outstanding operations only make
+// its counted waits stricter, and ours count only operations issued after the ones we wait for.
+// Addressing rules (LDS dest = M0 + inst_offset + lane*16, M0 beyond 64 KiB, zero fill past
+// num_records) are pinned by tools/ubench/ldsdma_probe.hip.
 // ---------------------------------------------------------------------------------------------
-constexpr int WB3 = 2;              // rows per batch (4 KiB = 4 buffer loads per wave)
-constexpr int NBUF = 3;             // batches in registers (48 VGPRs): 2 in flight = 384 matrix-pipe cycles
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-struct W3Stream {
-    __amdgpu_buffer_rsrc_t rs;
-    unsigned voff;                       // lane*16 + byte offset of the batch most recently requested
-    u32x4 g[NBUF][WB3][2];               // [buffer][row][hi/lo]
+// Timing experiments only (results are wrong with any bit set): build with -DGNR_ABLATE=<bits>.
+//   1 no LDS-DMA requests   2 no barriers   4 no activation conversion   8 no ring reads   16 no vmcnt waits
+#ifndef GNR_ABLATE
+#define GNR_ABLATE 0
+#endif
+constexpr int ABL = GNR_ABLATE;
+
+constexpr int RB_ROWS = 4;                             // rows per ring batch (one per wave)
+constexpr int NSLOT = 6;
+constexpr int DEPTH = NSLOT - 2;                       // batches in flight beyond the one made visible
+constexpr unsigned BATCH_BYTES = RB_ROWS * 2048u;      // 8 KiB
+constexpr unsigned RING_BYTES = NSLOT * BATCH_BYTES;   // 48 KiB at LDS offset 0
+static_assert(RB_ROWS == WAVES_PER_WG, "one row of each batch per wave");
+
+struct WRing {
+    i32x4 rs;                // buffer descriptor of the packed stream (num_records = exact bytes)
+    unsigned voff;           // lane*16 + wave*2048
+    unsigned soff;           // stream offset of the next batch to request
+    unsigned wr;             // LDS address (M0) of this wave's row in the slot to fill next
+    unsigned wr_end;         // wr wraps here
+    unsigned rd;             // ring offset of the batch being consumed
+    const char* lane_base;   // ring + lane*16
+    u32x4 g[2][2][2];        // [pair][row][hi/lo]: rows 0,1 and rows 2,3 of the current batch
 };
 
-template <int Q>
-__device__ __forceinline__ u32x4 w3load(const W3Stream& w) {
-    // 1 KiB piece Q (0..3) of a 4 KiB batch, addressed through the 12-bit immediate
-    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.voff + (unsigned)Q * 1024u, 0, 0));
+struct RingTicket {
+    unsigned soff, wr;
+};
+
+// Measured (tools/ablate_fwd3.sh): a piece blocks the issuing wave for ~94 cycles, and that is not
+// contention between the four waves -- spreading their requests over the phase (one wave per MFMA group)
+// made the kernel 12 % slower, because the barrier then waits for whichever wave is stalled.
+__device__ __forceinline__ void ring_issue(const WRing& w, const RingTicket& t) {
+    if (ABL & 1) return;
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen offset:1024 lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(w.voff), "s"(w.rs), "s"(t.soff), "s"(t.wr)
+        : "memory");
 }
-__device__ __forceinline__ void w3batch(const W3Stream& w, u32x4 (&g)[WB3][2]) {
-    g[0][0] = w3load<0>(w); g[0][1] = w3load<1>(w);
-    g[1][0] = w3load<2>(w); g[1][1] = w3load<3>(w);
+
+__device__ __forceinline__ RingTicket ring_advance(WRing& w) {
+    const RingTicket t = {w.soff, w.wr};
+    w.soff += BATCH_BYTES;
+    w.wr += BATCH_BYTES;
+    if (w.wr == w.wr_end) w.wr -= RING_BYTES;
+    return t;
 }
-__device__ __forceinline__ void w3_init(W3Stream& w, const float* packed, int lane) {
-    w.rs = __builtin_amdgcn_make_buffer_rsrc((void*)packed, 0, 0x7ffffff0, 0x00020000);
-    w.voff = (unsigned)lane * 16u;
+
+__device__ __forceinline__ void ring_request(WRing& w) { ring_issue(w, ring_advance(w)); }
+
+__device__ __forceinline__ void ring_read_pair(const WRing& w, unsigned slot_off, int pair, u32x4 (&g)[2][2]) {
+    if (ABL & 8) return;
+    const char* p = w.lane_base + slot_off + pair * 4096;
+    g[0][0] = *(const u32x4*)(p);
+    g[0][1] = *(const u32x4*)(p + 1024);
+    g[1][0] = *(const u32x4*)(p + 2048);
+    g[1][1] = *(const u32x4*)(p + 3072);
+}
+
+__device__ __forceinline__ void ring_init(WRing& w, const float* packed, unsigned stream_bytes, char* ring, int lane,
+                                          unsigned wave) {
+    const unsigned long long a = (unsigned long long)packed;
+    w.rs.x = (int)(unsigned)a;
+    w.rs.y = (int)(unsigned)(a >> 32);
+    w.rs.z = (int)stream_bytes;
+    w.rs.w = 0x00020000;
+    w.voff = (unsigned)lane * 16u + wave * 2048u;
+    w.soff = 0;
+    w.wr = (unsigned)(size_t)ring + wave * 2048u;
+    w.wr_end = w.wr + RING_BYTES;
+    w.rd = 0;
+    w.lane_base = ring + lane * 16;
+    if (ABL & 8) {
 #pragma unroll
-    for (int b = 0; b < NBUF - 1; ++b) {
-        w3batch(w, w.g[b]);
-        if (b + 1 < NBUF - 1) w.voff += WB3 * 2048u;
+        for (int q = 0; q < 8; ++q) w.g[q >> 2][(q >> 1) & 1][q & 1] = u32x4{(unsigned)lane, 1u, 2u, 3u};
+    }
+    if (ABL & 4) {}
+#pragma unroll
+    for (int k = 0; k <= DEPTH; ++k) ring_request(w);
+}
+
+// first rows into registers: call after ring_init, with no other barrier in between
+__device__ __forceinline__ void ring_start(WRing& w) {
+    wait_vm<2 * DEPTH>();
+    __builtin_amdgcn_s_barrier();
+    ring_read_pair(w, 0, 0, w.g[0]);
+}
+
+// NP pairs of rows (NP even): pair(P, g) issues the six MFMAs of rows 2P, 2P+1 from g[row][hi/lo]
+template <int NP, class PairFn>
+__device__ __forceinline__ void ring_layer(WRing& w, PairFn pair) {
+    static_assert(NP % 2 == 0, "layers start and end on batch boundaries");
+#pragma clang loop unroll(full)
+    for (int ph = 0; ph < NP / 2; ++ph) {
+        if (!(ABL & 16)) wait_vm<2 * (DEPTH - 1)>();
+        if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
+        ring_request(w);
+        ring_read_pair(w, w.rd, 1, w.g[1]);
+        pair(2 * ph, w.g[0]);
+        const unsigned nrd = (w.rd + BATCH_BYTES == RING_BYTES) ? 0u : w.rd + BATCH_BYTES;
+        ring_read_pair(w, nrd, 0, w.g[0]);
+        pair(2 * ph + 1, w.g[1]);
+        w.rd = nrd;
     }
 }
 
@@ -143,13 +250,11 @@ struct NoSide {
     __device__ __forceinline__ void operator()(int, int, float, float) const {}
 };
 
-// bias + optional ReLU + split of register pair (r, r+1) of raw accumulator tile `src` into `dst`
+// optional ReLU + split of register pair (r, r+1) of accumulator tile `src` (bias already inside)
 template <bool RELU, class Side>
-__device__ __forceinline__ void convert_pair(const f32x16& src, const float* bias_tile, int h, int r, BTile& dst, int t,
-                                             Side side) {
-    const int ch = (r & 3) + 8 * (r >> 2) + 4 * h;                       // r even: channels ch, ch+1
-    float a = src[r] + bias_tile[ch], b = src[r + 1] + bias_tile[ch + 1];
-    if (RELU) { a = a > 0.0f ? a : 0.0f; b = b > 0.0f ? b : 0.0f; }
+__device__ __forceinline__ void convert_pair(const f32x16& src, int r, BTile& dst, int t, Side side) {
+    float a = src[r], b = src[r + 1];
+    if (RELU) { a = fmaxf(a, 0.0f); b = fmaxf(b, 0.0f); }
     side(t, r, a, b);
     unsigned hi, lo;
     split_pair(a, b, hi, lo);
@@ -158,59 +263,68 @@ __device__ __forceinline__ void convert_pair(const f32x16& src, const float* bia
     dst.l[u][w] = lo;
 }
 
-// ---- one dense layer from RAW previous-layer accumulators --------------------------------------
-// prev[t] (+ prev_bias, ReLU?) is converted tile by tile while the MFMAs of the previous tile run.
-template <int NT_IN, int NT_OUT, bool ZERO, bool RELU_IN, class Side = NoSide>
-__device__ __forceinline__ void mm3_h(const f32x16 (&prev)[NT_H], const float* prev_bias, int h, f32x16 (&acc)[NT_H],
-                                      W3Stream& w, Side side = Side()) {
-    constexpr int ROWS_PER_TILE = 2 * NT_OUT;               // two K=16 steps
-    constexpr int NROW = NT_IN * ROWS_PER_TILE;
-    constexpr int NB = NROW / WB3, NB_TILE = ROWS_PER_TILE / WB3;
-    static_assert(ROWS_PER_TILE % WB3 == 0 && NB % NBUF == 0, "rows must keep batch and buffer phase");
-    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    BTile cur, nxt;
+// accumulator tile nt starts from its bias: lane (j, h) register r <-> channel 32nt + (r&3) + 8(r>>2) + 4h
+__device__ __forceinline__ void bias_init(f32x16& acc, const float* bias, int nt, int h) {
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) convert_pair<RELU_IN>(prev[0], prev_bias, h, r, cur, 0, side);
-#pragma clang loop unroll(full)
-    for (int t = 0; t < NT_IN; ++t) {
-#pragma clang loop unroll(full)
-        for (int bt = 0; bt < NB_TILE; ++bt) {
-            const int kb = t * NB_TILE + bt;
-            // request the batch NBUF-1 ahead (runs on into the next layer's rows)
-            w.voff += WB3 * 2048u;
-            w3batch(w, w.g[(kb + NBUF - 1) % NBUF]);
-            // a slice of the NEXT input tile's conversion
-            if (t + 1 < NT_IN) {
-#pragma unroll
-                for (int pr = (bt * 8) / NB_TILE; pr < ((bt + 1) * 8) / NB_TILE; ++pr)
-                    convert_pair<RELU_IN>(prev[t + 1], prev_bias + 32 * (t + 1), h, 2 * pr, nxt, t + 1, side);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // the rows of the batch interleaved term by term: consecutive MFMAs hit different accumulators
-#pragma unroll
-            for (int term = 0; term < 3; ++term) {
-#pragma unroll
-                for (int q = 0; q < WB3; ++q) {
-                    const int i = bt * WB3 + q;             // row within the tile
-                    const int u = i / NT_OUT, nt = i % NT_OUT;
-                    const u32x4 a = w.g[kb % NBUF][q][term == 1 ? 1 : 0];      // hi, lo, hi
-                    const u32x4 b = term == 2 ? cur.l[u] : cur.h[u];           // hi, hi, lo
-                    acc[nt] = mfma_bf(a, b, (ZERO && term == 0 && t == 0 && u == 0) ? zero : acc[nt]);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (t + 1 < NT_IN) cur = nxt;
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *(const f32x4*)(bias + 32 * nt + 8 * q + 4 * h);
+        acc[4 * q + 0] = v.x; acc[4 * q + 1] = v.y; acc[4 * q + 2] = v.z; acc[4 * q + 3] = v.w;
     }
 }
 
-// ---- the 64-slot positional encoding (4 K=16 steps = two pre-converted BTiles in LDS) ------------
+// ---- one dense layer from the previous layer's accumulators ---------------------------------------
+// prev[t] (bias inside; ReLU here if RELU_IN) is split tile by tile underneath the MFMAs of the tile
+// before it.  INIT: acc starts from out_bias (else it continues, e.g. L5 after its encoding part).
+template <int NT_IN, int NT_OUT, bool INIT, bool RELU_IN, class Side = NoSide>
+__device__ __forceinline__ void mm3_h(const f32x16 (&prev)[NT_H], f32x16 (&acc)[NT_H], const float* out_bias, int h,
+                                      WRing& w, Side side = Side()) {
+    constexpr int PPT = NT_OUT;                 // row pairs per input tile (2 K-steps x NT_OUT rows / 2)
+    constexpr int NP = NT_IN * PPT;
+    BTile cur, nxt;
+    if (INIT) { bias_init(acc[0], out_bias, 0, h); bias_init(acc[1 % NT_OUT], out_bias, 1 % NT_OUT, h); }
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) convert_pair<RELU_IN>(prev[0], r, cur, 0, side);
+    ring_layer<NP>(w, [&](int P, const u32x4 (&g)[2][2]) {
+        const int t = P / PPT, pt = P % PPT;
+        const int i0 = 2 * pt, i1 = i0 + 1;
+        const int u0 = i0 / NT_OUT, n0 = i0 % NT_OUT, u1 = i1 / NT_OUT, n1 = i1 % NT_OUT;
+        // biases of the tiles the NEXT pair opens
+        if (INIT && t == 0) {
+#pragma unroll
+            for (int i = i0 + 2; i < i0 + 4; ++i)
+                if (i >= 2 && i < NT_OUT) bias_init(acc[i], out_bias, i, h);
+        }
+        acc[n0] = mfma_bf(g[0][0], cur.h[u0], acc[n0]);
+        acc[n1] = mfma_bf(g[1][0], cur.h[u1], acc[n1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < NT_IN && !(ABL & 4)) {
+#pragma unroll
+            for (int pr = ((2 * pt) * 8) / (2 * PPT); pr < ((2 * pt + 1) * 8) / (2 * PPT); ++pr)
+                convert_pair<RELU_IN>(prev[t + 1], 2 * pr, nxt, t + 1, side);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[n0] = mfma_bf(g[0][1], cur.h[u0], acc[n0]);
+        acc[n1] = mfma_bf(g[1][1], cur.h[u1], acc[n1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < NT_IN && !(ABL & 4)) {
+#pragma unroll
+            for (int pr = ((2 * pt + 1) * 8) / (2 * PPT); pr < ((2 * pt + 2) * 8) / (2 * PPT); ++pr)
+                convert_pair<RELU_IN>(prev[t + 1], 2 * pr, nxt, t + 1, side);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[n0] = mfma_bf(g[0][0], cur.l[u0], acc[n0]);
+        acc[n1] = mfma_bf(g[1][0], cur.l[u1], acc[n1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (pt == PPT - 1 && t + 1 < NT_IN) cur = nxt;
+    });
+}
+
+// ---- the 64-slot positional encoding (4 K=16 steps, pre-split in LDS) ------------------------------
 template <int NT_OUT>
-__device__ __forceinline__ void mm3_enc(const unsigned* enc_col, f32x16 (&acc)[NT_H], W3Stream& w) {
-    constexpr int NROW = 4 * NT_OUT;
-    constexpr int NB = NROW / WB3;
-    static_assert(NROW % WB3 == 0 && NB % NBUF == 0, "rows must keep batch and buffer phase");
-    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+__device__ __forceinline__ void mm3_enc(const unsigned* enc_col, f32x16 (&acc)[NT_H], const float* out_bias, int h,
+                                        WRing& w) {
+    constexpr int NP = 4 * NT_OUT / 2;
+    static_assert(NT_OUT % 2 == 0, "a row pair stays inside one K step");
     // LDS column layout: word index = tile*16 + (hi? 0 : 8) + u*4 + w, stride 256 threads
     u32x4 bh[4], bl[4];
 #pragma unroll
@@ -220,37 +334,46 @@ __device__ __forceinline__ void mm3_enc(const unsigned* enc_col, f32x16 (&acc)[N
             bh[s][c] = enc_col[((s >> 1) * 16 + (s & 1) * 4 + c) * 256];
             bl[s][c] = enc_col[((s >> 1) * 16 + 8 + (s & 1) * 4 + c) * 256];
         }
-#pragma clang loop unroll(full)
-    for (int kb = 0; kb < NB; ++kb) {
-        w.voff += WB3 * 2048u;
-        w3batch(w, w.g[(kb + NBUF - 1) % NBUF]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int term = 0; term < 3; ++term) {
-#pragma unroll
-            for (int q = 0; q < WB3; ++q) {
-                const int i = kb * WB3 + q;
-                const int s = i / NT_OUT, nt = i % NT_OUT;
-                const u32x4 a = w.g[kb % NBUF][q][term == 1 ? 1 : 0];
-                const u32x4 b = term == 2 ? bl[s] : bh[s];
-                acc[nt] = mfma_bf(a, b, (term == 0 && s == 0) ? zero : acc[nt]);
-            }
+    bias_init(acc[0], out_bias, 0, h);
+    bias_init(acc[1], out_bias, 1, h);
+    ring_layer<NP>(w, [&](int P, const u32x4 (&g)[2][2]) {
+        const int i0 = 2 * P, s = i0 / NT_OUT, n0 = i0 % NT_OUT, n1 = n0 + 1;
+        if (s == 0 && n0 + 3 < NT_OUT) {
+            bias_init(acc[n0 + 2], out_bias, n0 + 2, h);
+            bias_init(acc[n0 + 3], out_bias, n0 + 3, h);
         }
+        acc[n0] = mfma_bf(g[0][0], bh[s], acc[n0]);
+        acc[n1] = mfma_bf(g[1][0], bh[s], acc[n1]);
+        acc[n0] = mfma_bf(g[0][1], bh[s], acc[n0]);
+        acc[n1] = mfma_bf(g[1][1], bh[s], acc[n1]);
+        acc[n0] = mfma_bf(g[0][0], bl[s], acc[n0]);
+        acc[n1] = mfma_bf(g[1][0], bl[s], acc[n1]);
         __builtin_amdgcn_sched_barrier(0);
-    }
+    });
 }
 
-constexpr size_t FWD3_LDS_BYTES = (size_t)(ENC_STEPS * 256 + WAVES_PER_WG * N_CHAIN * H) * sizeof(float);
+// LDS: [ring 48 KiB][encoding 32 x 256 words][per-wave bias table (N_CHAIN layers + density row) x 4]
+constexpr int BIAS_ROWS = N_CHAIN + 1;
+constexpr size_t FWD3_LDS_BYTES = RING_BYTES + (size_t)(ENC_STEPS * 256 + WAVES_PER_WG * BIAS_ROWS * H) * sizeof(float);
+static_assert(FWD3_LDS_BYTES <= 160 * 1024, "LDS budget");
 
 __global__ __launch_bounds__(256, 1) void fwd3_kernel(const FwdParams fp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    unsigned* enc_lds = (unsigned*)smem;                 // [32 words][256 threads]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* bias_lds = smem + ENC_STEPS * 256 + wave * (N_CHAIN * H);
+    char* ring = (char*)smem;
+    unsigned* enc_lds = (unsigned*)(smem + RING_BYTES / 4);          // [32 words][256 threads]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* bias_lds = smem + RING_BYTES / 4 + ENC_STEPS * 256 + wave * (BIAS_ROWS * H);
     const int j = lane & 31, h = lane >> 5;
-    const long chunk = (long)blockIdx.x * WAVES_PER_WG + wave;
-    if (chunk >= fp.n_chunks) return;
     const GnrProblem& p = fp.prob;
+
+    WRing w;
+    ring_init(w, fp.ws[0].packed, (unsigned)(fp.n_streams * ROWS3 * 2048), ring, lane, wave);
+
+    // every wave stays in the barrier protocol: past the end it recomputes the last chunk and stores nothing
+    const long chunk_raw = (long)blockIdx.x * WAVES_PER_WG + wave;
+    const bool live = chunk_raw < fp.n_chunks;
+    const long chunk = live ? chunk_raw : fp.n_chunks - 1;
     const int cpr = fp.chunks_per_ray;
     const long ray_g = chunk / cpr;
     const int c_in = (int)(chunk - ray_g * cpr);
@@ -260,9 +383,6 @@ __global__ __launch_bounds__(256, 1) void fwd3_kernel(const FwdParams fp) {
     const bool valid = i < p.n_samples;
     const long row = chunk * CHUNK + j;
 
-    W3Stream w;
-    w3_init(w, fp.ws[0].packed, lane);
-
     const Ray r = make_ray(p, b, ray);
     const int ic = valid ? i : p.n_samples - 1;
     const float z0 = sample_edge(p, r.oz, ray_g, ic);
@@ -271,7 +391,7 @@ __global__ __launch_bounds__(256, 1) void fwd3_kernel(const FwdParams fp) {
     const float px = __fadd_rn(r.ox, __fmul_rn(__fmul_rn(r.dx, r.l), z0));
     const float py = __fadd_rn(r.oy, __fmul_rn(__fmul_rn(r.dy, r.l), z0));
     const float pz = __fadd_rn(r.oz, __fmul_rn(__fmul_rn(r.dz, r.l), z0));
-    if (fp.want_wl && h == 0) fp.zval[row] = z0;
+    if (fp.want_wl && h == 0 && live) fp.zval[row] = z0;
 
     // encoding: fp32 sincosf, then hi/lo split into two pre-converted B tiles kept in LDS
     unsigned* enc_col = enc_lds + tid;
@@ -290,46 +410,49 @@ __global__ __launch_bounds__(256, 1) void fwd3_kernel(const FwdParams fp) {
                     enc_col[(T * 16 + 8 + u * 4 + wd) * 256] = lo;
                 }
     }
+    ring_start(w);
 
     f32x16 A[NT_H], Bv[NT_H];
 #pragma unroll 1
     for (int s = 0; s < fp.n_streams; ++s) {
         const StreamWs& ws = fp.ws[s];
-        {
+        {   // this wave's biases (latent codes folded in) + the density row -> LDS
             const long bstride = (long)p.batch * H;
             const float* bsrc = ws.bias + (long)b * H;
             for (int q = lane; q < N_CHAIN * (H / 4); q += 64) {
                 const int l = q / (H / 4), c4 = q - l * (H / 4);
                 *(f32x4*)(bias_lds + l * H + 4 * c4) = *(const f32x4*)(bsrc + l * bstride + 4 * c4);
             }
+            for (int q = lane; q < H / 4; q += 64)
+                *(f32x4*)(bias_lds + N_CHAIN * H + 4 * q) = *(const f32x4*)(ws.wsig + 4 * q);
         }
         auto bl = [&](int l) { return bias_lds + l * H; };
 
-        mm3_enc<NT_H>(enc_col, A, w);                                         // L0 (raw) -> A
+        mm3_enc<NT_H>(enc_col, A, bl(0), h, w);                                // L0 -> A (pre-activation)
 #pragma unroll 1
-        for (int rep = 0; rep < 2; ++rep) {                                   // L1..L4
-            mm3_h<NT_H, NT_H, true, true>(A, bl(2 * rep), h, Bv, w);
-            mm3_h<NT_H, NT_H, true, true>(Bv, bl(2 * rep + 1), h, A, w);
+        for (int rep = 0; rep < 2; ++rep) {                                    // L1..L4
+            mm3_h<NT_H, NT_H, true, true>(A, Bv, bl(2 * rep + 1), h, w);
+            mm3_h<NT_H, NT_H, true, true>(Bv, A, bl(2 * rep + 2), h, w);
         }
-        mm3_enc<NT_H>(enc_col, Bv, w);                                        // L5: enc part, then h4 part
-        mm3_h<NT_H, NT_H, false, true>(A, bl(4), h, Bv, w);
-        mm3_h<NT_H, NT_H, true, true>(Bv, bl(5), h, A, w);                    // L6
-        mm3_h<NT_H, NT_H, true, true>(A, bl(6), h, Bv, w);                    // L7 (raw h7 in Bv)
-        // RGB0 consumes h7 = relu(Bv + b7); the density head rides on the conversion (fp32 VALU dot)
+        mm3_enc<NT_H>(enc_col, Bv, bl(5), h, w);                               // L5: encoding part, then h4 part
+        mm3_h<NT_H, NT_H, false, true>(A, Bv, bl(5), h, w);
+        mm3_h<NT_H, NT_H, true, true>(Bv, A, bl(6), h, w);                     // L6
+        mm3_h<NT_H, NT_H, true, true>(A, Bv, bl(7), h, w);                     // L7 (pre-activation h7 in Bv)
+        // RGB0 consumes h7 = relu(Bv); the density head rides on the conversion (fp32 VALU dot)
         float sig = 0.0f;
-        const float* wsg = ws.wsig + 4 * h;
-        mm3_h<NT_H, NT_H, true, true>(Bv, bl(7), h, A, w, [&](int t, int rr, float a, float bb) {
+        const float* wsg = bias_lds + N_CHAIN * H + 4 * h;
+        mm3_h<NT_H, NT_H, true, true>(Bv, A, bl(LR0), h, w, [&](int t, int rr, float a, float bb) {
             const int ch = 32 * t + (rr & 3) + 8 * (rr >> 2);
             sig = fmaf(wsg[ch], a, sig);
             sig = fmaf(wsg[ch + 1], bb, sig);
         });
         sig += __shfl_xor(sig, 32);
         sig += ws.wsig[H];
-        mm3_h<NT_H, NT_H2, true, false>(A, bl(LR0), h, Bv, w);                // RGB1 from y0 (no activation)
-        mm3_h<NT_H2, NT_F, true, true>(Bv, bl(LR1), h, A, w);                 // RGB2 from relu(y1)
-        bias_act<NT_F, false>(A, bl(LR2), h);
-        composite_chunk(A, sig, delta, z0, ws, chunk, row, lane, fp.want_wl != 0);
+        mm3_h<NT_H, NT_H2, true, false>(A, Bv, bl(LR1), h, w);                 // RGB1 from y0 (no activation)
+        mm3_h<NT_H2, NT_F, true, true>(Bv, A, bl(LR2), h, w);                  // RGB2 from relu(y1)
+        if (live) composite_chunk(A, sig, delta, z0, ws, chunk, row, lane, fp.want_wl != 0);
     }
+    wait_vm<0>();       // no LDS-DMA may outlive the wave
 }
 
 void launch_prep3(const GnrProblem& p, int n_streams, const GnrWeights* const* wts, StreamWs* ws, hipStream_t stream) {
