@@ -31,6 +31,8 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_SAMPLE_STREAM = 2 * 1351680          # folded count, fwd
 PEAK_FP32_MFMA_TFLOPS = 157.3                 # MI355X_MICROARCH.md chip-level parameters
+# bf16x3: three bf16 MFMAs per fp32-equivalent product -> a third of the 16x fp32 rate (dense bf16 peak / 3)
+PEAK_BF16X3_TFLOPS = 16.0 * PEAK_FP32_MFMA_TFLOPS / 3.0
 
 
 def parse():
@@ -42,6 +44,9 @@ def parse():
     ap.add_argument("--side", type=int, default=512, help="rays per image = side^2")
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--micro", type=int, default=16384, help="rays per backward micro-batch")
+    ap.add_argument("--precision", choices=("fp32", "bf16x3"), default=os.environ.get("GNR_BENCH_PRECISION", "fp32"),
+                    help="fp32: exact fp32 MFMA everywhere; bf16x3: forward + dgrad chain on bf16 MFMA with a "
+                         "3-term hi/lo split (fp32 accumulate; weight-gradient GEMMs stay fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=512)
     return ap.parse_args()
@@ -151,7 +156,7 @@ def main():
             with torch.no_grad():
                 with timer:
                     render.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"],
-                                             p["appea_code"], face, eyes, n_samples=n_p)
+                                             p["appea_code"], face, eyes, n_samples=n_p, precision=args.precision)
                 if timed:
                     kernel_ms.append(timer.elapsed_ms())
             return
@@ -163,7 +168,7 @@ def main():
             with timer:
                 out = render.render_two_stream(xy, p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"],
                                                p["appea_code"], face, eyes, n_samples=n_p,
-                                               t_rand=t_rand[:, :xy.shape[2]])
+                                               t_rand=t_rand[:, :xy.shape[2]], precision=args.precision)
             if timed:
                 kernel_ms.append(timer.elapsed_ms())
             loss = sum((out["feat_" + t] ** 2).mean() + out["bg_alpha_" + t].mean() for t in ("face", "eyes"))
@@ -210,19 +215,27 @@ def main():
                 pj = json.load(f)
             traffic = pj["hbm_bytes_per_ray"] * rays_per_launch
             traffic_src = "profiles/r1_pmc_fwd.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, per ray x rays per launch)"
+        x3 = args.precision == "bf16x3"
+        peak = PEAK_BF16X3_TFLOPS if x3 else PEAK_FP32_MFMA_TFLOPS
+        kname = ("gnr::fwd3_kernel<%s>" if x3 else "gnr::fwd_kernel<%s>") % ("true" if args.mode == "fwdbwd" else "false")
+        if x3:
+            traffic, traffic_src = None, None
         res = {
             "metric": "rays/sec (512x512, 64 samples/ray) %s" % ("fwd+bwd" if args.mode == "fwdbwd" else "fwd"),
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "bf16x3 (hi/lo split bf16 MFMA, f32 accumulate; wgrad f32)" if x3 else "f32", "data": "synthetic",
             "config": {"workload": "%s: %dx%d rays x %d samples/ray, two streams (face+eyes), %s, "
                                    "1 image per GPU%s" % ("cfg2b" if (side, n_p) == (512, 64) else "custom", side, side, n_p, args.mode,
                                                           ", %d-ray micro-batches" % micro if args.mode == "fwdbwd" else ""),
                        "rays_per_step_per_gpu": n_rays, "samples_per_ray": n_p,
-                       "parallelism": "dp%d (images sharded)" % world},
-            "roofline": {"bound": "mfma", "kernel": "gnr::fwd_kernel<%s>" % ("true" if args.mode == "fwdbwd" else "false"), "achieved": achieved,
-                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                       "parallelism": "dp%d (images sharded)" % world, "precision": args.precision},
+            "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved,
+                         "peak": peak, "unit": "TFLOP/s",
+                         "peak_basis": ("dense bf16 MFMA peak (16 x 157.3) / 3 terms; achieved counts the "
+                                        "fp32-equivalent algorithmic FLOPs") if x3 else "fp32 MFMA peak",
+                         "frac": achieved / peak, "frac_of_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "flop_per_launch": flop_per_launch, "avg_launch_ms": avg_ms,
                          "launches_timed": len(kernel_ms),
                          # whole step against the same peak: algorithmic FLOPs of the step (fwd, or
@@ -230,7 +243,8 @@ def main():
                          "step_achieved": (3 if args.mode == "fwdbwd" else 1) * n_rays * n_p * 2
                                           * FLOP_PER_SAMPLE_STREAM / (ms * 1e-3) / 1e12,
                          "step_frac": (3 if args.mode == "fwdbwd" else 1) * n_rays * n_p * 2
-                                      * FLOP_PER_SAMPLE_STREAM / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
+                                      * FLOP_PER_SAMPLE_STREAM / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                         "step_frac_basis": "fp32 MFMA peak"},
         }
         if aux_ms:
             # HBM-bound compositing pass (CalcRayColor backward): algorithmic bytes per sample =

@@ -55,7 +55,7 @@ class GnrInputGrads(C.Structure):
     _fields_ = [("R", _p), ("T", _p), ("shape_code", _p), ("gaze", _p), ("appea_code", _p)]
 
 
-EXPORTS = ("gnr_abi_version", "gnr_workspace_bytes", "gnr_fwd", "gnr_fwd_bf16x3", "gnr_bwd", "gnr_resample",
+EXPORTS = ("gnr_abi_version", "gnr_workspace_bytes", "gnr_fwd", "gnr_fwd_bf16x3", "gnr_bwd", "gnr_bwd_bf16x3", "gnr_resample",
            "gnr_sample_zvals", "gnr_set_kernel_timing", "gnr_set_aux_timing", "gnr_merge_scratch_bytes",
            "gnr_merge_fwd", "gnr_merge_bwd", "gnr_last_error")
 
@@ -84,13 +84,14 @@ def load():
     lib.gnr_fwd.argtypes = [C.POINTER(GnrProblem), C.POINTER(GnrWeights), C.POINTER(GnrWeights),
                             C.POINTER(GnrOutputs), C.c_int, _p, C.c_size_t, _p]
     lib.gnr_fwd_bf16x3.restype = C.c_int
-    lib.gnr_fwd_bf16x3.argtypes = [C.POINTER(GnrProblem), C.POINTER(GnrWeights), C.POINTER(GnrWeights),
-                                   C.POINTER(GnrOutputs), _p, C.c_size_t, _p]
+    lib.gnr_fwd_bf16x3.argtypes = lib.gnr_fwd.argtypes
     lib.gnr_bwd.restype = C.c_int
     lib.gnr_bwd.argtypes = [C.POINTER(GnrProblem), C.POINTER(GnrWeights), C.POINTER(GnrWeights),
                             C.POINTER(GnrOutputGrads), C.POINTER(GnrInputGrads),
                             C.POINTER(GnrWeightGrads), C.POINTER(GnrWeightGrads),
                             _p, C.c_size_t, _p, C.c_size_t, _p]
+    lib.gnr_bwd_bf16x3.restype = C.c_int
+    lib.gnr_bwd_bf16x3.argtypes = lib.gnr_bwd.argtypes
     lib.gnr_resample.restype = C.c_int
     lib.gnr_resample.argtypes = [_p, _p, _p, C.c_int64, C.c_int32, C.c_int32, _p, _p]
     lib.gnr_sample_zvals.restype = C.c_int

@@ -14,7 +14,7 @@ void launch_resample(const float* w, const float* cz, const float* u, long n_ray
                      float* zout, hipStream_t stream);
 int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, const GnrOutputGrads* dout,
             const GnrInputGrads* din, const GnrWeightGrads* const* dw, void* saved, size_t saved_bytes,
-            void* scratch, size_t scratch_bytes, hipStream_t stream);
+            void* scratch, size_t scratch_bytes, hipStream_t stream, bool bf16x3);
 size_t bwd_scratch_bytes(const GnrProblem* p, int n_streams);
 
 static thread_local std::string g_err;
@@ -185,13 +185,14 @@ int gnr_fwd(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes,
 }
 
 int gnr_fwd_bf16x3(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes, const GnrOutputs* out,
-                   void* workspace, size_t ws_bytes, void* stream) {
-    return fwd_impl(p, face, eyes, out, 0, workspace, ws_bytes, stream, true);
+                   int save_for_backward, void* workspace, size_t ws_bytes, void* stream) {
+    return fwd_impl(p, face, eyes, out, save_for_backward, workspace, ws_bytes, stream, true);
 }
 
-int gnr_bwd(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes, const GnrOutputGrads* dout,
-            const GnrInputGrads* din, const GnrWeightGrads* dface, const GnrWeightGrads* deyes,
-            void* saved_workspace, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream) {
+static int bwd_impl(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes, const GnrOutputGrads* dout,
+                    const GnrInputGrads* din, const GnrWeightGrads* dface, const GnrWeightGrads* deyes,
+                    void* saved_workspace, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream,
+                    bool bf16x3) {
     const int n_streams = eyes ? 2 : 1;
     if (check_problem(p, n_streams)) return 1;
     if (check_weights(face, "first-stream")) return 1;
@@ -200,7 +201,21 @@ int gnr_bwd(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes,
     const GnrWeights* w[2] = {face, eyes};
     const GnrWeightGrads* dw[2] = {dface, deyes};
     return run_bwd(p, n_streams, w, dout, din, dw, saved_workspace, saved_bytes, scratch, scratch_bytes,
-                   (hipStream_t)stream);
+                   (hipStream_t)stream, bf16x3);
+}
+
+int gnr_bwd(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes, const GnrOutputGrads* dout,
+            const GnrInputGrads* din, const GnrWeightGrads* dface, const GnrWeightGrads* deyes,
+            void* saved_workspace, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream) {
+    return bwd_impl(p, face, eyes, dout, din, dface, deyes, saved_workspace, saved_bytes, scratch, scratch_bytes,
+                    stream, false);
+}
+
+int gnr_bwd_bf16x3(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes, const GnrOutputGrads* dout,
+                   const GnrInputGrads* din, const GnrWeightGrads* dface, const GnrWeightGrads* deyes,
+                   void* saved_workspace, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream) {
+    return bwd_impl(p, face, eyes, dout, din, dface, deyes, saved_workspace, saved_bytes, scratch, scratch_bytes,
+                    stream, true);
 }
 
 int gnr_resample(const float* weights, const float* coarse_z, const float* u, int64_t n_rays_total,

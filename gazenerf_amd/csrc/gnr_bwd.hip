@@ -13,7 +13,7 @@
 // Once per call: geo_kernel  d(pts), dL/dl partials -> dR, dT (GenSamplePoints backward).
 #include <atomic>
 
-#include "gnr_chain.h"
+#include "gnr_bwd_common.h"
 
 namespace gnr {
 int fail(const char* fmt, ...);
@@ -24,33 +24,6 @@ void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb,
                   int colsum_ld, const float* vec, float* vec_out, float* scratch, hipStream_t stream);
 void launch_vecsum(const float* v, int batch, long per_image, float* out, int out_stride, hipStream_t stream);
 extern std::atomic<hipEvent_t> g_ev_start, g_ev_stop, g_aux_start, g_aux_stop;
-
-// ---------------------------------------------------------------------------------------------
-// transposed weight stream.  Backward "layer" ids, in execution order:
-//   0: RGB2^T (in 9 tiles -> out 6)   1: RGB1^T (6 -> 12)   2: RGB0^T (12 -> 12)
-//   3,4: L7^T, L6^T (12 -> 12)   5: L5e^T (12 -> 2)   6: L5h^T (12 -> 12)   7..10: L4^T..L1^T
-//   11: L0e^T (12 -> 2).  Memory order == execution order: the kernel reads one linear row stream.
-// ---------------------------------------------------------------------------------------------
-constexpr int N_BL = 12;
-__host__ __device__ constexpr int bl_in_tiles(int l) { return l == 0 ? NT_F : (l == 1 ? NT_H2 : NT_H); }
-__host__ __device__ constexpr int bl_out_tiles(int l) { return l == 0 ? NT_H2 : ((l == 5 || l == 11) ? 2 : NT_H); }
-__host__ __device__ constexpr size_t bl_floats(int l) { return (size_t)bl_in_tiles(l) * 16 * bl_out_tiles(l) * 64; }
-__host__ __device__ constexpr size_t bl_offset(int l) {
-    size_t o = 0;
-    for (int i = 0; i < l; ++i) o += bl_floats(i);
-    return o;
-}
-constexpr size_t PACKEDT_FLOATS = bl_offset(N_BL);
-
-struct PackTParams {
-    const float* w[N_BL];
-    int ld[N_BL];
-    int n_valid[N_BL];     // forward outputs (contraction length here)
-    int col0[N_BL];        // first source column of the outputs of this backward layer
-    int k_valid[N_BL];     // number of valid output channels (hidden) ; enc layers: 64 slots
-    int enc[N_BL];
-    float* packed;
-};
 
 __global__ void packT_kernel(const PackTParams pp) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < PACKEDT_FLOATS;
@@ -230,59 +203,12 @@ __global__ __launch_bounds__(256) void comp_bwd_kernel(const CompBwdParams cp) {
 // ---------------------------------------------------------------------------------------------
 // dgrad chain
 // ---------------------------------------------------------------------------------------------
-struct BwdParams {
-    GnrProblem prob;
-    int chunks_per_ray;
-    long n_chunks, M;
-    const float* packedT;
-    const float* wsig;        // [H] density weight
-    const float* gT;          // [rays][288]
-    const float* wglob;       // [M]
-    const float* dsig;        // [M]
-    const unsigned* relu_bits;  // [9][n_chunks][6][64]
-    const float* enc;         // [M][64] CCM
-    const float* zval;        // [M]
-    float* dY_h;              // [8][M][H]
-    float* dY_r0;             // [M][H]
-    float* dY_r1;             // [M][H2]
-    float* dfeat;             // [M][288]
-    float* geo_chunk;         // [n_chunks][8]: sum dpts (3), sum z*dpts (3)
-    int accumulate_geo;
-};
-
 template <int NT>
 __device__ __forceinline__ void zero_tiles(f32x16 (&acc)[NT_H]) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-}
-
-// d(encoding) held as a 2-tile C/D register file (lane-half h owns the slots it encoded) -> d(pts).
-// Embedder backward: d/dp sin(a p) = a cos(a p), d/dp cos(a p) = -a sin(a p).
-__device__ __forceinline__ void enc_backward(const f32x16 (&E)[NT_H], const float* __restrict__ enc_row, int h,
-                                             float& gx, float& gy, float& gz) {
-    float d[ENC_STEPS];
-#pragma unroll
-    for (int s = 0; s < ENC_STEPS; ++s) d[s] = E[s >> 4][s & 15];
-    float ax = 0.0f, ay = 0.0f, az = 0.0f;
-    if (h == 0) { ax += d[0]; az += d[1]; } else { ay += d[0]; }
-#pragma unroll
-    for (int fl = 0; fl < 5; ++fl) {
-        const float scale = (float)(1 << fl) * (h ? 32.0f : 1.0f);
-        float acc3[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const int si = 2 + 6 * fl + a, ci = si + 3;
-            const float sv = enc_row[(2 * si + h) * CHUNK], cv = enc_row[(2 * ci + h) * CHUNK];
-            acc3[a] = scale * (cv * d[si] - sv * d[ci]);
-        }
-        ax += acc3[0]; ay += acc3[1]; az += acc3[2];
-    }
-    ax += __shfl_xor(ax, 32);
-    ay += __shfl_xor(ay, 32);
-    az += __shfl_xor(az, 32);
-    gx += ax; gy += ay; gz += az;
 }
 
 __global__ __launch_bounds__(256, 1) void bwd_chain_kernel(const BwdParams bp) {
@@ -570,7 +496,7 @@ size_t bwd_scratch_bytes(const GnrProblem* p, int) { return carve_bwd(p, nullptr
 
 int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, const GnrOutputGrads* dout,
             const GnrInputGrads* din, const GnrWeightGrads* const* dw, void* saved, size_t saved_bytes,
-            void* scratch, size_t scratch_bytes, hipStream_t st) {
+            void* scratch, size_t scratch_bytes, hipStream_t st, bool bf16x3) {
     FwdParams fp{};
     const size_t need_saved = carve_fwd(p, n_streams, true, nullptr, nullptr);
     if (!saved || saved_bytes < need_saved)
@@ -627,7 +553,8 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         setl(10, W.fea_w[1], H, H, 0, H, 0);
         setl(11, W.fea_w[0], vp, H, 0, ENC_PAD, 1);
         pt.packed = sc.packedT;
-        hipLaunchKernelGGL(packT_kernel, dim3(1024), dim3(256), 0, st, pt);
+        if (bf16x3) launch_packT3(pt, st);
+        else hipLaunchKernelGGL(packT_kernel, dim3(1024), dim3(256), 0, st, pt);
         // 4. dgrad chain
         BwdParams bp{};
         bp.prob = *p; bp.chunks_per_ray = cpr; bp.n_chunks = fp.n_chunks; bp.M = M;
@@ -636,8 +563,11 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         bp.dY_h = sc.dY_h; bp.dY_r0 = sc.dY_r0; bp.dY_r1 = sc.dY_r1; bp.dfeat = sc.dfeat;
         bp.geo_chunk = sc.geo_chunk; bp.accumulate_geo = s > 0;
         if (hipEvent_t e = g_ev_start.load(); e && s == 0) (void)hipEventRecord(e, st);
-        hipLaunchKernelGGL(bwd_chain_kernel, dim3((unsigned)((fp.n_chunks + WAVES_PER_WG - 1) / WAVES_PER_WG)),
-                           dim3(256), 0, st, bp);
+        if (bf16x3)
+            launch_bwd3_chain(bp, st);
+        else
+            hipLaunchKernelGGL(bwd_chain_kernel, dim3((unsigned)((fp.n_chunks + WAVES_PER_WG - 1) / WAVES_PER_WG)),
+                               dim3(256), 0, st, bp);
         if (hipEvent_t e = g_ev_stop.load(); e && s == 0) (void)hipEventRecord(e, st);
 
         // 5. weight gradients dW = dY^T X; the same kernels emit the per-image column sums of dY

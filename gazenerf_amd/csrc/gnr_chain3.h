@@ -1,0 +1,330 @@
+// gnr_chain3.h -- the "bf16x3" building blocks shared by gnr_fwd3.hip and gnr_bwd3.hip (gfx950).
+//
+// Every fp32 operand x is split x = hi + lo (+ ~2^-17 |x|), hi = bf16(x), lo = bf16(x - hi), and
+//     a * b  ~=  a_hi b_hi + a_lo b_hi + a_hi b_lo          (fp32 accumulate in the MFMA)
+// i.e. three v_mfma_f32_32x32x16_bf16 (32 matrix-pipe cycles, 16 k each) replace eight
+// v_mfma_f32_32x32x2_f32 (64 cycles each): 5.3x the fp32-MFMA rate at ~16 mantissa bits per operand.
+#pragma once
+#include "gnr_chain.h"
+
+namespace gnr {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
+    // A: lane l holds A[i = l&31][k = 8(l>>5) + 0..7]; B: B[k = 8(l>>5) + 0..7][j = l&31]; C/D as f32 32x32
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// round-to-nearest-even fp32 -> bf16 (finite inputs)
+__host__ __device__ __forceinline__ unsigned bf16_rne(float x) {
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__host__ __device__ __forceinline__ float bf16_to_f32(unsigned b) { return __builtin_bit_cast(float, b << 16); }
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// split a pair of fp32 values into packed {hi(a), hi(b)} and {lo(a), lo(b)}: v_cvt_pk_bf16_f32 (RNE),
+// shift/mask back to fp32, one packed subtract, v_cvt_pk_bf16_f32 -- 5 VALU instructions per pair
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+    const f32x2 v = {a, b};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    const f32x2 hf = {__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, bf16x2));
+}
+
+// k-order of a K=16 bf16 step s = 2t + u over an activation tile held in the C/D layout: lane-half h
+// supplies, as element q (0..7), register r = 8u + q of tile t.
+__host__ __device__ inline int dlayout3_channel(int step16, int h, int q) {
+    const int t = step16 >> 1, r = 8 * (step16 & 1) + q;
+    return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight ring: the workgroup's four waves consume the SAME rows, so the stream goes through LDS once
+// per workgroup instead of four times through the vector L1 (which at 2 KiB per 96 matrix-pipe cycles
+// per wave is past the 64 B/clk the texture path delivers).  LDS-DMA (buffer_load_dwordx4 ... lds)
+// fills a ring of NSLOT batches of RB_ROWS rows; wave w fetches row w of each batch (2 KiB = 2 pieces).
+//
+// Per batch k ("phase"), every wave:
+//   s_waitcnt vmcnt(2 (DEPTH-1))   its own share of batch k+1 has landed
+//   s_barrier                      -> batch k+1 is complete and visible; every wave has issued (hence
+//                                     fetched the operands of) all MFMAs of batch k-1
+//   request batch k+DEPTH+1        into the slot batch k-1 occupied            (NSLOT = DEPTH + 2)
+//   ds_read rows 2,3 of batch k;  MFMAs of rows 0,1;  ds_read rows 0,1 of batch k+1;  MFMAs of rows 2,3
+// The DMA is inline asm (hipcc would otherwise put a vmcnt(0) in front of every LDS read that might
+// alias it); hipcc's own vmcnt bookkeeping stays correct because extra outstanding operations only make
+// its counted waits stricter, and ours count only operations issued after the ones we wait for.
+// Addressing rules (LDS dest = M0 + inst_offset + lane*16, M0 beyond 64 KiB, zero fill past
+// num_records) are pinned by tools/ubench/ldsdma_probe.hip.
+// ---------------------------------------------------------------------------------------------
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// Timing experiments only (results are wrong with any bit set): build with -DGNR_ABLATE=<bits>.
+//   1 no LDS-DMA requests   2 no barriers   4 no activation conversion   8 no ring reads   16 no vmcnt waits
+#ifndef GNR_ABLATE
+#define GNR_ABLATE 0
+#endif
+constexpr int ABL = GNR_ABLATE;
+
+constexpr int RB_ROWS = 4;                             // rows per ring batch (one per wave)
+constexpr int NSLOT = 6;
+constexpr int DEPTH = NSLOT - 2;                       // batches in flight beyond the one made visible
+constexpr unsigned BATCH_BYTES = RB_ROWS * 2048u;      // 8 KiB
+constexpr unsigned RING_BYTES = NSLOT * BATCH_BYTES;   // 48 KiB at LDS offset 0
+static_assert(RB_ROWS == WAVES_PER_WG, "one row of each batch per wave");
+
+struct WRing {
+    i32x4 rs;                // buffer descriptor of the packed stream (num_records = exact bytes)
+    unsigned voff;           // lane*16 + wave*2048
+    unsigned soff;           // stream offset of the next batch to request
+    unsigned wr;             // LDS address (M0) of this wave's row in the slot to fill next
+    unsigned wr_end;         // wr wraps here
+    unsigned rd;             // ring offset of the batch being consumed
+    const char* lane_base;   // ring + lane*16
+    u32x4 g[2][2][2];        // [pair][row][hi/lo]: rows 0,1 and rows 2,3 of the current batch
+};
+
+struct RingTicket {
+    unsigned soff, wr;
+};
+
+// Measured (tools/ablate_fwd3.sh): a piece blocks the issuing wave for ~94 cycles, and that is not
+// contention between the four waves -- spreading their requests over the phase (one wave per MFMA group)
+// made the kernel 12 % slower, because the barrier then waits for whichever wave is stalled.
+__device__ __forceinline__ void ring_issue(const WRing& w, const RingTicket& t) {
+    if (ABL & 1) return;
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen offset:1024 lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(w.voff), "s"(w.rs), "s"(t.soff), "s"(t.wr)
+        : "memory");
+}
+
+__device__ __forceinline__ RingTicket ring_advance(WRing& w) {
+    const RingTicket t = {w.soff, w.wr};
+    w.soff += BATCH_BYTES;
+    w.wr += BATCH_BYTES;
+    if (w.wr == w.wr_end) w.wr -= RING_BYTES;
+    return t;
+}
+
+__device__ __forceinline__ void ring_request(WRing& w) { ring_issue(w, ring_advance(w)); }
+
+__device__ __forceinline__ void ring_read_pair(const WRing& w, unsigned slot_off, int pair, u32x4 (&g)[2][2]) {
+    if (ABL & 8) return;
+    const char* p = w.lane_base + slot_off + pair * 4096;
+    g[0][0] = *(const u32x4*)(p);
+    g[0][1] = *(const u32x4*)(p + 1024);
+    g[1][0] = *(const u32x4*)(p + 2048);
+    g[1][1] = *(const u32x4*)(p + 3072);
+}
+
+__device__ __forceinline__ void ring_init(WRing& w, const float* packed, unsigned stream_bytes, char* ring, int lane,
+                                          unsigned wave) {
+    const unsigned long long a = (unsigned long long)packed;
+    w.rs.x = (int)(unsigned)a;
+    w.rs.y = (int)(unsigned)(a >> 32);
+    w.rs.z = (int)stream_bytes;
+    w.rs.w = 0x00020000;
+    w.voff = (unsigned)lane * 16u + wave * 2048u;
+    w.soff = 0;
+    w.wr = (unsigned)(size_t)ring + wave * 2048u;
+    w.wr_end = w.wr + RING_BYTES;
+    w.rd = 0;
+    w.lane_base = ring + lane * 16;
+    if (ABL & 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) w.g[q >> 2][(q >> 1) & 1][q & 1] = u32x4{(unsigned)lane, 1u, 2u, 3u};
+    }
+    if (ABL & 4) {}
+#pragma unroll
+    for (int k = 0; k <= DEPTH; ++k) ring_request(w);
+}
+
+// first rows into registers: call after ring_init, with no other barrier in between
+__device__ __forceinline__ void ring_start(WRing& w) {
+    wait_vm<2 * DEPTH>();
+    __builtin_amdgcn_s_barrier();
+    ring_read_pair(w, 0, 0, w.g[0]);
+}
+
+// s_waitcnt vmcnt(n) for an n that is a constant after unrolling
+__device__ __forceinline__ void wait_vm_n(int n) {
+    switch (n < 30 ? n : 30) {
+#define GNR_W(k) case k: wait_vm<k>(); break;
+        GNR_W(0) GNR_W(1) GNR_W(2) GNR_W(3) GNR_W(4) GNR_W(5) GNR_W(6) GNR_W(7) GNR_W(8) GNR_W(9) GNR_W(10)
+        GNR_W(11) GNR_W(12) GNR_W(13) GNR_W(14) GNR_W(15) GNR_W(16) GNR_W(17) GNR_W(18) GNR_W(19) GNR_W(20)
+        GNR_W(21) GNR_W(22) GNR_W(23) GNR_W(24) GNR_W(25) GNR_W(26) GNR_W(27) GNR_W(28) GNR_W(29) GNR_W(30)
+#undef GNR_W
+    }
+}
+
+// NP pairs of rows (NP even): pair(P, g) issues the six MFMAs of rows 2P, 2P+1 from g[row][hi/lo].
+// stores(ph) = global stores the pair functions of phase ph issue (training dumps), 0 outside [0, NP/2):
+// they sit in the same in-order vmcnt queue as the LDS-DMA pieces, so the wait for "everything but the
+// last DEPTH-1 batches" must allow them too -- counting fewer than were issued only makes the wait
+// stricter, never unsafe.
+template <int NP, class PairFn, class StoresFn>
+__device__ __forceinline__ void ring_layer(WRing& w, PairFn pair, StoresFn stores) {
+    static_assert(NP % 2 == 0, "layers start and end on batch boundaries");
+#pragma clang loop unroll(full)
+    for (int ph = 0; ph < NP / 2; ++ph) {
+        int allow = 2 * (DEPTH - 1);
+#pragma unroll
+        for (int d = 1; d < DEPTH; ++d) allow += (ph - d >= 0) ? stores(ph - d) : 0;
+        if (!(ABL & 16)) wait_vm_n(allow);
+        if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
+        ring_request(w);
+        ring_read_pair(w, w.rd, 1, w.g[1]);
+        pair(2 * ph, w.g[0]);
+        const unsigned nrd = (w.rd + BATCH_BYTES == RING_BYTES) ? 0u : w.rd + BATCH_BYTES;
+        ring_read_pair(w, nrd, 0, w.g[0]);
+        pair(2 * ph + 1, w.g[1]);
+        w.rd = nrd;
+    }
+}
+
+// converted B operands of one 32-channel input tile: two K=16 steps, hi and lo
+struct BTile {
+    u32x4 h[2], l[2];
+};
+
+// Transform applied to every pair of previous-layer values (registers r, r+1 of tile t) right before
+// the hi/lo split: activation / ReLU mask, sign-bit collection, dumps.  May modify a and b.
+struct XfNone {
+    __device__ __forceinline__ void operator()(int, int, float&, float&) const {}
+};
+struct XfRelu {
+    __device__ __forceinline__ void operator()(int, int, float& a, float& b) const {
+        // one v_med3_f32 each (fmaxf would add a canonicalising v_max in IEEE mode)
+        a = __builtin_amdgcn_fmed3f(a, 0.0f, __builtin_inff());
+        b = __builtin_amdgcn_fmed3f(b, 0.0f, __builtin_inff());
+    }
+};
+
+template <bool WRITEBACK, class Xf>
+__device__ __forceinline__ void convert_pair(f32x16& src, int r, BTile& dst, int t, Xf& xf) {
+    float a = src[r], b = src[r + 1];
+    xf(t, r, a, b);
+    if (WRITEBACK) { src[r] = a; src[r + 1] = b; }
+    unsigned hi, lo;
+    split_pair(a, b, hi, lo);
+    const int u = r >> 3, w = (r & 7) >> 1;
+    dst.h[u][w] = hi;
+    dst.l[u][w] = lo;
+}
+
+// accumulator tile nt starts from its bias: lane (j, h) register r <-> channel 32nt + (r&3) + 8(r>>2) + 4h
+__device__ __forceinline__ void bias_init(f32x16& acc, const float* bias, int nt, int h) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *(const f32x4*)(bias + 32 * nt + 8 * q + 4 * h);
+        acc[4 * q + 0] = v.x; acc[4 * q + 1] = v.y; acc[4 * q + 2] = v.z; acc[4 * q + 3] = v.w;
+    }
+}
+
+// ---- one dense layer from the previous layer's accumulators ---------------------------------------
+// prev[t] goes through xf (bias is already inside the accumulators) and is split tile by tile underneath
+// the MFMAs of the tile before it.  INIT: how acc starts -- from out_bias, from zero (inline C operand),
+// or continuing (L5 after its encoding part).  WRITEBACK keeps xf's result in prev (a second layer
+// reading the same input then uses XfNone).
+enum { INIT_NONE = 0, INIT_BIAS = 1, INIT_ZERO = 2 };
+
+// DUMPS = global stores xf issues per call (0, or 2 when it dumps both values).
+template <int NT_IN, int NT_OUT, int INIT, bool WRITEBACK, int DUMPS, class Xf>
+__device__ __forceinline__ void mm3_h(f32x16 (&prev)[NT_H], f32x16 (&acc)[NT_H], const float* out_bias, int h, WRing& w,
+                                      Xf xf) {
+    constexpr int PPT = NT_OUT;                 // row pairs per input tile (2 K-steps x NT_OUT rows / 2)
+    constexpr int NP = NT_IN * PPT;
+    // conversions (xf calls) issued inside pair P: the next tile's 8 register pairs spread over 2 PPT slots
+    auto conv_in_pair = [](int P) {
+        const int t = P / PPT, pt = P % PPT;
+        return t + 1 < NT_IN ? ((2 * pt + 2) * 8) / (2 * PPT) - ((2 * pt) * 8) / (2 * PPT) : 0;
+    };
+    auto stores = [&](int ph) { return DUMPS * (conv_in_pair(2 * ph) + conv_in_pair(2 * ph + 1)); };
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    BTile cur, nxt;
+    if (INIT == INIT_BIAS) { bias_init(acc[0], out_bias, 0, h); bias_init(acc[1 % NT_OUT], out_bias, 1 % NT_OUT, h); }
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) convert_pair<WRITEBACK>(prev[0], r, cur, 0, xf);
+    ring_layer<NP>(w, [&](int P, const u32x4 (&g)[2][2]) {
+        const int t = P / PPT, pt = P % PPT;
+        const int i0 = 2 * pt, i1 = i0 + 1;
+        const int u0 = i0 / NT_OUT, n0 = i0 % NT_OUT, u1 = i1 / NT_OUT, n1 = i1 % NT_OUT;
+        // biases of the tiles the NEXT pair opens
+        if (INIT == INIT_BIAS && t == 0) {
+#pragma unroll
+            for (int i = i0 + 2; i < i0 + 4; ++i)
+                if (i >= 2 && i < NT_OUT) bias_init(acc[i], out_bias, i, h);
+        }
+        const bool z0 = INIT == INIT_ZERO && t == 0 && u0 == 0, z1 = INIT == INIT_ZERO && t == 0 && u1 == 0;
+        acc[n0] = mfma_bf(g[0][0], cur.h[u0], z0 ? zero : acc[n0]);
+        acc[n1] = mfma_bf(g[1][0], cur.h[u1], z1 ? zero : acc[n1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < NT_IN && !(ABL & 4)) {
+#pragma unroll
+            for (int pr = ((2 * pt) * 8) / (2 * PPT); pr < ((2 * pt + 1) * 8) / (2 * PPT); ++pr)
+                convert_pair<WRITEBACK>(prev[t + 1], 2 * pr, nxt, t + 1, xf);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[n0] = mfma_bf(g[0][1], cur.h[u0], acc[n0]);
+        acc[n1] = mfma_bf(g[1][1], cur.h[u1], acc[n1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < NT_IN && !(ABL & 4)) {
+#pragma unroll
+            for (int pr = ((2 * pt + 1) * 8) / (2 * PPT); pr < ((2 * pt + 2) * 8) / (2 * PPT); ++pr)
+                convert_pair<WRITEBACK>(prev[t + 1], 2 * pr, nxt, t + 1, xf);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[n0] = mfma_bf(g[0][0], cur.l[u0], acc[n0]);
+        acc[n1] = mfma_bf(g[1][0], cur.l[u1], acc[n1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (pt == PPT - 1 && t + 1 < NT_IN) cur = nxt;
+    }, stores);
+}
+
+// ---- the 64-slot positional encoding (4 K=16 steps, pre-split in LDS) ------------------------------
+template <int NT_OUT>
+__device__ __forceinline__ void mm3_enc(const unsigned* enc_col, f32x16 (&acc)[NT_H], const float* out_bias, int h,
+                                        WRing& w) {
+    constexpr int NP = 4 * NT_OUT / 2;
+    static_assert(NT_OUT % 2 == 0, "a row pair stays inside one K step");
+    // LDS column layout: word index = tile*16 + (hi? 0 : 8) + u*4 + w, stride 256 threads
+    u32x4 bh[4], bl[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bh[s][c] = enc_col[((s >> 1) * 16 + (s & 1) * 4 + c) * 256];
+            bl[s][c] = enc_col[((s >> 1) * 16 + 8 + (s & 1) * 4 + c) * 256];
+        }
+    bias_init(acc[0], out_bias, 0, h);
+    bias_init(acc[1], out_bias, 1, h);
+    ring_layer<NP>(w, [&](int P, const u32x4 (&g)[2][2]) {
+        const int i0 = 2 * P, s = i0 / NT_OUT, n0 = i0 % NT_OUT, n1 = n0 + 1;
+        if (s == 0 && n0 + 3 < NT_OUT) {
+            bias_init(acc[n0 + 2], out_bias, n0 + 2, h);
+            bias_init(acc[n0 + 3], out_bias, n0 + 3, h);
+        }
+        acc[n0] = mfma_bf(g[0][0], bh[s], acc[n0]);
+        acc[n1] = mfma_bf(g[1][0], bh[s], acc[n1]);
+        acc[n0] = mfma_bf(g[0][1], bh[s], acc[n0]);
+        acc[n1] = mfma_bf(g[1][1], bh[s], acc[n1]);
+        acc[n0] = mfma_bf(g[0][0], bl[s], acc[n0]);
+        acc[n1] = mfma_bf(g[1][0], bl[s], acc[n1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }, [](int) { return 0; });
+}
+
+}  // namespace gnr

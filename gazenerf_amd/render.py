@@ -167,13 +167,9 @@ def _run_forward(prob: _Problem, streams, save: bool, want_depth: bool, want_wei
             res.append((feat, bga, dep, wts))
         w0 = _weights_struct(streams[0])
         w1 = _weights_struct(streams[1]) if n_streams > 1 else None
-        if bf16x3:
-            rc = lib.gnr_fwd_bf16x3(C.byref(prob.c), C.byref(w0), C.byref(w1) if w1 is not None else None,
-                                    C.byref(outs), C.c_void_p(ws.data_ptr()), ws.numel(), _stream_ptr(dev))
-        else:
-            rc = lib.gnr_fwd(C.byref(prob.c), C.byref(w0), C.byref(w1) if w1 is not None else None,
-                             C.byref(outs), 1 if save else 0, C.c_void_p(ws.data_ptr()), ws.numel(),
-                             _stream_ptr(dev))
+        fwd = lib.gnr_fwd_bf16x3 if bf16x3 else lib.gnr_fwd
+        rc = fwd(C.byref(prob.c), C.byref(w0), C.byref(w1) if w1 is not None else None,
+                 C.byref(outs), 1 if save else 0, C.c_void_p(ws.data_ptr()), ws.numel(), _stream_ptr(dev))
         _lib.check(rc, lib)
     return res, ws
 
@@ -193,8 +189,6 @@ class _RenderFn(torch.autograd.Function):
                    for s in range(n_streams)]
         need_grad = any(ctx.needs_input_grad[1:])
         bf16x3 = cfg.get("precision", "fp32") == "bf16x3"
-        if bf16x3 and need_grad:
-            raise RuntimeError("precision='bf16x3' is inference-only; run it under torch.no_grad() or use 'fp32'")
         res, ws = _run_forward(prob, streams, need_grad, cfg["want_depth"], cfg["want_weights"], bf16x3)
         ctx.cfg, ctx.prob, ctx.streams = cfg, prob, streams
         ctx.saved_ws = ws if need_grad else None
@@ -247,11 +241,12 @@ class _RenderFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             nbytes = lib.gnr_workspace_bytes(C.byref(prob.c), n_streams, _lib.WS_BWD)
             scratch = _alloc_ws(max(nbytes, 256), dev)
-            rc = lib.gnr_bwd(C.byref(prob.c), C.byref(w[0]), C.byref(w[1]) if n_streams > 1 else None,
-                             C.byref(dout), C.byref(din), C.byref(dw[0]),
-                             C.byref(dw[1]) if n_streams > 1 else None,
-                             C.c_void_p(ctx.saved_ws.data_ptr()), ctx.saved_ws.numel(),
-                             C.c_void_p(scratch.data_ptr()), scratch.numel(), _stream_ptr(dev))
+            bwd = lib.gnr_bwd_bf16x3 if cfg.get("precision", "fp32") == "bf16x3" else lib.gnr_bwd
+            rc = bwd(C.byref(prob.c), C.byref(w[0]), C.byref(w[1]) if n_streams > 1 else None,
+                     C.byref(dout), C.byref(din), C.byref(dw[0]),
+                     C.byref(dw[1]) if n_streams > 1 else None,
+                     C.c_void_p(ctx.saved_ws.data_ptr()), ctx.saved_ws.numel(),
+                     C.c_void_p(scratch.data_ptr()), scratch.numel(), _stream_ptr(dev))
             _lib.check(rc, lib)
         ctx.saved_ws = None
         flat = []
@@ -272,9 +267,9 @@ def render_two_stream(batch_xy, R, T, Kinv, shape_code, gaze, appea_code, face_p
     ``eyes_params=None`` evaluates a single MLP -- the hierarchical fine pass with the third
     network (models/gaze_nerf.py:102-108); its results come back under the "face" keys.
 
-    ``precision="bf16x3"`` (inference only) runs the dense layers on bf16 MFMA with a 3-term hi/lo
-    split of both operands; it agrees with the default exact-fp32 path to that path's own rounding
-    noise (see gnr_fwd_bf16x3 in include/gnr.h).
+    ``precision="bf16x3"`` runs the dense layers (forward and the dgrad chain of the backward) on bf16
+    MFMA with a 3-term hi/lo split of both operands; it agrees with the default exact-fp32 path to that
+    path's own rounding noise (see gnr_fwd_bf16x3 / gnr_bwd_bf16x3 in include/gnr.h).
     """
     if precision not in ("fp32", "bf16x3"):
         raise ValueError("precision must be 'fp32' or 'bf16x3'")

@@ -134,13 +134,20 @@ int gnr_fwd(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes,
             const GnrOutputs* out, int save_for_backward,
             void* workspace, size_t ws_bytes, void* stream);
 
-/* Inference-only variant of gnr_fwd with the dense layers on bf16 MFMA through a 3-term split
- * (x = hi + lo; a*b ~ a_hi*b_hi + a_lo*b_hi + a_hi*b_lo, fp32 accumulate): ~16 mantissa bits per
- * operand at 5.3x the fp32-MFMA rate.  Same arguments, workspace (GNR_WS_FWD) and outputs as gnr_fwd;
- * results agree with it to the fp32 path's own rounding noise (feature map <= ~6e-6, bg_alpha <=
- * ~3e-5 on the reference fixtures) -- inside the 1e-4 contract.  No backward. */
+/* gnr_fwd / gnr_bwd with the dense layers on bf16 MFMA through a 3-term split (x = hi + lo;
+ * a*b ~ a_hi*b_hi + a_lo*b_hi + a_hi*b_lo, fp32 accumulate): ~16 mantissa bits per operand at 5.3x the
+ * fp32-MFMA rate.  Same arguments, workspaces and outputs as gnr_fwd / gnr_bwd (the saved workspace has
+ * the same layout, so either backward may follow either forward).  Forward results agree with gnr_fwd to
+ * that path's own rounding noise (feature map <= ~6e-6, bg_alpha <= ~3e-5 on the reference fixtures:
+ * inside the 1e-4 contract); gradients stay inside the reference's own fp32-vs-fp64 noise on every
+ * tensor.  The weight-gradient GEMMs (dW = dY^T X) remain exact fp32 MFMA. */
 int gnr_fwd_bf16x3(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes,
-                   const GnrOutputs* out, void* workspace, size_t ws_bytes, void* stream);
+                   const GnrOutputs* out, int save_for_backward, void* workspace, size_t ws_bytes,
+                   void* stream);
+int gnr_bwd_bf16x3(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes,
+                   const GnrOutputGrads* dout, const GnrInputGrads* din, const GnrWeightGrads* dface,
+                   const GnrWeightGrads* deyes, void* saved_workspace, size_t saved_bytes, void* scratch,
+                   size_t scratch_bytes, void* stream);
 
 /* Backward of gnr_fwd for the same problem and weights. */
 int gnr_bwd(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes,

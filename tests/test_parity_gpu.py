@@ -193,11 +193,6 @@ def test_errors_are_exceptions():
     with pytest.raises(_lib.GnrError, match="n_samples"):
         render.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"],
                                  p["appea_code"], face, face, n_samples=1000)
-    # the split-bf16 kernel is inference-only: asking it for gradients is an error, not a fallback
-    sc = p["shape_code"].clone().requires_grad_(True)
-    with pytest.raises(RuntimeError, match="inference-only"):
-        render.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], sc, p["gaze"],
-                                 p["appea_code"], face, face, n_samples=32, precision="bf16x3")
     with pytest.raises(ValueError, match="precision"):
         render.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"],
                                  p["appea_code"], face, face, n_samples=32, precision="fp16")
@@ -215,14 +210,14 @@ GRAD_L2 = 2e-2
 GRAD_MAX = 4e-2
 
 
-def _grads_hip(p, face, eyes, n_samples, t_rand, dev):
+def _grads_hip(p, face, eyes, n_samples, t_rand, dev, precision="fp32"):
     pd = _to(p, dev)
     leaves = {k: pd[k].clone().requires_grad_(True) for k in ("R", "T", "shape_code", "gaze", "appea_code")}
     fp = {k: v.to(dev).clone().requires_grad_(True) for k, v in face.items()}
     ep = {k: v.to(dev).clone().requires_grad_(True) for k, v in eyes.items()}
     out = render.render_two_stream(pd["xy"], leaves["R"], leaves["T"], pd["Kinv"], leaves["shape_code"],
                                    leaves["gaze"], leaves["appea_code"], fp, ep, n_samples=n_samples,
-                                   t_rand=t_rand.to(dev) if t_rand is not None else None)
+                                   t_rand=t_rand.to(dev) if t_rand is not None else None, precision=precision)
     loss = sum((out["feat_" + t] ** 2).mean() + out["bg_alpha_" + t].mean() for t in ("face", "eyes"))
     loss.backward()
     return out, leaves, fp, ep
@@ -237,13 +232,14 @@ def _check_grad(name, got, ref):
         "%s: max-abs %.3e (scale %.3e), rel-L2 %.3e" % (name, err, scale, l2)
 
 
-def test_backward_vs_reference_fixture():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_backward_vs_reference_fixture(precision):
     """g6: B=2 x 32 rays x 64 samples, train-mode jitter, opaque head; gradients of the A8 loss
     captured from the reference's own autograd (big weight tensors as every 16th row)."""
     dev = _dev()
     g = load_golden("g6_backward")
     face, eyes = _weights(g)
-    out, leaves, fp, ep = _grads_hip(golden_problem(g), face, eyes, int(g["n_samples"]), g["t_rand"], dev)
+    out, leaves, fp, ep = _grads_hip(golden_problem(g), face, eyes, int(g["n_samples"]), g["t_rand"], dev, precision)
     for tag in ("face", "eyes"):
         assert _maxabs(out["feat_" + tag], g["out_feat_" + tag]) <= TOL
         assert _maxabs(out["bg_alpha_" + tag], g["out_bg_alpha_" + tag]) <= TOL
@@ -258,8 +254,9 @@ def test_backward_vs_reference_fixture():
             _check_grad("%s.%s" % (tag, name), got.reshape(ref.shape), ref)
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("n_samples,n_rays,batch,train", [(64, 40, 2, True), (32, 21, 1, False), (40, 9, 2, True)])
-def test_backward_vs_oracle_live(n_samples, n_rays, batch, train):
+def test_backward_vs_oracle_live(n_samples, n_rays, batch, train, precision):
     dev = _dev()
     sub = torch.arange(n_rays) * 53 % 4096
     p = synth.synth_problem(64, batch=batch, camera="9", seed=31, ray_subset=sub)
@@ -272,7 +269,7 @@ def test_backward_vs_oracle_live(n_samples, n_rays, batch, train):
     ref = O.render_two_stream(p["xy"], leaves["R"], leaves["T"], p["Kinv"], leaves["shape_code"], leaves["gaze"],
                               leaves["appea_code"], fo, eo, n_samples, t_rand=t_rand)
     O.synthetic_loss(ref).backward()
-    out, hl, fp, ep = _grads_hip(p, face, eyes, n_samples, t_rand, dev)
+    out, hl, fp, ep = _grads_hip(p, face, eyes, n_samples, t_rand, dev, precision)
     for k in leaves:
         _check_grad("d" + k, hl[k].grad, leaves[k].grad)
     for tag, hp, op in (("face", fp, fo), ("eyes", ep, eo)):
@@ -280,7 +277,8 @@ def test_backward_vs_oracle_live(n_samples, n_rays, batch, train):
             _check_grad("%s.%s" % (tag, name), hp[name].grad, op[name].grad)
 
 
-def test_backward_is_deterministic():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_backward_is_deterministic(precision):
     """Two identical calls give bit-identical gradients (fixed-order split reductions; the reference
     trains with cudnn.deterministic=True, train.py:57)."""
     dev = _dev()
@@ -288,8 +286,8 @@ def test_backward_is_deterministic():
     face = synth.hash_mlp_params("face", seed=0, density_scale=50.0)
     eyes = synth.hash_mlp_params("eyes", seed=0, density_scale=50.0)
     t_rand = synth.synth_jitter(2, 64, 64, seed=2)
-    a = _grads_hip(p, face, eyes, 64, t_rand, dev)
-    b = _grads_hip(p, face, eyes, 64, t_rand, dev)
+    a = _grads_hip(p, face, eyes, 64, t_rand, dev, precision)
+    b = _grads_hip(p, face, eyes, 64, t_rand, dev, precision)
     for k in a[1]:
         assert torch.equal(a[1][k].grad, b[1][k].grad), k
     for x, y in ((a[2], b[2]), (a[3], b[3])):
@@ -401,8 +399,9 @@ def test_merge_end_to_end_with_render_op():
 
 
 # ----------------------------------------------------------------------------- edge cases
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("n_samples,n_rays,batch", [(2, 1, 1), (512, 3, 1), (33, 5, 2), (64, 1, 4)])
-def test_edge_sizes_forward_and_backward(n_samples, n_rays, batch):
+def test_edge_sizes_forward_and_backward(n_samples, n_rays, batch, precision):
     """Minimum (2) and maximum (512) sample counts, a single ray, one sample past a chunk boundary
     (33), more images than rays: forward vs the oracle on its own edges, gradients finite and equal
     to the oracle's within the fp32 noise bound."""
@@ -420,12 +419,12 @@ def test_edge_sizes_forward_and_backward(n_samples, n_rays, batch):
                               leaves["appea_code"], fo, eo, n_samples, t_rand=t_rand)
     O.synthetic_loss(ref).backward()
     with torch.no_grad():
-        out_e = _hip(p, face, eyes, n_samples, dev, z_edges=edges, return_weights=True)
+        out_e = _hip(p, face, eyes, n_samples, dev, z_edges=edges, return_weights=True, precision=precision)
     for tag in ("face", "eyes"):
         assert _maxabs(out_e["feat_" + tag], ref["feat_" + tag]) <= TOL
         assert _maxabs(out_e["bg_alpha_" + tag], ref["bg_alpha_" + tag]) <= TOL
         assert _maxabs(out_e["w_" + tag], ref["w_" + tag]) <= W_TOL
-    out, hl, fp, ep = _grads_hip(p, face, eyes, n_samples, t_rand, dev)
+    out, hl, fp, ep = _grads_hip(p, face, eyes, n_samples, t_rand, dev, precision)
     for k in leaves:
         assert torch.isfinite(hl[k].grad).all()
     if (n_samples & (n_samples - 1)) == 0:          # power-of-two counts: same z as the oracle's sweep
