@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--micro", type=int, default=16384, help="rays per backward micro-batch")
     ap.add_argument("--precision", choices=("fp32", "bf16x3"), default=os.environ.get("GNR_BENCH_PRECISION", "fp32"),
                     help="fp32: exact fp32 MFMA everywhere; bf16x3: forward + dgrad chain on bf16 MFMA with a "
-                         "3-term hi/lo split (fp32 accumulate; weight-gradient GEMMs stay fp32)")
+                         "3-term hi/lo split (fp32 accumulate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=512)
     return ap.parse_args()
@@ -224,7 +224,7 @@ def main():
             "metric": "rays/sec (512x512, 64 samples/ray) %s" % ("fwd+bwd" if args.mode == "fwdbwd" else "fwd"),
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16x3 (hi/lo split bf16 MFMA, f32 accumulate; wgrad f32)" if x3 else "f32", "data": "synthetic",
+            "dtype": "bf16x3 (3-term hi/lo split on bf16 MFMA, f32 accumulate)" if x3 else "f32", "data": "synthetic",
             "config": {"workload": "%s: %dx%d rays x %d samples/ray, two streams (face+eyes), %s, "
                                    "1 image per GPU%s" % ("cfg2b" if (side, n_p) == (512, 64) else "custom", side, side, n_p, args.mode,
                                                           ", %d-ray micro-batches" % micro if args.mode == "fwdbwd" else ""),

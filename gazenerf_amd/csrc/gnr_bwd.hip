@@ -21,7 +21,7 @@ size_t carve_fwd(const GnrProblem* p, int n_streams, bool save, char* base, FwdP
 size_t wgrad_scratch_floats();
 void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, int batch,
                   long chunks_per_image, float* dW, int ldw, int col_off, int enc_map, float* colsum_out,
-                  int colsum_ld, const float* vec, float* vec_out, float* scratch, hipStream_t stream);
+                  int colsum_ld, const float* vec, float* vec_out, float* scratch, hipStream_t stream, bool bf16x3);
 void launch_vecsum(const float* v, int batch, long per_image, float* out, int out_stride, hipStream_t stream);
 extern std::atomic<hipEvent_t> g_ev_start, g_ev_stop, g_aux_start, g_aux_stop;
 
@@ -578,25 +578,25 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         auto dbl = [&](int l) { return sc.dbias + (size_t)l * p->batch * H; };
         const long cpi = (long)p->n_rays * cpr;                       // chunks per image
         launch_wgrad(sc.dfeat, FEAT_PAD, p->feat_nc, ws.act_y1, H2, H2, p->batch, cpi, DW.rgb_w[2], H2, 0, 0,
-                     dbl(LR2), H, nullptr, nullptr, sc.wg_part, st);
+                     dbl(LR2), H, nullptr, nullptr, sc.wg_part, st, bf16x3);
         launch_wgrad(sc.dY_r1, H2, H2, ws.act_y0, H, H, p->batch, cpi, DW.rgb_w[1], H + p->appea_dims, 0, 0,
-                     dbl(LR1), H, nullptr, nullptr, sc.wg_part, st);
+                     dbl(LR1), H, nullptr, nullptr, sc.wg_part, st, bf16x3);
         launch_wgrad(sc.dY_r0, H, H, hptr(7), H, H, p->batch, cpi, DW.rgb_w[0], H, 0, 0, dbl(LR0), H,
-                     sc.dsig, DW.density_w, sc.wg_part, st);
+                     sc.dsig, DW.density_w, sc.wg_part, st, bf16x3);
         for (int l = 7; l >= 1; --l) {
             if (l == 5) {
                 launch_wgrad(dyh(5), H, H, hptr(4), H, H, p->batch, cpi, DW.fea_w[5], vp + H, vp, 0, dbl(5), H,
-                             nullptr, nullptr, sc.wg_part, st);
+                             nullptr, nullptr, sc.wg_part, st, bf16x3);
                 if (DW.fea_w[5])
                     launch_wgrad(dyh(5), H, H, fp.enc, ENC_PAD, ENC_PAD, p->batch, cpi, DW.fea_w[5], vp + H, 0, 1,
-                                 nullptr, 0, nullptr, nullptr, sc.wg_part, st);
+                                 nullptr, 0, nullptr, nullptr, sc.wg_part, st, bf16x3);
             } else {
                 launch_wgrad(dyh(l), H, H, hptr(l - 1), H, H, p->batch, cpi, DW.fea_w[l], H, 0, 0, dbl(l), H,
-                             nullptr, nullptr, sc.wg_part, st);
+                             nullptr, nullptr, sc.wg_part, st, bf16x3);
             }
         }
         launch_wgrad(dyh(0), H, H, fp.enc, ENC_PAD, ENC_PAD, p->batch, cpi, DW.fea_w[0], vp, 0, 1, dbl(0), H,
-                     nullptr, nullptr, sc.wg_part, st);
+                     nullptr, nullptr, sc.wg_part, st, bf16x3);
         launch_vecsum(sc.dsig_ray, p->batch, p->n_rays, dbl(N_CHAIN), H, st);
 
         // 6. latent gradients from the per-image bias sums

@@ -23,7 +23,7 @@
 // Riding along on otherwise idle VALU slots:
 //   * column sums of dY (bias gradients, per image)            -- waves with tile-k == 0
 //   * vec^T X for a per-sample vector (density-head gradient)  -- waves with tile-n == 0
-#include "gnr_device.h"
+#include "gnr_chain3.h"
 
 namespace gnr {
 
@@ -195,6 +195,176 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams wp) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16x3 variant: same tiling, split and reduce; the operands are split hi/lo (3-term product, fp32
+// accumulate) while they are staged, so the LDS image is four bf16 planes per buffer
+// (A_hi, A_lo, B_hi, B_lo: [128 rows][32 samples] = 8 KiB each) and a chunk costs 24
+// v_mfma_f32_32x32x16_bf16 per wave (768 matrix-pipe cycles) instead of 64 fp32 MFMAs (4096).
+// Row = 64 bytes = 4 pieces of 8 samples; piece p of row n sits at piece p ^ ((n >> 2) & 3), which
+// keeps the 16 rows of every ds_read_b128 lane group on 16 different 16-byte slots.  A lane's
+// operand for K-step ks (16 samples) is piece 2*lh + ks of its row: lane-half lh contracts samples
+// 16 lh .. 16 lh + 15 of the chunk, the same free choice of order as in the fp32 kernel.
+// The bias / density-head riders are taken from the fp32 values in the staging registers.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int swz3(int n, int p) { return n * 32 + ((p ^ ((n >> 2) & 3)) << 3); }   // in bf16 elements
+
+template <bool VEC>
+__global__ __launch_bounds__(256, 2) void wgrad3_kernel(const WgradParams wp) {
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2][4][WG_TN * CHUNK];   // [buffer][A_hi,A_lo,B_hi,B_lo]
+    const int tiles = wp.tiles_n * wp.tiles_k;
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int split = xcd + 8 * (slot / tiles);
+    const int tile = slot % tiles;
+    if (split >= wp.batch * wp.spi) return;
+    const int tn = tile / wp.tiles_k, tk = tile - tn * wp.tiles_k;
+    if (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) __builtin_amdgcn_s_setprio(1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int b = split / wp.spi, sp = split - b * wp.spi;
+    const long c0 = (long)b * wp.chunks_per_image + (long)sp * wp.chunks_per_split;
+    long c1 = c0 + wp.chunks_per_split;
+    const long cmax = (long)(b + 1) * wp.chunks_per_image;
+    if (c1 > cmax) c1 = cmax;
+
+    // staging: thread owns pieces (row r0 = tid/4, piece pc = tid%4) and (row r0 + 64, pc) of both operands
+    const int r0 = tid >> 2, pc = tid & 3;
+    const float* ga[2];
+    const float* gb[2];
+    int lpos[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int r = r0 + 64 * q;
+        int n = tn * WG_TN + r; if (n >= wp.lda) n = wp.lda - 1;
+        int k = tk * WG_TK + r; if (k >= wp.ldb) k = wp.ldb - 1;
+        ga[q] = wp.A + (long)n * CHUNK + 8 * pc;
+        gb[q] = wp.B + (long)k * CHUNK + 8 * pc;
+        lpos[q] = swz3(r, pc);
+    }
+    const long strideA = (long)CHUNK * wp.lda, strideB = (long)CHUNK * wp.ldb;
+    f32x4 ra[2][2], rb[2][2];
+    auto gload = [&](long c) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            ra[q][0] = *(const f32x4*)(ga[q] + c * strideA);
+            ra[q][1] = *(const f32x4*)(ga[q] + c * strideA + 4);
+            rb[q][0] = *(const f32x4*)(gb[q] + c * strideB);
+            rb[q][1] = *(const f32x4*)(gb[q] + c * strideB + 4);
+        }
+    };
+    float cs[2] = {0.0f, 0.0f}, vs[2] = {0.0f, 0.0f};
+    f32x4 vv[2];
+    auto split8 = [](const f32x4& lo4, const f32x4& hi4, u32x4& h, u32x4& l) {
+        unsigned hh[4], ll[4];
+        split_pair(lo4.x, lo4.y, hh[0], ll[0]);
+        split_pair(lo4.z, lo4.w, hh[1], ll[1]);
+        split_pair(hi4.x, hi4.y, hh[2], ll[2]);
+        split_pair(hi4.z, hi4.w, hh[3], ll[3]);
+        h = u32x4{hh[0], hh[1], hh[2], hh[3]};
+        l = u32x4{ll[0], ll[1], ll[2], ll[3]};
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            u32x4 h, l;
+            split8(ra[q][0], ra[q][1], h, l);
+            *(u32x4*)&lds[buf][0][lpos[q]] = h;
+            *(u32x4*)&lds[buf][1][lpos[q]] = l;
+            cs[q] += ((ra[q][0].x + ra[q][0].y) + (ra[q][0].z + ra[q][0].w)) + ((ra[q][1].x + ra[q][1].y) + (ra[q][1].z + ra[q][1].w));
+            split8(rb[q][0], rb[q][1], h, l);
+            *(u32x4*)&lds[buf][2][lpos[q]] = h;
+            *(u32x4*)&lds[buf][3][lpos[q]] = l;
+            if (VEC) {
+                float d = vv[0].x * rb[q][0].x;
+                d = fmaf(vv[0].y, rb[q][0].y, d); d = fmaf(vv[0].z, rb[q][0].z, d); d = fmaf(vv[0].w, rb[q][0].w, d);
+                d = fmaf(vv[1].x, rb[q][1].x, d); d = fmaf(vv[1].y, rb[q][1].y, d);
+                d = fmaf(vv[1].z, rb[q][1].z, d); d = fmaf(vv[1].w, rb[q][1].w, d);
+                vs[q] += d;
+            }
+        }
+    };
+    auto vload = [&](long c) {
+        if (VEC) {
+            vv[0] = *(const f32x4*)(wp.vec + c * CHUNK + 8 * pc);
+            vv[1] = *(const f32x4*)(wp.vec + c * CHUNK + 8 * pc + 4);
+        }
+    };
+
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 acc[2][2] = {{zero, zero}, {zero, zero}};
+    // operand read positions: rows wn*64 + 32x + li (A) / wk*64 + 32y + li (B), K-step ks -> piece 2 lh + ks
+    int apos[2][2], bpos[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            apos[x][ks] = swz3(wn * 64 + 32 * x + li, 2 * lh + ks);
+            bpos[x][ks] = swz3(wk * 64 + 32 * x + li, 2 * lh + ks);
+        }
+
+    if (c0 < c1) {
+        gload(c0);
+        vload(c0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (long c = c0; c < c1; ++c) {
+        const int buf = (int)((c - c0) & 1);
+        if (c + 1 < c1) { gload(c + 1); vload(c + 1); }
+        u32x4 ah[2][2], al[2][2], bh[2][2], bl[2][2];      // [tile][K-step]
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                ah[x][ks] = *(const u32x4*)&lds[buf][0][apos[x][ks]];
+                al[x][ks] = *(const u32x4*)&lds[buf][1][apos[x][ks]];
+                bh[x][ks] = *(const u32x4*)&lds[buf][2][bpos[x][ks]];
+                bl[x][ks] = *(const u32x4*)&lds[buf][3][bpos[x][ks]];
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y)
+                        acc[x][y] = mfma_bf(term == 1 ? al[x][ks] : ah[x][ks], term == 2 ? bl[y][ks] : bh[y][ks], acc[x][y]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < c1) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* pt = wp.partial + (((long)split * wp.tiles_n + tn) * wp.tiles_k + tk) * (long)(WG_TN * WG_TK);
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = wn * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int jx = wk * 64 + y * 32 + li;
+                pt[i * WG_TK + jx] = acc[x][y][r];
+            }
+    // riders: the four threads tid%4 = 0..3 of a row hold its four 8-sample pieces
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        float t = cs[q];
+        t += __shfl_xor(t, 1);
+        t += __shfl_xor(t, 2);
+        if (tk == 0 && pc == 0) wp.colsum_part[(long)split * (wp.tiles_n * WG_TN) + tn * WG_TN + r0 + 64 * q] = t;
+        if (VEC) {
+            float u = vs[q];
+            u += __shfl_xor(u, 1);
+            u += __shfl_xor(u, 2);
+            if (tn == 0 && pc == 0) wp.vec_part[(long)split * (wp.tiles_k * WG_TK) + tk * WG_TK + r0 + 64 * q] = u;
+        }
+    }
+}
+
 struct WgradReduceParams {
     const float* partial;
     int splits, tiles_n, tiles_k;
@@ -250,7 +420,7 @@ size_t wgrad_scratch_floats() {
 // Optional: colsum_out[b][n] = per-image column sums of A; vec_out[k] = vec^T B.
 void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, int batch,
                   long chunks_per_image, float* dW, int ldw, int col_off, int enc_map, float* colsum_out,
-                  int colsum_ld, const float* vec, float* vec_out, float* scratch, hipStream_t stream) {
+                  int colsum_ld, const float* vec, float* vec_out, float* scratch, hipStream_t stream, bool bf16x3) {
     WgradParams wp{};
     wp.A = A; wp.B = B; wp.lda = lda; wp.ldb = ldb; wp.n_valid = n_valid; wp.k_valid = k_valid;
     wp.tiles_n = (n_valid + WG_TN - 1) / WG_TN;
@@ -277,8 +447,13 @@ void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb,
     wp.vec_part = vec_part;
     const int splits = batch * (int)spi;
     const unsigned blocks = (unsigned)(8 * ((splits + 7) / 8) * tiles);
-    if (wp.vec) hipLaunchKernelGGL((wgrad_kernel<true>), dim3(blocks), dim3(256), 0, stream, wp);
-    else hipLaunchKernelGGL((wgrad_kernel<false>), dim3(blocks), dim3(256), 0, stream, wp);
+    if (bf16x3) {
+        if (wp.vec) hipLaunchKernelGGL((wgrad3_kernel<true>), dim3(blocks), dim3(256), 0, stream, wp);
+        else hipLaunchKernelGGL((wgrad3_kernel<false>), dim3(blocks), dim3(256), 0, stream, wp);
+    } else {
+        if (wp.vec) hipLaunchKernelGGL((wgrad_kernel<true>), dim3(blocks), dim3(256), 0, stream, wp);
+        else hipLaunchKernelGGL((wgrad_kernel<false>), dim3(blocks), dim3(256), 0, stream, wp);
+    }
     WgradReduceParams rp{};
     rp.partial = scratch; rp.splits = splits; rp.tiles_n = wp.tiles_n; rp.tiles_k = wp.tiles_k;
     rp.n_valid = n_valid; rp.k_valid = k_valid; rp.dW = dW; rp.ldw = ldw; rp.col_off = col_off; rp.enc_map = enc_map;

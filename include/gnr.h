@@ -140,7 +140,8 @@ int gnr_fwd(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes,
  * the same layout, so either backward may follow either forward).  Forward results agree with gnr_fwd to
  * that path's own rounding noise (feature map <= ~6e-6, bg_alpha <= ~3e-5 on the reference fixtures:
  * inside the 1e-4 contract); gradients stay inside the reference's own fp32-vs-fp64 noise on every
- * tensor.  The weight-gradient GEMMs (dW = dY^T X) remain exact fp32 MFMA. */
+ * tensor.  The weight-gradient GEMMs (dW = dY^T X) use the same split; bias, latent-code,
+ * density-head and geometry gradients, the compositing backward and all reductions stay fp32. */
 int gnr_fwd_bf16x3(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes,
                    const GnrOutputs* out, int save_for_backward, void* workspace, size_t ws_bytes,
                    void* stream);
