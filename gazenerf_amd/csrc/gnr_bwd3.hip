@@ -4,7 +4,8 @@
 // weights stream through the workgroup's LDS ring as [hi][lo] bf16 rows, a layer's output stays in
 // registers as raw fp32 accumulators and the NEXT layer's transform applies the ReLU mask (+ the
 // density-head term), dumps the result -- that layer's dY, the A operand of the weight-gradient GEMMs,
-// same chunk-channel-major fp32 layout as the fp32 chain writes -- and splits it into bf16 hi/lo.
+// fp32 in the channel-quad layout of gnr_chain3.h (one 16-byte store per quad) -- and splits it into
+// bf16 hi/lo.  Needs the saved workspace of gnr_fwd_bf16x3 (encoding and activations in that layout).
 // tools/cpu_bf16x3_grad_probe.py: gradients of a bf16x3 step sit inside the reference's own fp32-vs-fp64
 // noise on every tensor (worst rel-L2 9.96e-3 against 1.01e-2 for plain fp32; 3e-5 where fp32 has 3e-6).
 #include "gnr_bwd_common.h"
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256, 1) void bwd3_chain_kernel(const BwdParams bp) 
     const long row = chunk * CHUNK + j;
     const long M = bp.M;
     for (int q = tid; q < H; q += 256) wsig_lds[q] = bp.wsig[q];
-    const float* enc_row = bp.enc + chunk * (CHUNK * ENC_PAD) + j;     // CCM: slot stride 32
+    const float* enc_row = bp.enc + chunk * (CHUNK * ENC_PAD) + 4 * j;     // channel-quad layout
     const float ds = bp.dsig[row];
     f32x16 A[NT_H], Bv[NT_H];
     float gx = 0.0f, gy = 0.0f, gz = 0.0f;
@@ -99,19 +100,19 @@ __global__ __launch_bounds__(256, 1) void bwd3_chain_kernel(const BwdParams bp) 
     // the in-order vmcnt queue behind fresh LDS-DMA pieces
     unsigned mk[RELU_WORDS], mkn[RELU_WORDS];
     auto bits = [&](int layer) { return bp.relu_bits + relu_bits_offset(layer, bp.n_chunks, chunk); };
-    auto dyh = [&](int l) { return dump_ptr(bp.dY_h + l * M * H, H, chunk, j, h); };
+    auto dyh = [&](int l) { return quad_ptr(bp.dY_h + l * M * H, H, chunk, j, h); };
     auto keep = [](unsigned word, int t, int rr, float v) {
         // bit 16 (t&1) + rr of the word -> all-ones / zero mask (v_bfe_i32 + v_and)
         const int m = __builtin_amdgcn_sbfe((int)word, 16 * (t & 1) + rr, 1);
         return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & m);
     };
-    // transform of a layer input: [mask with the sign bits in mk] + dump
+    // transform of a layer input: [mask with the sign bits in mk] + dump (channel-quad layout)
 #define GNR_XF(MASK, DP)                                                                          \
-    [&, dp = (DP)](int t, int rr, float& a, float& b) {                                           \
-        if (MASK) { a = keep(mk[t >> 1], t, rr, a); b = keep(mk[t >> 1], t, rr + 1, b); }         \
-        const int ch = 32 * t + (rr & 3) + 8 * (rr >> 2);                                         \
-        dp[ch * CHUNK] = a;                                                                       \
-        dp[(ch + 1) * CHUNK] = b;                                                                 \
+    [&, dp = (DP)](int t, int rr, f32x4& v) {                                                     \
+        if (MASK) {                                                                               \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = keep(mk[t >> 1], t, rr + e, v[e]); \
+        }                                                                                         \
+        *(f32x4*)(dp + quad_off(t, rr)) = v;                                                      \
     }
     auto promote = [&]() {
 #pragma unroll
@@ -120,36 +121,35 @@ __global__ __launch_bounds__(256, 1) void bwd3_chain_kernel(const BwdParams bp) 
 
     load_relu_bits<NT_H2>(mkn, bits(8), lane);
     // RGB2^T: A(9) -> Bv(6)                          (dumps dfeat)
-    mm3_h<NT_F, NT_H2, INIT_ZERO, false, 2>(A, Bv, nullptr, h, w, GNR_XF(false, dump_ptr(bp.dfeat, FEAT_PAD, chunk, j, h)));
+    mm3_h<NT_F, NT_H2, INIT_ZERO, false, 1>(A, Bv, nullptr, h, w, GNR_XF(false, quad_ptr(bp.dfeat, FEAT_PAD, chunk, j, h)));
     promote();
     load_relu_bits<NT_H>(mkn, bits(7), lane);
     // RGB1^T: Bv(6) -> A(12), input masked by y1 > 0  (dumps dY_r1)
-    mm3_h<NT_H2, NT_H, INIT_ZERO, false, 2>(Bv, A, nullptr, h, w, GNR_XF(true, dump_ptr(bp.dY_r1, H2, chunk, j, h)));
+    mm3_h<NT_H2, NT_H, INIT_ZERO, false, 1>(Bv, A, nullptr, h, w, GNR_XF(true, quad_ptr(bp.dY_r1, H2, chunk, j, h)));
     // RGB0^T: A -> Bv, no activation on y0           (dumps dY_r0)
-    mm3_h<NT_H, NT_H, INIT_ZERO, false, 2>(A, Bv, nullptr, h, w, GNR_XF(false, dump_ptr(bp.dY_r0, H, chunk, j, h)));
+    mm3_h<NT_H, NT_H, INIT_ZERO, false, 1>(A, Bv, nullptr, h, w, GNR_XF(false, quad_ptr(bp.dY_r0, H, chunk, j, h)));
     promote();
     load_relu_bits<NT_H>(mkn, bits(6), lane);
     // L7^T: Bv -> A; input = (d h7 + density head) masked by h7 > 0   (dumps dY_7)
     {
         const float* wsg = wsig_lds + 4 * h;
         float* dp = dyh(7);
-        mm3_h<NT_H, NT_H, INIT_ZERO, false, 2>(Bv, A, nullptr, h, w, [&, dp](int t, int rr, float& a, float& b) {
-            const int ch = 32 * t + (rr & 3) + 8 * (rr >> 2);
-            a = keep(mk[t >> 1], t, rr, fmaf(wsg[ch], ds, a));
-            b = keep(mk[t >> 1], t, rr + 1, fmaf(wsg[ch + 1], ds, b));
-            dp[ch * CHUNK] = a;
-            dp[(ch + 1) * CHUNK] = b;
+        mm3_h<NT_H, NT_H, INIT_ZERO, false, 1>(Bv, A, nullptr, h, w, [&, dp](int t, int rr, f32x4& v) {
+            const f32x4 w4 = *(const f32x4*)(wsg + 32 * t + 8 * (rr >> 2));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = keep(mk[t >> 1], t, rr + e, fmaf(w4[e], ds, v[e]));
+            *(f32x4*)(dp + quad_off(t, rr)) = v;
         });
     }
     promote();
     load_relu_bits<NT_H>(mkn, bits(5), lane);
     // L6^T: A -> Bv, input masked by h6 > 0           (dumps dY_6)
-    mm3_h<NT_H, NT_H, INIT_ZERO, false, 2>(A, Bv, nullptr, h, w, GNR_XF(true, dyh(6)));
+    mm3_h<NT_H, NT_H, INIT_ZERO, false, 1>(A, Bv, nullptr, h, w, GNR_XF(true, dyh(6)));
     promote();
     load_relu_bits<NT_H>(mkn, bits(4), lane);
     // L5: encoding columns first (2 tiles; masks h5 > 0 in place, dumps dY_5), then the hidden columns -> A
-    mm3_h<NT_H, 2, INIT_ZERO, true, 2>(Bv, A, nullptr, h, w, GNR_XF(true, dyh(5)));
-    enc_backward(A, enc_row, h, gx, gy, gz);
+    mm3_h<NT_H, 2, INIT_ZERO, true, 1>(Bv, A, nullptr, h, w, GNR_XF(true, dyh(5)));
+    enc_backward<true>(A, enc_row, h, gx, gy, gz);
     mm3_h<NT_H, NT_H, INIT_ZERO, false, 0>(Bv, A, nullptr, h, w, XfNone());
     // L4^T..L1^T (dump dY_4 .. dY_1)
 #pragma unroll 1
@@ -157,16 +157,16 @@ __global__ __launch_bounds__(256, 1) void bwd3_chain_kernel(const BwdParams bp) 
         const int la = 4 - 2 * rep, lb = 3 - 2 * rep;        // inputs dY_4, dY_3 then dY_2, dY_1
         promote();
         load_relu_bits<NT_H>(mkn, bits(la - 1), lane);
-        mm3_h<NT_H, NT_H, INIT_ZERO, false, 2>(A, Bv, nullptr, h, w, GNR_XF(true, dyh(la)));
+        mm3_h<NT_H, NT_H, INIT_ZERO, false, 1>(A, Bv, nullptr, h, w, GNR_XF(true, dyh(la)));
         promote();
         load_relu_bits<NT_H>(mkn, bits(lb - 1 >= 0 ? lb - 1 : 0), lane);
-        mm3_h<NT_H, NT_H, INIT_ZERO, false, 2>(Bv, A, nullptr, h, w, GNR_XF(true, dyh(lb)));
+        mm3_h<NT_H, NT_H, INIT_ZERO, false, 1>(Bv, A, nullptr, h, w, GNR_XF(true, dyh(lb)));
     }
     promote();
     // L0: encoding columns from dY_0 (in A, masked by h0 > 0; dumps dY_0)
-    mm3_h<NT_H, 2, INIT_ZERO, false, 2>(A, Bv, nullptr, h, w, GNR_XF(true, dyh(0)));
+    mm3_h<NT_H, 2, INIT_ZERO, false, 1>(A, Bv, nullptr, h, w, GNR_XF(true, dyh(0)));
 #undef GNR_XF
-    enc_backward(Bv, enc_row, h, gx, gy, gz);
+    enc_backward<true>(Bv, enc_row, h, gx, gy, gz);
 
     // chunk partials for the geometry gradient: sum dpts, sum z * dpts
     const float z = bp.zval[row];

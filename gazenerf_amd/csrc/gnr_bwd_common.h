@@ -53,8 +53,12 @@ struct BwdParams {
 
 // d(encoding) held as a 2-tile C/D register file (lane-half h owns the slots it encoded) -> d(pts).
 // Embedder backward: d/dp sin(a p) = a cos(a p), d/dp cos(a p) = -a sin(a p).
+// QUAD: the saved encoding is in the channel-quad layout (enc_row = chunk base + 4 j), else
+// chunk-channel-major (enc_row = chunk base + j).
+template <bool QUAD = false>
 __device__ __forceinline__ void enc_backward(const f32x16 (&E)[NT_H], const float* __restrict__ enc_row, int h,
                                              float& gx, float& gy, float& gz) {
+    auto at = [&](int n) { return QUAD ? enc_row[(n >> 2) * 128 + (n & 3)] : enc_row[n * CHUNK]; };
     float d[ENC_STEPS];
 #pragma unroll
     for (int s = 0; s < ENC_STEPS; ++s) d[s] = E[s >> 4][s & 15];
@@ -67,7 +71,7 @@ __device__ __forceinline__ void enc_backward(const f32x16 (&E)[NT_H], const floa
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const int si = 2 + 6 * fl + a, ci = si + 3;
-            const float sv = enc_row[(2 * si + h) * CHUNK], cv = enc_row[(2 * ci + h) * CHUNK];
+            const float sv = at(2 * si + h), cv = at(2 * ci + h);
             acc3[a] = scale * (cv * d[si] - sv * d[ci]);
         }
         ax += acc3[0]; ay += acc3[1]; az += acc3[2];

@@ -66,6 +66,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // Timing experiments only (results are wrong with any bit set): build with -DGNR_ABLATE=<bits>.
 //   1 no LDS-DMA requests   2 no barriers   4 no activation conversion   8 no ring reads   16 no vmcnt waits
+//   32 no activation dumps (training forward)   64 vmcnt waits ignore the dump stores (as in inference)
 #ifndef GNR_ABLATE
 #define GNR_ABLATE 0
 #endif
@@ -182,7 +183,7 @@ __device__ __forceinline__ void ring_layer(WRing& w, PairFn pair, StoresFn store
     for (int ph = 0; ph < NP / 2; ++ph) {
         int allow = 2 * (DEPTH - 1);
 #pragma unroll
-        for (int d = 1; d < DEPTH; ++d) allow += (ph - d >= 0) ? stores(ph - d) : 0;
+        for (int d = 1; d < DEPTH; ++d) allow += (ph - d >= 0 && !(ABL & 64)) ? stores(ph - d) : 0;
         if (!(ABL & 16)) wait_vm_n(allow);
         if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
         ring_request(w);
@@ -200,29 +201,42 @@ struct BTile {
     u32x4 h[2], l[2];
 };
 
-// Transform applied to every pair of previous-layer values (registers r, r+1 of tile t) right before
-// the hi/lo split: activation / ReLU mask, sign-bit collection, dumps.  May modify a and b.
+// Transform applied to every quad of previous-layer values -- registers r..r+3 (r % 4 == 0) of tile t,
+// i.e. the four consecutive channels 32t + 8(r>>2) + 4h + 0..3 of this lane's sample -- right before the
+// hi/lo split: activation / ReLU mask, sign-bit collection, dumps.  May modify v.
 struct XfNone {
-    __device__ __forceinline__ void operator()(int, int, float&, float&) const {}
+    __device__ __forceinline__ void operator()(int, int, f32x4&) const {}
 };
 struct XfRelu {
-    __device__ __forceinline__ void operator()(int, int, float& a, float& b) const {
+    __device__ __forceinline__ void operator()(int, int, f32x4& v) const {
         // one v_med3_f32 each (fmaxf would add a canonicalising v_max in IEEE mode)
-        a = __builtin_amdgcn_fmed3f(a, 0.0f, __builtin_inff());
-        b = __builtin_amdgcn_fmed3f(b, 0.0f, __builtin_inff());
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], 0.0f, __builtin_inff());
     }
 };
 
+// Training dumps use the "channel-quad" layout: element (chunk c, channel n, sample j) of a C-channel
+// tensor at c*32*C + (n>>2)*128 + 4j + (n&3) floats, so that the quad a lane holds is ONE 16-byte store
+// and a wave's store covers 1 KiB contiguous.  (The vector-memory path accepts roughly one wave
+// instruction per ~20 cycles per CU whatever its width: dword stores of the same data -- the
+// chunk-channel-major layout of the fp32 kernels -- cost 4x the instructions and, measured, +40 % on
+// the training forward.)  quad_ptr: this lane's base; quad (t, r) lives at + (8t + (r>>2)*2) * 128.
+__device__ __forceinline__ float* quad_ptr(float* dst, int C, long chunk, int j, int h) {
+    return dst + chunk * (CHUNK * (long)C) + h * 128 + 4 * j;
+}
+__device__ __forceinline__ int quad_off(int t, int r) { return (8 * t + 2 * (r >> 2)) * 128; }
+
 template <bool WRITEBACK, class Xf>
-__device__ __forceinline__ void convert_pair(f32x16& src, int r, BTile& dst, int t, Xf& xf) {
-    float a = src[r], b = src[r + 1];
-    xf(t, r, a, b);
-    if (WRITEBACK) { src[r] = a; src[r + 1] = b; }
-    unsigned hi, lo;
-    split_pair(a, b, hi, lo);
+__device__ __forceinline__ void convert_quad(f32x16& src, int r, BTile& dst, int t, Xf& xf) {
+    f32x4 v = {src[r], src[r + 1], src[r + 2], src[r + 3]};
+    xf(t, r, v);
+    if (WRITEBACK) { src[r] = v.x; src[r + 1] = v.y; src[r + 2] = v.z; src[r + 3] = v.w; }
+    unsigned h0, l0, h1, l1;
+    split_pair(v.x, v.y, h0, l0);
+    split_pair(v.z, v.w, h1, l1);
     const int u = r >> 3, w = (r & 7) >> 1;
-    dst.h[u][w] = hi;
-    dst.l[u][w] = lo;
+    dst.h[u][w] = h0; dst.h[u][w + 1] = h1;
+    dst.l[u][w] = l0; dst.l[u][w + 1] = l1;
 }
 
 // accumulator tile nt starts from its bias: lane (j, h) register r <-> channel 32nt + (r&3) + 8(r>>2) + 4h
@@ -241,23 +255,23 @@ __device__ __forceinline__ void bias_init(f32x16& acc, const float* bias, int nt
 // reading the same input then uses XfNone).
 enum { INIT_NONE = 0, INIT_BIAS = 1, INIT_ZERO = 2 };
 
-// DUMPS = global stores xf issues per call (0, or 2 when it dumps both values).
+// DUMPS = global stores xf issues per call (0, or 1 when it dumps its quad).
 template <int NT_IN, int NT_OUT, int INIT, bool WRITEBACK, int DUMPS, class Xf>
 __device__ __forceinline__ void mm3_h(f32x16 (&prev)[NT_H], f32x16 (&acc)[NT_H], const float* out_bias, int h, WRing& w,
                                       Xf xf) {
     constexpr int PPT = NT_OUT;                 // row pairs per input tile (2 K-steps x NT_OUT rows / 2)
     constexpr int NP = NT_IN * PPT;
-    // conversions (xf calls) issued inside pair P: the next tile's 8 register pairs spread over 2 PPT slots
+    // conversions (xf calls) issued inside pair P: the next tile's 4 register quads spread over 2 PPT slots
     auto conv_in_pair = [](int P) {
         const int t = P / PPT, pt = P % PPT;
-        return t + 1 < NT_IN ? ((2 * pt + 2) * 8) / (2 * PPT) - ((2 * pt) * 8) / (2 * PPT) : 0;
+        return t + 1 < NT_IN ? ((2 * pt + 2) * 4) / (2 * PPT) - ((2 * pt) * 4) / (2 * PPT) : 0;
     };
     auto stores = [&](int ph) { return DUMPS * (conv_in_pair(2 * ph) + conv_in_pair(2 * ph + 1)); };
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     BTile cur, nxt;
     if (INIT == INIT_BIAS) { bias_init(acc[0], out_bias, 0, h); bias_init(acc[1 % NT_OUT], out_bias, 1 % NT_OUT, h); }
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) convert_pair<WRITEBACK>(prev[0], r, cur, 0, xf);
+    for (int r = 0; r < 16; r += 4) convert_quad<WRITEBACK>(prev[0], r, cur, 0, xf);
     ring_layer<NP>(w, [&](int P, const u32x4 (&g)[2][2]) {
         const int t = P / PPT, pt = P % PPT;
         const int i0 = 2 * pt, i1 = i0 + 1;
@@ -274,8 +288,8 @@ __device__ __forceinline__ void mm3_h(f32x16 (&prev)[NT_H], f32x16 (&acc)[NT_H],
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < NT_IN && !(ABL & 4)) {
 #pragma unroll
-            for (int pr = ((2 * pt) * 8) / (2 * PPT); pr < ((2 * pt + 1) * 8) / (2 * PPT); ++pr)
-                convert_pair<WRITEBACK>(prev[t + 1], 2 * pr, nxt, t + 1, xf);
+            for (int qd = ((2 * pt) * 4) / (2 * PPT); qd < ((2 * pt + 1) * 4) / (2 * PPT); ++qd)
+                convert_quad<WRITEBACK>(prev[t + 1], 4 * qd, nxt, t + 1, xf);
         }
         __builtin_amdgcn_sched_barrier(0);
         acc[n0] = mfma_bf(g[0][1], cur.h[u0], acc[n0]);
@@ -283,8 +297,8 @@ __device__ __forceinline__ void mm3_h(f32x16 (&prev)[NT_H], f32x16 (&acc)[NT_H],
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < NT_IN && !(ABL & 4)) {
 #pragma unroll
-            for (int pr = ((2 * pt + 1) * 8) / (2 * PPT); pr < ((2 * pt + 2) * 8) / (2 * PPT); ++pr)
-                convert_pair<WRITEBACK>(prev[t + 1], 2 * pr, nxt, t + 1, xf);
+            for (int qd = ((2 * pt + 1) * 4) / (2 * PPT); qd < ((2 * pt + 2) * 4) / (2 * PPT); ++qd)
+                convert_quad<WRITEBACK>(prev[t + 1], 4 * qd, nxt, t + 1, xf);
         }
         __builtin_amdgcn_sched_barrier(0);
         acc[n0] = mfma_bf(g[0][0], cur.l[u0], acc[n0]);

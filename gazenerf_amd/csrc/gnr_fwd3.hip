@@ -78,10 +78,11 @@ constexpr int BIAS_ROWS = N_CHAIN + 1;
 constexpr size_t FWD3_LDS_BYTES = RING_BYTES + (size_t)(ENC_STEPS * 256 + WAVES_PER_WG * BIAS_ROWS * H) * sizeof(float);
 static_assert(FWD3_LDS_BYTES <= 160 * 1024, "LDS budget");
 
-// SAVE (training forward): same dumps as fwd_kernel<true> -- every layer's post-activation output in the
-// chunk-channel-major layout, ReLU sign bits, sigma_raw, the encoding and the sample geometry -- so
-// either backward (gnr_bwd, gnr_bwd_bf16x3) can follow.  A layer's output is dumped by the transform of
-// the NEXT layer's mm3_h, i.e. spread over that layer's MFMA stream.
+// SAVE (training forward): the dumps of fwd_kernel<true> -- every layer's post-activation output, ReLU
+// sign bits, sigma_raw, the encoding and the sample geometry -- with the activations and the encoding in
+// the channel-quad layout (gnr_chain3.h) that gnr_bwd_bf16x3 expects; act_feat stays chunk-channel-major
+// for comp_bwd_kernel.  A layer's output is dumped by the transform of the NEXT layer's mm3_h, i.e.
+// spread over that layer's MFMA stream.
 template <bool SAVE>
 __global__ __launch_bounds__(256, 1) void fwd3_kernel(const FwdParams fp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -136,9 +137,10 @@ __global__ __launch_bounds__(256, 1) void fwd3_kernel(const FwdParams fp) {
                     enc_col[(T * 16 + 8 + u * 4 + wd) * 256] = lo;
                 }
         if (SAVE) {
+            // channel-quad layout, channel = encoding slot 2 s + h
 #pragma unroll
             for (int s = 0; s < ENC_STEPS; ++s)
-                fp.enc[chunk * (CHUNK * ENC_PAD) + (2 * s + h) * CHUNK + j] = e[s];
+                fp.enc[chunk * (CHUNK * ENC_PAD) + ((2 * s + h) >> 2) * 128 + 4 * j + ((2 * s + h) & 3)] = e[s];
             if (h == 0) {
                 fp.delta[row] = delta;
                 fp.zval[row] = z0;
@@ -168,31 +170,27 @@ __global__ __launch_bounds__(256, 1) void fwd3_kernel(const FwdParams fp) {
         // training forward: the transform of a layer input = activation + sign bits + dump of that input
         unsigned word = 0;
         auto xf_relu = [&](float* dst, int C, unsigned* bits) {
-            float* dp = SAVE ? dump_ptr(dst, C, chunk, j, h) : nullptr;
-            return [=, &word](int t, int rr, float& a, float& bb) {
+            float* qp = SAVE ? quad_ptr(dst, C, chunk, j, h) : nullptr;
+            return [=, &word](int t, int rr, f32x4& v) {
                 if (SAVE) {
-                    const bool pa = a > 0.0f, pb = bb > 0.0f;
-                    a = pa ? a : 0.0f;
-                    bb = pb ? bb : 0.0f;
-                    word = (word << 2) | (pa ? 2u : 0u) | (pb ? 1u : 0u);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool pos = v[e] > 0.0f;
+                        v[e] = pos ? v[e] : 0.0f;
+                        word = (word << 1) | (pos ? 1u : 0u);
+                    }
                     // 32 sign bits (tiles 2q, 2q+1) complete: first inserted = register 0 of the even tile
-                    if ((t & 1) && rr == 14) bits[(t >> 1) * 64 + lane] = __builtin_bitreverse32(word);
-                    const int ch = 32 * t + (rr & 3) + 8 * (rr >> 2);
-                    dp[ch * CHUNK] = a;
-                    dp[(ch + 1) * CHUNK] = bb;
+                    if ((t & 1) && rr == 12) bits[(t >> 1) * 64 + lane] = __builtin_bitreverse32(word);
+                    if (!(ABL & 32) && !((ABL & 128) && (t & 1))) *(f32x4*)(qp + quad_off(t, rr)) = v;
                 } else {
-                    XfRelu()(t, rr, a, bb);
+                    XfRelu()(t, rr, v);
                 }
             };
         };
         auto xf_lin = [&](float* dst, int C) {
-            float* dp = SAVE ? dump_ptr(dst, C, chunk, j, h) : nullptr;
-            return [=](int t, int rr, float& a, float& bb) {
-                if (SAVE) {
-                    const int ch = 32 * t + (rr & 3) + 8 * (rr >> 2);
-                    dp[ch * CHUNK] = a;
-                    dp[(ch + 1) * CHUNK] = bb;
-                }
+            float* qp = SAVE ? quad_ptr(dst, C, chunk, j, h) : nullptr;
+            return [=](int t, int rr, f32x4& v) {
+                if (SAVE && !(ABL & 32)) *(f32x4*)(qp + quad_off(t, rr)) = v;
             };
         };
         auto sb = [&](int layer) { return SAVE ? ws.relu_bits + relu_bits_offset(layer, fp.n_chunks, chunk) : nullptr; };
@@ -202,30 +200,32 @@ __global__ __launch_bounds__(256, 1) void fwd3_kernel(const FwdParams fp) {
 #pragma unroll 1
         for (int rep = 0; rep < 2; ++rep) {                                    // L1..L4
             const int la = 2 * rep + 1, lb = la + 1;
-            mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 2 : 0>(A, Bv, bl(la), h, w, xf_relu(ah(la - 1), H, sb(la - 1)));
-            mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 2 : 0>(Bv, A, bl(lb), h, w, xf_relu(ah(lb - 1), H, sb(lb - 1)));
+            mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 1 : 0>(A, Bv, bl(la), h, w, xf_relu(ah(la - 1), H, sb(la - 1)));
+            mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 1 : 0>(Bv, A, bl(lb), h, w, xf_relu(ah(lb - 1), H, sb(lb - 1)));
         }
         mm3_enc<NT_H>(enc_col, Bv, bl(5), h, w);                               // L5: encoding part, then h4 part
-        mm3_h<NT_H, NT_H, INIT_NONE, false, SAVE ? 2 : 0>(A, Bv, bl(5), h, w, xf_relu(ah(4), H, sb(4)));
-        mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 2 : 0>(Bv, A, bl(6), h, w, xf_relu(ah(5), H, sb(5)));      // L6
-        mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 2 : 0>(A, Bv, bl(7), h, w, xf_relu(ah(6), H, sb(6)));      // L7
+        mm3_h<NT_H, NT_H, INIT_NONE, false, SAVE ? 1 : 0>(A, Bv, bl(5), h, w, xf_relu(ah(4), H, sb(4)));
+        mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 1 : 0>(Bv, A, bl(6), h, w, xf_relu(ah(5), H, sb(5)));      // L6
+        mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 1 : 0>(A, Bv, bl(7), h, w, xf_relu(ah(6), H, sb(6)));      // L7
         // RGB0 consumes h7 = relu(Bv); the density head rides on the conversion (fp32 VALU dot)
         float sig = 0.0f;
         {
             const float* wsg = bias_lds + N_CHAIN * H + 4 * h;
             auto base = xf_relu(ah(7), H, sb(7));
-            mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 2 : 0>(Bv, A, bl(LR0), h, w, [&, base](int t, int rr, float& a, float& bb) {
-                base(t, rr, a, bb);
-                const int ch = 32 * t + (rr & 3) + 8 * (rr >> 2);
-                sig = fmaf(wsg[ch], a, sig);
-                sig = fmaf(wsg[ch + 1], bb, sig);
+            mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 1 : 0>(Bv, A, bl(LR0), h, w, [&, base](int t, int rr, f32x4& v) {
+                base(t, rr, v);
+                const f32x4 w4 = *(const f32x4*)(wsg + 32 * t + 8 * (rr >> 2));
+                sig = fmaf(w4.x, v.x, sig);
+                sig = fmaf(w4.y, v.y, sig);
+                sig = fmaf(w4.z, v.z, sig);
+                sig = fmaf(w4.w, v.w, sig);
             });
         }
         sig += __shfl_xor(sig, 32);
         sig += ws.wsig[H];
         if (SAVE && h == 0) ws.sigma_raw[row] = sig;
-        mm3_h<NT_H, NT_H2, INIT_BIAS, false, SAVE ? 2 : 0>(A, Bv, bl(LR1), h, w, xf_lin(SAVE ? ws.act_y0 : nullptr, H));
-        mm3_h<NT_H2, NT_F, INIT_BIAS, false, SAVE ? 2 : 0>(Bv, A, bl(LR2), h, w, xf_relu(SAVE ? ws.act_y1 : nullptr, H2, sb(8)));
+        mm3_h<NT_H, NT_H2, INIT_BIAS, false, SAVE ? 1 : 0>(A, Bv, bl(LR1), h, w, xf_lin(SAVE ? ws.act_y0 : nullptr, H));
+        mm3_h<NT_H2, NT_F, INIT_BIAS, false, SAVE ? 1 : 0>(Bv, A, bl(LR2), h, w, xf_relu(SAVE ? ws.act_y1 : nullptr, H2, sb(8)));
         if (SAVE) dump<NT_F>(A, ws.act_feat, FEAT_PAD, chunk, j, h);
         composite_chunk(A, sig, delta, z0, ws, chunk, row, lane, SAVE || fp.want_wl != 0);
     }

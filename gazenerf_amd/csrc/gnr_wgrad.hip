@@ -200,13 +200,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams wp) {
 // accumulate) while they are staged, so the LDS image is four bf16 planes per buffer
 // (A_hi, A_lo, B_hi, B_lo: [128 rows][32 samples] = 8 KiB each) and a chunk costs 24
 // v_mfma_f32_32x32x16_bf16 per wave (768 matrix-pipe cycles) instead of 64 fp32 MFMAs (4096).
-// Row = 64 bytes = 4 pieces of 8 samples; piece p of row n sits at piece p ^ ((n >> 2) & 3), which
-// keeps the 16 rows of every ds_read_b128 lane group on 16 different 16-byte slots.  A lane's
-// operand for K-step ks (16 samples) is piece 2*lh + ks of its row: lane-half lh contracts samples
+//
+// Operands arrive in the channel-quad layout of the bf16x3 chain kernels (gnr_chain3.h): element
+// (chunk, channel n, sample j) at (n>>2)*128 + 4j + (n&3).  The [128 channels][32 samples] tile of a
+// chunk is still one contiguous 16 KiB block; thread (g = tid/8, p = tid%8) loads the 64 contiguous
+// bytes of channel quad g, samples 4p..4p+3, re-reads its 4x4 register block channel by channel (the
+// transpose is free), splits pairs of consecutive samples and writes 8 bytes of hi and of lo per channel.
+//
+// LDS row = 64 bytes = 4 pieces of 8 samples; piece q of row n sits at piece q ^ ((n >> 2) & 3), which
+// keeps the 16 rows of every ds_read_b128 lane group on 16 different 16-byte slots.  A lane's operand
+// for K-step ks (16 samples) is piece 2*lh + ks of its row: lane-half lh contracts samples
 // 16 lh .. 16 lh + 15 of the chunk, the same free choice of order as in the fp32 kernel.
 // The bias / density-head riders are taken from the fp32 values in the staging registers.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int swz3(int n, int p) { return n * 32 + ((p ^ ((n >> 2) & 3)) << 3); }   // in bf16 elements
+__device__ __forceinline__ int swz3(int n, int q) { return n * 32 + ((q ^ ((n >> 2) & 3)) << 3); }   // in bf16 elements
 
 template <bool VEC>
 __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const WgradParams wp) {
@@ -228,67 +235,53 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const WgradParams wp) {
     const long cmax = (long)(b + 1) * wp.chunks_per_image;
     if (c1 > cmax) c1 = cmax;
 
-    // staging: thread owns pieces (row r0 = tid/4, piece pc = tid%4) and (row r0 + 64, pc) of both operands
-    const int r0 = tid >> 2, pc = tid & 3;
-    const float* ga[2];
-    const float* gb[2];
-    int lpos[2];
+    // staging: thread owns channel quad g (tile rows 4g..4g+3), samples 4p..4p+3 of both operands
+    // (quads clamped into the tensor: rows beyond it only feed outputs that are dropped)
+    const int g = tid >> 3, p = tid & 7;
+    int qa = tn * (WG_TN / 4) + g; if (qa >= wp.lda / 4) qa = wp.lda / 4 - 1;
+    int qb = tk * (WG_TK / 4) + g; if (qb >= wp.ldb / 4) qb = wp.ldb / 4 - 1;
+    const float* ga = wp.A + (long)qa * 128 + 16 * p;
+    const float* gb = wp.B + (long)qb * 128 + 16 * p;
+    int lpos[4];                                  // row 4g + e, samples 4p..4p+3: piece p>>1, half p&1
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int r = r0 + 64 * q;
-        int n = tn * WG_TN + r; if (n >= wp.lda) n = wp.lda - 1;
-        int k = tk * WG_TK + r; if (k >= wp.ldb) k = wp.ldb - 1;
-        ga[q] = wp.A + (long)n * CHUNK + 8 * pc;
-        gb[q] = wp.B + (long)k * CHUNK + 8 * pc;
-        lpos[q] = swz3(r, pc);
-    }
+    for (int e = 0; e < 4; ++e) lpos[e] = swz3(4 * g + e, p >> 1) + 4 * (p & 1);
     const long strideA = (long)CHUNK * wp.lda, strideB = (long)CHUNK * wp.ldb;
-    f32x4 ra[2][2], rb[2][2];
+    f32x4 ra[4], rb[4];                           // [sample 4p + s] = 4 channels
     auto gload = [&](long c) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            ra[q][0] = *(const f32x4*)(ga[q] + c * strideA);
-            ra[q][1] = *(const f32x4*)(ga[q] + c * strideA + 4);
-            rb[q][0] = *(const f32x4*)(gb[q] + c * strideB);
-            rb[q][1] = *(const f32x4*)(gb[q] + c * strideB + 4);
+        for (int s = 0; s < 4; ++s) {
+            ra[s] = *(const f32x4*)(ga + c * strideA + 4 * s);
+            rb[s] = *(const f32x4*)(gb + c * strideB + 4 * s);
         }
     };
-    float cs[2] = {0.0f, 0.0f}, vs[2] = {0.0f, 0.0f};
-    f32x4 vv[2];
-    auto split8 = [](const f32x4& lo4, const f32x4& hi4, u32x4& h, u32x4& l) {
-        unsigned hh[4], ll[4];
-        split_pair(lo4.x, lo4.y, hh[0], ll[0]);
-        split_pair(lo4.z, lo4.w, hh[1], ll[1]);
-        split_pair(hi4.x, hi4.y, hh[2], ll[2]);
-        split_pair(hi4.z, hi4.w, hh[3], ll[3]);
-        h = u32x4{hh[0], hh[1], hh[2], hh[3]};
-        l = u32x4{ll[0], ll[1], ll[2], ll[3]};
-    };
+    float cs[4] = {0.0f, 0.0f, 0.0f, 0.0f}, vs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 vv;                                     // vec[samples 4p..4p+3]
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            u32x4 h, l;
-            split8(ra[q][0], ra[q][1], h, l);
-            *(u32x4*)&lds[buf][0][lpos[q]] = h;
-            *(u32x4*)&lds[buf][1][lpos[q]] = l;
-            cs[q] += ((ra[q][0].x + ra[q][0].y) + (ra[q][0].z + ra[q][0].w)) + ((ra[q][1].x + ra[q][1].y) + (ra[q][1].z + ra[q][1].w));
-            split8(rb[q][0], rb[q][1], h, l);
-            *(u32x4*)&lds[buf][2][lpos[q]] = h;
-            *(u32x4*)&lds[buf][3][lpos[q]] = l;
+        for (int e = 0; e < 4; ++e) {
+            u32x2 h, l;
+            unsigned hh, ll;
+            split_pair(ra[0][e], ra[1][e], hh, ll); h.x = hh; l.x = ll;
+            split_pair(ra[2][e], ra[3][e], hh, ll); h.y = hh; l.y = ll;
+            *(u32x2*)&lds[buf][0][lpos[e]] = h;
+            *(u32x2*)&lds[buf][1][lpos[e]] = l;
+            cs[e] += (ra[0][e] + ra[1][e]) + (ra[2][e] + ra[3][e]);
+            split_pair(rb[0][e], rb[1][e], hh, ll); h.x = hh; l.x = ll;
+            split_pair(rb[2][e], rb[3][e], hh, ll); h.y = hh; l.y = ll;
+            *(u32x2*)&lds[buf][2][lpos[e]] = h;
+            *(u32x2*)&lds[buf][3][lpos[e]] = l;
             if (VEC) {
-                float d = vv[0].x * rb[q][0].x;
-                d = fmaf(vv[0].y, rb[q][0].y, d); d = fmaf(vv[0].z, rb[q][0].z, d); d = fmaf(vv[0].w, rb[q][0].w, d);
-                d = fmaf(vv[1].x, rb[q][1].x, d); d = fmaf(vv[1].y, rb[q][1].y, d);
-                d = fmaf(vv[1].z, rb[q][1].z, d); d = fmaf(vv[1].w, rb[q][1].w, d);
-                vs[q] += d;
+                float d = vv.x * rb[0][e];
+                d = fmaf(vv.y, rb[1][e], d);
+                d = fmaf(vv.z, rb[2][e], d);
+                d = fmaf(vv.w, rb[3][e], d);
+                vs[e] += d;
             }
         }
     };
     auto vload = [&](long c) {
-        if (VEC) {
-            vv[0] = *(const f32x4*)(wp.vec + c * CHUNK + 8 * pc);
-            vv[1] = *(const f32x4*)(wp.vec + c * CHUNK + 8 * pc + 4);
-        }
+        if (VEC) vv = *(const f32x4*)(wp.vec + c * CHUNK + 4 * p);
     };
 
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -349,18 +342,20 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const WgradParams wp) {
                 const int jx = wk * 64 + y * 32 + li;
                 pt[i * WG_TK + jx] = acc[x][y][r];
             }
-    // riders: the four threads tid%4 = 0..3 of a row hold its four 8-sample pieces
+    // riders: the eight threads p = 0..7 of a quad hold its eight 4-sample pieces
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        float t = cs[q];
+    for (int e = 0; e < 4; ++e) {
+        float t = cs[e];
         t += __shfl_xor(t, 1);
         t += __shfl_xor(t, 2);
-        if (tk == 0 && pc == 0) wp.colsum_part[(long)split * (wp.tiles_n * WG_TN) + tn * WG_TN + r0 + 64 * q] = t;
+        t += __shfl_xor(t, 4);
+        if (tk == 0 && p == 0) wp.colsum_part[(long)split * (wp.tiles_n * WG_TN) + tn * WG_TN + 4 * g + e] = t;
         if (VEC) {
-            float u = vs[q];
+            float u = vs[e];
             u += __shfl_xor(u, 1);
             u += __shfl_xor(u, 2);
-            if (tn == 0 && pc == 0) wp.vec_part[(long)split * (wp.tiles_k * WG_TK) + tk * WG_TK + r0 + 64 * q] = u;
+            u += __shfl_xor(u, 4);
+            if (tn == 0 && p == 0) wp.vec_part[(long)split * (wp.tiles_k * WG_TK) + tk * WG_TK + 4 * g + e] = u;
         }
     }
 }

@@ -136,8 +136,9 @@ int gnr_fwd(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes,
 
 /* gnr_fwd / gnr_bwd with the dense layers on bf16 MFMA through a 3-term split (x = hi + lo;
  * a*b ~ a_hi*b_hi + a_lo*b_hi + a_hi*b_lo, fp32 accumulate): ~16 mantissa bits per operand at 5.3x the
- * fp32-MFMA rate.  Same arguments, workspaces and outputs as gnr_fwd / gnr_bwd (the saved workspace has
- * the same layout, so either backward may follow either forward).  Forward results agree with gnr_fwd to
+ * fp32-MFMA rate.  Same arguments, workspace sizes and outputs as gnr_fwd / gnr_bwd, but the saved
+ * activations use a different internal layout: gnr_bwd_bf16x3 must follow gnr_fwd_bf16x3 (and gnr_bwd
+ * must follow gnr_fwd) on the same saved workspace.  Forward results agree with gnr_fwd to
  * that path's own rounding noise (feature map <= ~6e-6, bg_alpha <= ~3e-5 on the reference fixtures:
  * inside the 1e-4 contract); gradients stay inside the reference's own fp32-vs-fp64 noise on every
  * tensor.  The weight-gradient GEMMs (dW = dY^T X) use the same split; bias, latent-code,

@@ -14,7 +14,11 @@ to = lambda d: {k: v.to(dev) for k, v in d.items()}
 fw, ew = to(synth.hash_mlp_params("face", seed=0, density_scale=50.0)), to(synth.hash_mlp_params("eyes", seed=0, density_scale=50.0))
 p = to(synth.synth_problem(128, batch=1, seed=5))
 timer = KernelTimer(); ms = []
-with torch.no_grad():
+SAVE = os.environ.get("GNR_ABL_SAVE", "0") == "1"
+if SAVE:
+    for d in (fw, ew):
+        for v in d.values(): v.requires_grad_(True)
+with torch.set_grad_enabled(SAVE):
     for i in range(6):
         with timer:
             render.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"], p["appea_code"], fw, ew, n_samples=64, precision="bf16x3")
