@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256, 1) void bwd3_chain_kernel(const BwdParams bp) 
         if (MASK) {                                                                               \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = keep(mk[t >> 1], t, rr + e, v[e]); \
         }                                                                                         \
-        *(f32x4*)(dp + quad_off(t, rr)) = v;                                                      \
+        dump_store((f32x4*)(dp + quad_off(t, rr)), v);                                            \
     }
     auto promote = [&]() {
 #pragma unroll
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, 1) void bwd3_chain_kernel(const BwdParams bp) 
             const f32x4 w4 = *(const f32x4*)(wsg + 32 * t + 8 * (rr >> 2));
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = keep(mk[t >> 1], t, rr + e, fmaf(w4[e], ds, v[e]));
-            *(f32x4*)(dp + quad_off(t, rr)) = v;
+            dump_store((f32x4*)(dp + quad_off(t, rr)), v);
         });
     }
     promote();

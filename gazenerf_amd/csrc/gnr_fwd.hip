@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel(const FwdParams fp) {
             // CCM [chunk][64][32] in our k-order: channel slot 2*step + h
 #pragma unroll
             for (int s = 0; s < ENC_STEPS; ++s)
-                fp.enc[chunk * (CHUNK * ENC_PAD) + (2 * s + h) * CHUNK + j] = e[s];
+                dump_store(fp.enc + chunk * (CHUNK * ENC_PAD) + (2 * s + h) * CHUNK + j, e[s]);
             if (h == 0) {
                 fp.delta[row] = delta;
                 fp.zval[row] = z0;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel(const FwdParams fp) {
                 unsigned* dst = sb(layer);
 #pragma unroll
                 for (int q = 0; q < RELU_WORDS; ++q)
-                    if (q < words) dst[q * 64 + lane] = mkw[q];
+                    if (q < words) dump_store(dst + q * 64 + lane, mkw[q]);
             }
         };
 

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, 1) void fwd3_kernel(const FwdParams fp) {
             // channel-quad layout, channel = encoding slot 2 s + h
 #pragma unroll
             for (int s = 0; s < ENC_STEPS; ++s)
-                fp.enc[chunk * (CHUNK * ENC_PAD) + ((2 * s + h) >> 2) * 128 + 4 * j + ((2 * s + h) & 3)] = e[s];
+                dump_store(fp.enc + chunk * (CHUNK * ENC_PAD) + ((2 * s + h) >> 2) * 128 + 4 * j + ((2 * s + h) & 3), e[s]);
             if (h == 0) {
                 fp.delta[row] = delta;
                 fp.zval[row] = z0;
@@ -180,8 +180,8 @@ __global__ __launch_bounds__(256, 1) void fwd3_kernel(const FwdParams fp) {
                         word = (word << 1) | (pos ? 1u : 0u);
                     }
                     // 32 sign bits (tiles 2q, 2q+1) complete: first inserted = register 0 of the even tile
-                    if ((t & 1) && rr == 12) bits[(t >> 1) * 64 + lane] = __builtin_bitreverse32(word);
-                    if (!(ABL & 32) && !((ABL & 128) && (t & 1))) *(f32x4*)(qp + quad_off(t, rr)) = v;
+                    if ((t & 1) && rr == 12) dump_store(bits + (t >> 1) * 64 + lane, __builtin_bitreverse32(word));
+                    if (!(ABL & 32) && !((ABL & 128) && (t & 1))) dump_store((f32x4*)(qp + quad_off(t, rr)), v);
                 } else {
                     XfRelu()(t, rr, v);
                 }
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void fwd3_kernel(const FwdParams fp) {
         auto xf_lin = [&](float* dst, int C) {
             float* qp = SAVE ? quad_ptr(dst, C, chunk, j, h) : nullptr;
             return [=](int t, int rr, f32x4& v) {
-                if (SAVE && !(ABL & 32)) *(f32x4*)(qp + quad_off(t, rr)) = v;
+                if (SAVE && !(ABL & 32)) dump_store((f32x4*)(qp + quad_off(t, rr)), v);
             };
         };
         auto sb = [&](int layer) { return SAVE ? ws.relu_bits + relu_bits_offset(layer, fp.n_chunks, chunk) : nullptr; };
