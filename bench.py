@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--precision", choices=("fp32", "bf16x3"), default=os.environ.get("GNR_BENCH_PRECISION", "fp32"),
                     help="fp32: exact fp32 MFMA everywhere; bf16x3: forward + dgrad chain on bf16 MFMA with a "
                          "3-term hi/lo split (fp32 accumulate)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16x3 leg of an fp32 run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=512)
     return ap.parse_args()
@@ -151,12 +152,12 @@ def main():
     aux_timer = KernelTimer(aux=True)
     kernel_ms, aux_ms = [], []
 
-    def step(timed):
+    def step(timed, precision):
         if args.mode == "fwd":
             with torch.no_grad():
                 with timer:
                     render.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"],
-                                             p["appea_code"], face, eyes, n_samples=n_p, precision=args.precision)
+                                             p["appea_code"], face, eyes, n_samples=n_p, precision=precision)
                 if timed:
                     kernel_ms.append(timer.elapsed_ms())
             return
@@ -168,7 +169,7 @@ def main():
             with timer:
                 out = render.render_two_stream(xy, p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"],
                                                p["appea_code"], face, eyes, n_samples=n_p,
-                                               t_rand=t_rand[:, :xy.shape[2]], precision=args.precision)
+                                               t_rand=t_rand[:, :xy.shape[2]], precision=precision)
             if timed:
                 kernel_ms.append(timer.elapsed_ms())
             loss = sum((out["feat_" + t] ** 2).mean() + out["bg_alpha_" + t].mean() for t in ("face", "eyes"))
@@ -178,24 +179,36 @@ def main():
                 aux_ms.append(aux_timer.elapsed_ms())
         reducer.all_reduce()
 
-    for _ in range(args.warmup):
-        step(False)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def timed_run(precision):
+        """W untimed + K timed steps, barrier + synchronize on both sides, max over ranks (seconds)."""
+        del kernel_ms[:], aux_ms[:]
+        for _ in range(args.warmup):
+            step(False, precision)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(True, precision)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, list(kernel_ms), list(aux_ms)
+
+    dt, kernel_ms_main, aux_ms_main = timed_run(args.precision)
+    alt = None
+    if args.precision == "fp32" and not args.no_alt:
+        # second, separately timed leg: the same workload on the bf16x3 kernels (reported beside the
+        # headline, never as it)
+        alt = timed_run("bf16x3")
+    kernel_ms, aux_ms = kernel_ms_main, aux_ms_main
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -256,6 +269,22 @@ def main():
             res["roofline_hbm"] = {"bound": "hbm", "kernel": "gnr::comp_bwd_kernel", "achieved": gbs, "peak": 8000.0,
                                    "unit": "GB/s", "frac": gbs / 8000.0, "bytes_per_launch": nbytes,
                                    "avg_launch_ms": a, "launches_timed": len(aux_ms), "traffic": None}
+        if alt is not None:
+            adt, akm, _ = alt
+            a_avg = sum(akm) / max(1, len(akm))
+            a_ach = flop_per_launch / (a_avg * 1e-3) / 1e12 if a_avg > 0 else 0.0
+            res["bf16x3"] = {
+                "note": "same workload, same timing protocol, dense layers (forward, dgrad chain, weight-gradient "
+                        "GEMMs) on bf16 MFMA with a 3-term hi/lo split, fp32 accumulate; feature map within "
+                        "1e-4 of the reference (measured <= 6e-6), gradients inside the reference's own "
+                        "fp32-vs-fp64 noise (tests/test_parity_gpu.py, DESIGN.md)",
+                "value": world * n_rays * args.steps / adt, "unit": "rays/s", "ms_per_step": adt / args.steps * 1e3,
+                "speedup_vs_fp32": dt / adt,
+                "roofline": {"bound": "mfma", "kernel": "gnr::fwd3_kernel<%s>" % ("true" if args.mode == "fwdbwd" else "false"),
+                             "achieved": a_ach, "peak": PEAK_BF16X3_TFLOPS, "unit": "TFLOP/s",
+                             "peak_basis": "dense bf16 MFMA peak (16 x 157.3) / 3 terms; fp32-equivalent FLOPs",
+                             "frac": a_ach / PEAK_BF16X3_TFLOPS, "frac_of_fp32_mfma_peak": a_ach / PEAK_FP32_MFMA_TFLOPS,
+                             "avg_launch_ms": a_avg, "launches_timed": len(akm)}}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.mode, args.cpu_rays, n_p)
         print(json.dumps(res), flush=True)

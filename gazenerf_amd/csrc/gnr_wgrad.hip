@@ -213,7 +213,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams wp) {
 // 16 lh .. 16 lh + 15 of the chunk, the same free choice of order as in the fp32 kernel.
 // The bias / density-head riders are taken from the fp32 values in the staging registers.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int swz3(int n, int q) { return n * 32 + ((q ^ ((n >> 2) & 3)) << 3); }   // in bf16 elements
+// Rows are additionally swapped in pairs for odd channel quads (n ^ ((n>>2)&1)): the 16 lanes of a
+// ds_write_b64 group cover two quads x one channel, and the swap puts those two 64-byte rows in different
+// halves of the 128-byte bank window (first version: 33 % of all LDS cycles were bank conflicts, PMC).
+__device__ __forceinline__ int swz3(int n, int q) {   // in bf16 elements
+    return (n ^ ((n >> 2) & 1)) * 32 + ((q ^ ((n >> 2) & 3)) << 3);
+}
 
 template <bool VEC>
 __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const WgradParams wp) {
@@ -379,9 +384,20 @@ __global__ void wgrad_reduce_kernel(const WgradReduceParams rp) {
         for (long e = gid; e < total; e += gsz) {
             const int n = (int)(e / rp.k_valid), k = (int)(e % rp.k_valid);
             const int tn = n / WG_TN, i = n % WG_TN, tk = k / WG_TK, j = k % WG_TK;
+            // fixed summation order (deterministic); 8 loads in flight per thread instead of a
+            // load -> add dependency chain over ~112 splits
             float acc = 0.0f;
-            for (int sp = 0; sp < rp.splits; ++sp)
-                acc += rp.partial[(((long)sp * rp.tiles_n + tn) * rp.tiles_k + tk) * (long)(WG_TN * WG_TK) + i * WG_TK + j];
+            const float* src = rp.partial + ((long)tn * rp.tiles_k + tk) * (long)(WG_TN * WG_TK) + i * WG_TK + j;
+            const long sstride = (long)rp.tiles_n * rp.tiles_k * (WG_TN * WG_TK);
+            int sp = 0;
+            for (; sp + 8 <= rp.splits; sp += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + (sp + u) * sstride);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+            for (; sp < rp.splits; ++sp) acc += src[sp * sstride];
             int col = k;
             if (rp.enc_map) {
                 col = enc_channel(k >> 1, k & 1);
