@@ -3,6 +3,7 @@
 Public surface:
     render_two_stream, importance_resample, sample_zvals   (gazenerf_amd.render)
     merge_featmaps                                         (gazenerf_amd.merge)
+    neural_render, NeuralRendererAMD                       (gazenerf_amd.upsample)
     HotPathRenderer, MLPParams                             (gazenerf_amd.module)
     synth                                                  synthetic input recipe
     build.build()                                          compile libgnr.so for gfx950
@@ -10,4 +11,5 @@ Public surface:
 from . import synth  # noqa: F401
 from .render import importance_resample, render_two_stream, sample_zvals  # noqa: F401
 from .merge import merge_featmaps  # noqa: F401
+from .upsample import NeuralRendererAMD, neural_render  # noqa: F401
 from .module import HotPathRenderer, MLPParams  # noqa: F401

@@ -51,13 +51,32 @@ class GnrMergeProblem(C.Structure):
                 ("bg_featmap", _p), ("gaze", _p)]
 
 
+UP_MAX = 4
+UP_WS_FWD, UP_WS_BWD = 0, 1
+
+
+class GnrUpsampleProblem(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("feat_nc", C.c_int32), ("featmap_size", C.c_int32),
+                ("n_blocks", C.c_int32), ("min_feat", C.c_int32), ("final_sigmoid", C.c_int32), ("x", _p)]
+
+
+class GnrUpsampleWeights(C.Structure):
+    _fields_ = [("up1_w", _p * UP_MAX), ("up1_b", _p * UP_MAX), ("up2_w", _p * UP_MAX), ("up2_b", _p * UP_MAX),
+                ("feat_w", _p * UP_MAX), ("feat_b", _p * UP_MAX),
+                ("rgb_w", _p * (UP_MAX + 1)), ("rgb_b", _p * (UP_MAX + 1))]
+
+
+GnrUpsampleWeightGrads = GnrUpsampleWeights      # identical layout (include/gnr.h)
+
+
 class GnrInputGrads(C.Structure):
     _fields_ = [("R", _p), ("T", _p), ("shape_code", _p), ("gaze", _p), ("appea_code", _p)]
 
 
 EXPORTS = ("gnr_abi_version", "gnr_workspace_bytes", "gnr_fwd", "gnr_fwd_bf16x3", "gnr_bwd", "gnr_bwd_bf16x3", "gnr_resample",
            "gnr_sample_zvals", "gnr_set_kernel_timing", "gnr_set_aux_timing", "gnr_merge_scratch_bytes",
-           "gnr_merge_fwd", "gnr_merge_bwd", "gnr_last_error")
+           "gnr_merge_fwd", "gnr_merge_bwd", "gnr_upsample_workspace_bytes", "gnr_upsample_fwd", "gnr_upsample_bwd",
+           "gnr_last_error")
 
 _lib = None
 
@@ -102,6 +121,13 @@ def load():
     lib.gnr_merge_scratch_bytes.argtypes = [C.POINTER(GnrMergeProblem)]
     lib.gnr_merge_fwd.restype = C.c_int
     lib.gnr_merge_fwd.argtypes = [C.POINTER(GnrMergeProblem), _p, _p, _p, _p]
+    lib.gnr_upsample_workspace_bytes.restype = C.c_size_t
+    lib.gnr_upsample_workspace_bytes.argtypes = [C.POINTER(GnrUpsampleProblem), C.c_int]
+    lib.gnr_upsample_fwd.restype = C.c_int
+    lib.gnr_upsample_fwd.argtypes = [C.POINTER(GnrUpsampleProblem), C.POINTER(GnrUpsampleWeights), _p, _p, C.c_size_t, _p]
+    lib.gnr_upsample_bwd.restype = C.c_int
+    lib.gnr_upsample_bwd.argtypes = [C.POINTER(GnrUpsampleProblem), C.POINTER(GnrUpsampleWeights), _p, _p,
+                                     C.POINTER(GnrUpsampleWeightGrads), _p, C.c_size_t, _p, C.c_size_t, _p]
     lib.gnr_merge_bwd.restype = C.c_int
     lib.gnr_merge_bwd.argtypes = [C.POINTER(GnrMergeProblem)] + [_p] * 10 + [C.c_size_t, _p]
     lib.gnr_set_aux_timing.restype = C.c_int

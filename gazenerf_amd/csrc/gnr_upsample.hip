@@ -1,0 +1,629 @@
+// gnr_upsample.hip -- the 2-D upsampler after the volumetric hot path, gfx950.
+//
+// Replaces NeuralRenderer.forward (models/neural_renderer.py:100-113) with PixelShuffleUpsample
+// (models/pixel_shuffle_upsample.py:33-42) and Blur (:7-16), forward and backward:
+//
+//   rgb = up(conv_rgb0(x));  net = x
+//   block i:  a1 = lrelu(W1 net + b1);  a2 = lrelu(W2 a1 + b2)
+//             u  = pixel_shuffle(a2 + repeat(net, 4), 2);  v = blur(u)
+//             net = lrelu(Wf v + bf);  rgb = rgb + conv_rgb(i+1)(net);  if not last: rgb = up(rgb)
+//   img = sigmoid(rgb);   up = blur o bilinear-x2 (align_corners=False);  blur = reflect-padded [1,2,1]^2/16
+//
+// All tensors are the reference's channels-first fp32 images [B][C][H*W].  The 1x1 convolutions are GEMMs
+// over pixels (C[M][N] = A[M][K] B[K][N], N = pixels contiguous): conv_gemm_kernel, fp32 MFMA
+// (v_mfma_f32_32x32x2_f32, exact fp32), 128x128 tile per 256-thread workgroup through a k-major LDS image
+// (every operand read is a conflict-free ds_read_b32), epilogues fused: bias + LeakyReLU, the
+// residual-repeat + pixel_shuffle store of the PixelShuffleUpsample tail (with the sign byte the backward
+// needs), LeakyReLU-derivative masks and accumulation for the dgrad GEMMs (A = W^T by strides).
+// Weight gradients re-use wgrad_kernel (gnr_wgrad.hip) on the image layout; the 3-channel RGB branch and the
+// stencils (blur, bilinear, their adjoints) are one-thread-per-pixel HBM-bound kernels.
+// Work per 64x64 -> 512x512 image: 19.6 GFLOP forward (9.8 GMAC), ~0.6 GB of activation traffic.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/gnr.h"
+#include "gnr_device.h"
+
+namespace gnr {
+int fail(const char* fmt, ...);
+size_t wgrad_scratch_floats();
+void launch_wgrad_img(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, int batch,
+                      long pixels_per_image, float* dW, int ldw, float* colsum_out, int colsum_ld, float* scratch,
+                      hipStream_t stream);
+
+constexpr float LEAK = 0.2f;
+constexpr int UP_MAX = GNR_UPSAMPLE_MAX_BLOCKS;
+
+// ---------------------------------------------------------------------------------------------
+// C[M][N] = epilogue(A[M][K] B[K][N])
+// ---------------------------------------------------------------------------------------------
+struct GemmParams {
+    const float* A; long a_rs, a_cs;               // A(m,k) = A[m*a_rs + k*a_cs]
+    const float* B; long b_batch;                  // B(b,k,n) = B[b*b_batch + k*N + n]
+    float* C; long c_batch;                        // C(b,m,n) = C[b*c_batch + m*N + n]   (plain store)
+    int M, K, N;                                   // N % 128 == 0
+    const float* bias;                             // [M] or NULL
+    int leaky;                                     // LeakyReLU(0.2) on (acc + bias)
+    const float* mask_ref; long mask_batch;        // result *= (mask_ref(b,m,n) > 0 ? 1 : 0.2)
+    int accumulate;                                // C += result
+    int shuffle, W;                                // PixelShuffleUpsample tail: n = y*W + x
+    const float* res; long res_batch;              // residual res(b, m % (M/4), n)
+    unsigned char* sign_out; long sign_batch;      // (acc + bias > 0) per (b,m,n)
+};
+
+constexpr int GT = 128, GK = 16;
+
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams gp) {
+    __shared__ __attribute__((aligned(16))) float As[2][GK][GT], Bs[2][GK][GT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * GT, m0 = blockIdx.y * GT, b = blockIdx.z;
+    const float* Bb = gp.B + (long)b * gp.b_batch;
+    // staging roles
+    const int am = tid & 127, akq = tid >> 7;              // A: row am, k = akq*8 + e
+    const int bk = tid >> 5, bn4 = tid & 31;               // B: rows bk and bk+8, float4 column bn4
+    float ra[8];
+    f32x4 rb[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + akq * 8 + e, m = m0 + am;
+            ra[e] = (m < gp.M && k < gp.K) ? gp.A[(long)m * gp.a_rs + (long)k * gp.a_cs] : 0.0f;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int k = k0 + bk + 8 * e;
+            rb[e] = k < gp.K ? *(const f32x4*)(Bb + (long)k * gp.N + n0 + 4 * bn4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) As[buf][akq * 8 + e][am] = ra[e];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) *(f32x4*)&Bs[buf][bk + 8 * e][4 * bn4] = rb[e];
+    };
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 acc[2][2] = {{zero, zero}, {zero, zero}};
+    const int nk = (gp.K + GK - 1) / GK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * GK);
+#pragma unroll
+        for (int s = 0; s < GK / 2; ++s) {
+            const int k = 2 * s + lh;
+            const float a0 = As[buf][k][64 * wm + li], a1 = As[buf][k][64 * wm + 32 + li];
+            const float b0 = Bs[buf][k][64 * wn + li], b1 = Bs[buf][k][64 * wn + 32 + li];
+            acc[0][0] = mfma32(a0, b0, acc[0][0]);
+            acc[0][1] = mfma32(a0, b1, acc[0][1]);
+            acc[1][0] = mfma32(a1, b0, acc[1][0]);
+            acc[1][1] = mfma32(a1, b1, acc[1][1]);
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    const int Cq = gp.M / 4;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 64 * wm + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int n = n0 + 64 * wn + 32 * y + li;
+                if (m >= gp.M) continue;
+                float v = acc[x][y][r];
+                if (gp.bias) v += gp.bias[m];
+                if (gp.sign_out) gp.sign_out[(long)b * gp.sign_batch + (long)m * gp.N + n] = v > 0.0f ? 1 : 0;
+                if (gp.leaky) v = v > 0.0f ? v : LEAK * v;
+                if (gp.mask_ref) v *= gp.mask_ref[(long)b * gp.mask_batch + (long)m * gp.N + n] > 0.0f ? 1.0f : LEAK;
+                if (gp.shuffle) {
+                    // x.repeat(1,4,1,1) + pixel_shuffle(2): in-channel m = 4c + 2i + j -> out (c, 2y+i, 2x+j)
+                    v += gp.res[(long)b * gp.res_batch + (long)(m % Cq) * gp.N + n];
+                    const int c = m >> 2, i = (m >> 1) & 1, j = m & 1;
+                    const int py = n / gp.W, px = n - py * gp.W;
+                    gp.C[(long)b * gp.c_batch + (long)c * (4L * gp.N) + (long)(2 * py + i) * (2 * gp.W) + 2 * px + j] = v;
+                } else {
+                    float* dst = gp.C + (long)b * gp.c_batch + (long)m * gp.N + n;
+                    *dst = gp.accumulate ? *dst + v : v;
+                }
+            }
+}
+
+static void launch_gemm(const GemmParams& gp, int batch, hipStream_t st) {
+    hipLaunchKernelGGL(conv_gemm_kernel, dim3(gp.N / GT, (gp.M + GT - 1) / GT, batch), dim3(256), 0, st, gp);
+}
+
+// ---------------------------------------------------------------------------------------------
+// stencils: out(plane, y, x) over planes = B*C images of H x W
+// ---------------------------------------------------------------------------------------------
+// Blur taps (reflect padding == kornia filter2d border_type='reflect'): forward row y reads y-1, y, y+1 with the
+// out-of-range neighbour reflected onto the inner one; the adjoint gathers with the transposed weights.
+__device__ __forceinline__ void blur_taps(int u, int n, bool adjoint, float& wl, float& wc, float& wr) {
+    wc = 0.5f;
+    if (!adjoint) {
+        wl = u >= 1 ? 0.25f : 0.0f;
+        wr = u + 1 < n ? 0.25f : 0.0f;
+        if (u == 0) wr += 0.25f;          // in[-1] -> in[1]
+        if (u == n - 1) wl += 0.25f;      // in[n]  -> in[n-2]
+    } else {
+        wl = u >= 1 ? (u == 1 ? 0.5f : 0.25f) : 0.0f;
+        wr = u + 1 < n ? (u == n - 2 ? 0.5f : 0.25f) : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in, float* __restrict__ out, long planes,
+                                                   int H, int W, int adjoint) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = planes * H * W;
+    if (idx >= total) return;
+    const int x = (int)(idx % W), y = (int)((idx / W) % H);
+    const float* p = in + (idx - x - (long)y * W);
+    float xl, xc, xr, yl, yc, yr;
+    blur_taps(x, W, adjoint, xl, xc, xr);
+    blur_taps(y, H, adjoint, yl, yc, yr);
+    const int x0 = x >= 1 ? x - 1 : x, x2 = x + 1 < W ? x + 1 : x;
+    const int y0 = y >= 1 ? y - 1 : y, y2 = y + 1 < H ? y + 1 : y;
+    auto row = [&](int yy) { return xl * p[(long)yy * W + x0] + xc * p[(long)yy * W + x] + xr * p[(long)yy * W + x2]; };
+    out[idx] = yl * row(y0) + yc * row(y) + yr * row(y2);
+}
+
+// bilinear x2, align_corners=False: out[2m] = .25 in[m-1] + .75 in[m] (m = 0: in[0]); out[2m+1] = .75 in[m] + .25 in[m+1]
+__global__ __launch_bounds__(256) void bilinear2x_kernel(const float* __restrict__ in, float* __restrict__ out, long planes,
+                                                         int H, int W) {
+    const int H2 = 2 * H, W2 = 2 * W;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= planes * H2 * W2) return;
+    const int ox = (int)(idx % W2), oy = (int)((idx / W2) % H2);
+    const float* p = in + (idx / ((long)H2 * W2)) * ((long)H * W);
+    auto taps = [](int o, int n, int& i0, int& i1, float& w0, float& w1) {
+        const int m = o >> 1;
+        if (o & 1) { i0 = m; i1 = m + 1 < n ? m + 1 : m; w0 = 0.75f; w1 = 0.25f; }
+        else { i0 = m >= 1 ? m - 1 : 0; i1 = m; w0 = m >= 1 ? 0.25f : 0.0f; w1 = m >= 1 ? 0.75f : 1.0f; }
+    };
+    int x0, x1, y0, y1;
+    float wx0, wx1, wy0, wy1;
+    taps(ox, W, x0, x1, wx0, wx1);
+    taps(oy, H, y0, y1, wy0, wy1);
+    out[idx] = wy0 * (wx0 * p[(long)y0 * W + x0] + wx1 * p[(long)y0 * W + x1]) +
+               wy1 * (wx0 * p[(long)y1 * W + x0] + wx1 * p[(long)y1 * W + x1]);
+}
+
+// adjoint: din[m] = sum_o w(o,m) dout[o] with o in {2m-1, 2m, 2m+1, 2m+2}
+__global__ __launch_bounds__(256) void bilinear2x_adj_kernel(const float* __restrict__ dout, float* __restrict__ din,
+                                                             long planes, int H, int W) {
+    const int H2 = 2 * H, W2 = 2 * W;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= planes * H * W) return;
+    const int x = (int)(idx % W), y = (int)((idx / W) % H);
+    const float* p = dout + (idx / ((long)H * W)) * ((long)H2 * W2);
+    auto taps = [](int m, int n, int (&o)[4], float (&w)[4]) {
+        o[0] = 2 * m - 1; w[0] = m >= 1 ? 0.25f : 0.0f;                 // odd output of m-1 reads in[m]
+        o[1] = 2 * m;     w[1] = m >= 1 ? 0.75f : 1.0f;
+        o[2] = 2 * m + 1; w[2] = m + 1 < n ? 0.75f : 1.0f;
+        o[3] = 2 * m + 2; w[3] = m + 1 < n ? 0.25f : 0.0f;              // even output of m+1 reads in[m]
+        if (o[0] < 0) o[0] = 0;
+        if (o[3] > 2 * n - 1) o[3] = 2 * n - 1;
+    };
+    int ox[4], oy[4];
+    float wx[4], wy[4];
+    taps(x, W, ox, wx);
+    taps(y, H, oy, wy);
+    float acc = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        float r = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) r += wx[c] * p[(long)oy[a] * W2 + ox[c]];
+        acc += wy[a] * r;
+    }
+    din[idx] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the 3-channel RGB branch
+// ---------------------------------------------------------------------------------------------
+// rgb(b,o,p) = [rgb(b,o,p) +] sum_c W[o][c] net(b,c,p) + bias[o];  img = sigmoid(rgb) if wanted
+__global__ __launch_bounds__(256) void rgb_conv_kernel(const float* __restrict__ net, int C, long P, int batch,
+                                                       const float* __restrict__ w, const float* __restrict__ bias,
+                                                       float* __restrict__ rgb, int accumulate, float* __restrict__ img) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)batch * P) return;
+    const long b = idx / P, p = idx - b * P;
+    const float* np = net + b * C * P + p;
+    float a0 = bias[0], a1 = bias[1], a2 = bias[2];
+    for (int c = 0; c < C; ++c) {
+        const float v = np[(long)c * P];
+        a0 = fmaf(w[c], v, a0);
+        a1 = fmaf(w[C + c], v, a1);
+        a2 = fmaf(w[2 * C + c], v, a2);
+    }
+    float* rp = rgb + b * 3 * P + p;
+    if (accumulate) { a0 += rp[0]; a1 += rp[P]; a2 += rp[2 * P]; }
+    rp[0] = a0; rp[P] = a1; rp[2 * P] = a2;
+    if (img) {
+        float* ip = img + b * 3 * P + p;
+        ip[0] = 1.0f / (1.0f + expf(-a0)); ip[P] = 1.0f / (1.0f + expf(-a1)); ip[2 * P] = 1.0f / (1.0f + expf(-a2));
+    }
+}
+
+// dnet(b,c,p) = ([dnet(b,c,p)] + sum_o W[o][c] drgb(b,o,p)) * (net(b,c,p) > 0 ? 1 : 0.2)   [mask optional]
+__global__ __launch_bounds__(256) void rgb_conv_bwd_data_kernel(const float* __restrict__ drgb, int C, long P, int batch,
+                                                                const float* __restrict__ w, float* __restrict__ dnet,
+                                                                int accumulate, const float* __restrict__ act) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)batch * P) return;
+    const long b = idx / P, p = idx - b * P;
+    const float* gp = drgb + b * 3 * P + p;
+    const float g0 = gp[0], g1 = gp[P], g2 = gp[2 * P];
+    for (int c = 0; c < C; ++c) {
+        const long o = b * C * P + (long)c * P + p;
+        float v = w[c] * g0 + w[C + c] * g1 + w[2 * C + c] * g2;
+        if (accumulate) v += dnet[o];
+        if (act) v *= act[o] > 0.0f ? 1.0f : LEAK;
+        dnet[o] = v;
+    }
+}
+
+// dW[o][c] = sum_{b,p} drgb(b,o,p) net(b,c,p);  db[o] = sum drgb(b,o,p).  One block per c (c == C: bias), fixed order.
+__global__ __launch_bounds__(256) void rgb_conv_bwd_weight_kernel(const float* __restrict__ drgb, const float* __restrict__ net,
+                                                                  int C, long P, int batch, float* __restrict__ dw,
+                                                                  float* __restrict__ db) {
+    __shared__ float red[3][256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+    for (long i = tid; i < (long)batch * P; i += 256) {
+        const long b = i / P, p = i - b * P;
+        const float v = c < C ? net[b * C * P + (long)c * P + p] : 1.0f;
+        const float* gp = drgb + b * 3 * P + p;
+        a0 = fmaf(gp[0], v, a0); a1 = fmaf(gp[P], v, a1); a2 = fmaf(gp[2 * P], v, a2);
+    }
+    red[0][tid] = a0; red[1][tid] = a1; red[2][tid] = a2;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) { red[0][tid] += red[0][tid + s]; red[1][tid] += red[1][tid + s]; red[2][tid] += red[2][tid + s]; }
+        __syncthreads();
+    }
+    if (tid < 3) {
+        if (c < C) { if (dw) dw[tid * C + c] = red[tid][0]; }
+        else if (db) db[tid] = red[tid][0];
+    }
+}
+
+// d(rgb) = d(img) * img * (1 - img)
+__global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restrict__ dimg, const float* __restrict__ img,
+                                                          float* __restrict__ drgb, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) drgb[i] = dimg[i] * img[i] * (1.0f - img[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// PixelShuffleUpsample tail, backward: du [B][C][2H][2W] ->
+//   dpre2(b,k,p) = G(b,k,p) * (sign(b,k,p) ? 1 : 0.2),  G(b, 4c+2i+j, y*W+x) = du(b, c, 2y+i, 2x+j)      (k < 4C)
+//   dres(b,c,p)  = sum_{q<4} G(b, c + q C, p)                                                    (x.repeat adjoint)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void unshuffle_bwd_kernel(const float* __restrict__ du, const unsigned char* __restrict__ sign,
+                                                            int C, int H, int W, int batch, float* __restrict__ dpre2,
+                                                            float* __restrict__ dres) {
+    const long P = (long)H * W;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long n2 = (long)batch * 4 * C * P, n1 = (long)batch * C * P;
+    auto G = [&](long b, int k, long p) {
+        const int c = k >> 2, i = (k >> 1) & 1, j = k & 1;
+        const int y = (int)(p / W), x = (int)(p - (long)y * W);
+        return du[(b * C + c) * 4 * P + (long)(2 * y + i) * (2 * W) + 2 * x + j];
+    };
+    if (idx < n2) {
+        const long b = idx / (4L * C * P), rem = idx - b * 4L * C * P;
+        const int k = (int)(rem / P);
+        const long p = rem - (long)k * P;
+        dpre2[idx] = G(b, k, p) * (sign[idx] ? 1.0f : LEAK);
+    } else if (idx < n2 + n1) {
+        const long e = idx - n2;
+        const long b = e / ((long)C * P), rem = e - b * (long)C * P;
+        const int c = (int)(rem / P);
+        const long p = rem - (long)c * P;
+        dres[e] = (G(b, c, p) + G(b, c + C, p)) + (G(b, c + 2 * C, p) + G(b, c + 3 * C, p));
+    }
+}
+
+// out[n] = sum_b in[b][n]
+__global__ void sum_batch_kernel(const float* __restrict__ in, int batch, int n, int ld, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = 0.0f;
+    for (int b = 0; b < batch; ++b) a += in[(long)b * ld + i];
+    out[i] = a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct UpDims {
+    int n_blocks, ch[UP_MAX + 1], side[UP_MAX + 1];
+};
+
+static int up_dims(const GnrUpsampleProblem* p, UpDims* d) {
+    if (!p) return fail("gnr_upsample: problem is NULL");
+    if (p->batch < 1 || p->feat_nc < 1) return fail("gnr_upsample: batch and feat_nc must be >= 1");
+    if (p->n_blocks < 1 || p->n_blocks > UP_MAX) return fail("gnr_upsample: n_blocks must be 1..%d", UP_MAX);
+    if (p->featmap_size < 16 || (p->featmap_size & (p->featmap_size - 1)))
+        return fail("gnr_upsample: featmap_size must be a power of two >= 16 (got %d)", p->featmap_size);
+    if (p->min_feat < 1) return fail("gnr_upsample: min_feat must be >= 1");
+    if (!p->x) return fail("gnr_upsample: x is NULL");
+    d->n_blocks = p->n_blocks;
+    for (int i = 0; i <= p->n_blocks; ++i) {
+        const int c = p->feat_nc >> i;
+        d->ch[i] = c > p->min_feat ? c : p->min_feat;       // max(feat_nc // 2^i, min_feat), neural_renderer.py:60-97
+        d->side[i] = p->featmap_size << i;
+    }
+    return 0;
+}
+
+struct UpSaved {                        // kept for the backward
+    float* a1[UP_MAX];                  // [B][2C][P]
+    unsigned char* sign2[UP_MAX];       // [B][4C][P]
+    float* v[UP_MAX];                   // [B][C][4P]   blurred
+    float* net[UP_MAX];                 // [B][C'][4P]  block output
+    float* img;                         // [B][3][Pn]
+    float* u;                           // [B][C][4P]   scratch (largest block)
+    float* rgb_a; float* rgb_b;         // [B][3][Pn]   scratch
+};
+
+static size_t up_carve(const GnrUpsampleProblem* p, const UpDims& d, char* base, UpSaved* s) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* q = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return q; };
+    UpSaved z{};
+    size_t umax = 0;
+    const size_t B = (size_t)p->batch;
+    for (int i = 0; i < d.n_blocks; ++i) {
+        const size_t C = d.ch[i], Cn = d.ch[i + 1], P = (size_t)d.side[i] * d.side[i];
+        z.a1[i] = (float*)take(B * 2 * C * P * 4);
+        z.sign2[i] = (unsigned char*)take(B * 4 * C * P);
+        z.v[i] = (float*)take(B * C * 4 * P * 4);
+        z.net[i] = (float*)take(B * Cn * 4 * P * 4);
+        if (B * C * 4 * P * 4 > umax) umax = B * C * 4 * P * 4;
+    }
+    const size_t Pn = (size_t)d.side[d.n_blocks] * d.side[d.n_blocks];
+    z.img = (float*)take(B * 3 * Pn * 4);
+    z.u = (float*)take(umax);
+    z.rgb_a = (float*)take(B * 3 * Pn * 4);
+    z.rgb_b = (float*)take(B * 3 * Pn * 4);
+    if (s) *s = z;
+    return off;
+}
+
+struct UpScratch {                      // backward temporaries
+    float* g0; float* g1;               // two buffers of the largest activation size
+    float* drgb_a; float* drgb_b;       // [B][3][Pn]
+    float* colsum;                      // [B][max M]
+    float* wg;                          // wgrad partial tiles
+};
+
+static size_t up_carve_bwd(const GnrUpsampleProblem* p, const UpDims& d, char* base, UpScratch* s) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* q = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return q; };
+    size_t big = 0;
+    const size_t B = (size_t)p->batch;
+    int mmax = 0;
+    for (int i = 0; i < d.n_blocks; ++i) {
+        const size_t C = d.ch[i], P = (size_t)d.side[i] * d.side[i];
+        if (B * 4 * C * P * 4 > big) big = B * 4 * C * P * 4;       // dpre2 == du size
+        if (4 * d.ch[i] > mmax) mmax = 4 * d.ch[i];
+    }
+    const size_t Pn = (size_t)d.side[d.n_blocks] * d.side[d.n_blocks];
+    UpScratch z{};
+    z.g0 = (float*)take(big);
+    z.g1 = (float*)take(big);
+    z.drgb_a = (float*)take(B * 3 * Pn * 4);
+    z.drgb_b = (float*)take(B * 3 * Pn * 4);
+    z.colsum = (float*)take(B * (size_t)(mmax + 128) * 4);
+    z.wg = (float*)take(wgrad_scratch_floats() * 4);
+    if (s) *s = z;
+    return off;
+}
+
+static inline unsigned blocks_for(long n) { return (unsigned)((n + 255) / 256); }
+
+static int check_up_weights(const GnrUpsampleWeights* w, int n_blocks) {
+    if (!w) return fail("gnr_upsample: weights are NULL");
+    for (int i = 0; i < n_blocks; ++i)
+        if (!w->up1_w[i] || !w->up1_b[i] || !w->up2_w[i] || !w->up2_b[i] || !w->feat_w[i] || !w->feat_b[i])
+            return fail("gnr_upsample: a block-%d weight pointer is NULL", i);
+    for (int i = 0; i <= n_blocks; ++i)
+        if (!w->rgb_w[i] || !w->rgb_b[i]) return fail("gnr_upsample: feat_2_rgb_list.%d pointer is NULL", i);
+    return 0;
+}
+
+// rgb <- blur(bilinear2x(rgb_in)) for 3-channel images at side S -> 2S; tmp holds the bilinear result
+static void up_rgb(const float* in, float* tmp, float* out, int batch, int S, hipStream_t st) {
+    const long planes = (long)batch * 3;
+    hipLaunchKernelGGL(bilinear2x_kernel, dim3(blocks_for(planes * 4L * S * S)), dim3(256), 0, st, in, tmp, planes, S, S);
+    hipLaunchKernelGGL(blur_kernel, dim3(blocks_for(planes * 4L * S * S)), dim3(256), 0, st, tmp, out, planes, 2 * S, 2 * S, 0);
+}
+
+}  // namespace gnr
+
+using namespace gnr;
+
+extern "C" {
+
+size_t gnr_upsample_workspace_bytes(const GnrUpsampleProblem* p, int kind) {
+    UpDims d;
+    if (up_dims(p, &d)) return 0;
+    if (kind == GNR_UP_WS_FWD) return up_carve(p, d, nullptr, nullptr);
+    if (kind == GNR_UP_WS_BWD) return up_carve_bwd(p, d, nullptr, nullptr);
+    fail("gnr_upsample_workspace_bytes: unknown kind %d", kind);
+    return 0;
+}
+
+int gnr_upsample_fwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, float* img, void* workspace,
+                     size_t ws_bytes, void* stream) {
+    UpDims d;
+    if (up_dims(p, &d)) return 1;
+    if (check_up_weights(w, d.n_blocks)) return 1;
+    if (!img) return fail("gnr_upsample_fwd: output image is NULL");
+    const size_t need = up_carve(p, d, nullptr, nullptr);
+    if (!workspace || ws_bytes < need) return fail("gnr_upsample_fwd: workspace too small (%zu < %zu bytes)", ws_bytes, need);
+    if ((uintptr_t)workspace & 255) return fail("gnr_upsample_fwd: workspace must be 256-byte aligned");
+    UpSaved s;
+    up_carve(p, d, (char*)workspace, &s);
+    hipStream_t st = (hipStream_t)stream;
+    const int B = p->batch;
+
+    // rgb = up(conv_rgb0(x))
+    {
+        const long P = (long)d.side[0] * d.side[0];
+        hipLaunchKernelGGL(rgb_conv_kernel, dim3(blocks_for((long)B * P)), dim3(256), 0, st, p->x, d.ch[0], P, B, w->rgb_w[0],
+                           w->rgb_b[0], s.rgb_a, 0, (float*)nullptr);
+        up_rgb(s.rgb_a, s.rgb_b, s.rgb_a, B, d.side[0], st);          // in -> tmp -> out: in may be overwritten
+    }
+    const float* net = p->x;
+    float* rgb = s.rgb_a;
+    float* rgb_tmp = s.rgb_b;
+    for (int i = 0; i < d.n_blocks; ++i) {
+        const int C = d.ch[i], Cn = d.ch[i + 1], S = d.side[i];
+        const long P = (long)S * S;
+        GemmParams g{};
+        // a1 = lrelu(W1 net + b1)
+        g.A = w->up1_w[i]; g.a_rs = C; g.a_cs = 1; g.B = net; g.b_batch = (long)C * P; g.C = s.a1[i]; g.c_batch = 2L * C * P;
+        g.M = 2 * C; g.K = C; g.N = (int)P; g.bias = w->up1_b[i]; g.leaky = 1;
+        launch_gemm(g, B, st);
+        // u = pixel_shuffle(lrelu(W2 a1 + b2) + repeat(net))
+        g = GemmParams{};
+        g.A = w->up2_w[i]; g.a_rs = 2 * C; g.a_cs = 1; g.B = s.a1[i]; g.b_batch = 2L * C * P; g.C = s.u; g.c_batch = 4L * C * P;
+        g.M = 4 * C; g.K = 2 * C; g.N = (int)P; g.bias = w->up2_b[i]; g.leaky = 1; g.shuffle = 1; g.W = S;
+        g.res = net; g.res_batch = (long)C * P; g.sign_out = s.sign2[i]; g.sign_batch = 4L * C * P;
+        launch_gemm(g, B, st);
+        // v = blur(u)
+        hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * C * 4 * P)), dim3(256), 0, st, s.u, s.v[i], (long)B * C, 2 * S,
+                           2 * S, 0);
+        // net' = lrelu(Wf v + bf)
+        g = GemmParams{};
+        g.A = w->feat_w[i]; g.a_rs = C; g.a_cs = 1; g.B = s.v[i]; g.b_batch = 4L * C * P; g.C = s.net[i]; g.c_batch = 4L * Cn * P;
+        g.M = Cn; g.K = C; g.N = (int)(4 * P); g.bias = w->feat_b[i]; g.leaky = 1;
+        launch_gemm(g, B, st);
+        // rgb += conv_rgb(i+1)(net');  last block: img = sigmoid(rgb) (or rgb itself)
+        const bool last = i == d.n_blocks - 1;
+        hipLaunchKernelGGL(rgb_conv_kernel, dim3(blocks_for((long)B * 4 * P)), dim3(256), 0, st, s.net[i], Cn, 4 * P, B,
+                           w->rgb_w[i + 1], w->rgb_b[i + 1], rgb, 1, last && p->final_sigmoid ? s.img : (float*)nullptr);
+        if (!last) up_rgb(rgb, rgb_tmp, rgb, B, 2 * S, st);
+        net = s.net[i];
+    }
+    const size_t out_bytes = (size_t)B * 3 * d.side[d.n_blocks] * d.side[d.n_blocks] * 4;
+    (void)hipMemcpyAsync(img, p->final_sigmoid ? s.img : rgb, out_bytes, hipMemcpyDeviceToDevice, st);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("gnr_upsample_fwd: launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, const float* d_img, float* d_x,
+                     const GnrUpsampleWeightGrads* dw, void* saved, size_t saved_bytes, void* scratch,
+                     size_t scratch_bytes, void* stream) {
+    UpDims d;
+    if (up_dims(p, &d)) return 1;
+    if (check_up_weights(w, d.n_blocks)) return 1;
+    if (!d_img) return fail("gnr_upsample_bwd: d_img is NULL");
+    const size_t need_s = up_carve(p, d, nullptr, nullptr), need_t = up_carve_bwd(p, d, nullptr, nullptr);
+    if (!saved || saved_bytes < need_s) return fail("gnr_upsample_bwd: saved workspace too small (%zu < %zu bytes)", saved_bytes, need_s);
+    if (!scratch || scratch_bytes < need_t) return fail("gnr_upsample_bwd: scratch too small (%zu < %zu bytes)", scratch_bytes, need_t);
+    if (((uintptr_t)saved & 255) || ((uintptr_t)scratch & 255)) return fail("gnr_upsample_bwd: workspaces must be 256-byte aligned");
+    UpSaved s;
+    up_carve(p, d, (char*)saved, &s);
+    UpScratch t;
+    up_carve_bwd(p, d, (char*)scratch, &t);
+    GnrUpsampleWeightGrads G{};
+    if (dw) G = *dw;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = p->batch, nb = d.n_blocks;
+    const long Pn = (long)d.side[nb] * d.side[nb];
+
+    // d(rgb) at full resolution
+    float* drgb = t.drgb_a;
+    float* drgb_tmp = t.drgb_b;
+    if (p->final_sigmoid)
+        hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(blocks_for((long)B * 3 * Pn)), dim3(256), 0, st, d_img, s.img, drgb, (long)B * 3 * Pn);
+    else
+        (void)hipMemcpyAsync(drgb, d_img, (size_t)B * 3 * Pn * 4, hipMemcpyDeviceToDevice, st);
+
+    float* dnet_next = nullptr;       // gradient w.r.t. net' of block i coming from block i+1 (its input)
+    for (int i = nb - 1; i >= 0; --i) {
+        const int C = d.ch[i], Cn = d.ch[i + 1], S = d.side[i];
+        const long P = (long)S * S, P4 = 4 * P;
+        const float* net_in = i == 0 ? p->x : s.net[i - 1];
+        // the RGB branch at this resolution: rgb_i = up(rgb_{i-1}) + conv(net') ...; undo the up() that FOLLOWED block i
+        if (i < nb - 1) {
+            // drgb currently is at side 4S (block i+1's resolution): adjoint of blur o bilinear
+            hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * 3 * 16 * P)), dim3(256), 0, st, drgb, drgb_tmp, (long)B * 3, 4 * S,
+                               4 * S, 1);
+            hipLaunchKernelGGL(bilinear2x_adj_kernel, dim3(blocks_for((long)B * 3 * P4)), dim3(256), 0, st, drgb_tmp, drgb, (long)B * 3,
+                               2 * S, 2 * S);
+        }
+        // conv_rgb(i+1): weight/bias gradients, then dhid = (dnet' + Wr^T drgb) * lrelu'(net')
+        if (G.rgb_w[i + 1] || G.rgb_b[i + 1])
+            hipLaunchKernelGGL(rgb_conv_bwd_weight_kernel, dim3(Cn + 1), dim3(256), 0, st, drgb, s.net[i], Cn, P4, B, G.rgb_w[i + 1],
+                               G.rgb_b[i + 1]);
+        float* dhid = dnet_next ? dnet_next : t.g0;
+        hipLaunchKernelGGL(rgb_conv_bwd_data_kernel, dim3(blocks_for((long)B * P4)), dim3(256), 0, st, drgb, Cn, P4, B, w->rgb_w[i + 1],
+                           dhid, dnet_next ? 1 : 0, s.net[i]);
+        float* other = dhid == t.g0 ? t.g1 : t.g0;
+        // feat_layers[i]: dWf = dhid v^T, dbf; dv = Wf^T dhid
+        launch_wgrad_img(dhid, Cn, Cn, s.v[i], C, C, B, P4, G.feat_w[i], C, t.colsum, Cn + 128, t.wg, st);
+        if (G.feat_b[i]) hipLaunchKernelGGL(sum_batch_kernel, dim3((Cn + 63) / 64), dim3(64), 0, st, t.colsum, B, Cn, Cn + 128, G.feat_b[i]);
+        GemmParams g{};
+        g.A = w->feat_w[i]; g.a_rs = 1; g.a_cs = C; g.B = dhid; g.b_batch = (long)Cn * P4; g.C = other; g.c_batch = (long)C * P4;
+        g.M = C; g.K = Cn; g.N = (int)P4;
+        launch_gemm(g, B, st);                                           // other = dv
+        // du = blur^T dv  (into dhid's buffer)
+        hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * C * P4)), dim3(256), 0, st, other, dhid, (long)B * C, 2 * S, 2 * S, 1);
+        float* du = dhid;
+        // un-shuffle: dpre2 (-> other) and the residual part of d(net_in) (-> s.u, free in the backward)
+        float* dpre2 = other;
+        float* dnet = s.u;
+        hipLaunchKernelGGL(unshuffle_bwd_kernel, dim3(blocks_for((long)B * 5 * C * P)), dim3(256), 0, st, du, s.sign2[i], C, S, S, B, dpre2,
+                           dnet);
+        // layer_2: dW2 = dpre2 a1^T, db2; dpre1 = (W2^T dpre2) * lrelu'(a1)  (-> du's buffer)
+        launch_wgrad_img(dpre2, 4 * C, 4 * C, s.a1[i], 2 * C, 2 * C, B, P, G.up2_w[i], 2 * C, t.colsum, 4 * C + 128, t.wg, st);
+        if (G.up2_b[i]) hipLaunchKernelGGL(sum_batch_kernel, dim3((4 * C + 63) / 64), dim3(64), 0, st, t.colsum, B, 4 * C, 4 * C + 128, G.up2_b[i]);
+        float* dpre1 = du;
+        g = GemmParams{};
+        g.A = w->up2_w[i]; g.a_rs = 1; g.a_cs = 2 * C; g.B = dpre2; g.b_batch = 4L * C * P; g.C = dpre1; g.c_batch = 2L * C * P;
+        g.M = 2 * C; g.K = 4 * C; g.N = (int)P; g.mask_ref = s.a1[i]; g.mask_batch = 2L * C * P;
+        launch_gemm(g, B, st);
+        // layer_1: dW1 = dpre1 net_in^T, db1; dnet += W1^T dpre1
+        launch_wgrad_img(dpre1, 2 * C, 2 * C, net_in, C, C, B, P, G.up1_w[i], C, t.colsum, 2 * C + 128, t.wg, st);
+        if (G.up1_b[i]) hipLaunchKernelGGL(sum_batch_kernel, dim3((2 * C + 63) / 64), dim3(64), 0, st, t.colsum, B, 2 * C, 2 * C + 128, G.up1_b[i]);
+        g = GemmParams{};
+        g.A = w->up1_w[i]; g.a_rs = 1; g.a_cs = C; g.B = dpre1; g.b_batch = 2L * C * P; g.C = dnet; g.c_batch = (long)C * P;
+        g.M = C; g.K = 2 * C; g.N = (int)P; g.accumulate = 1;
+        launch_gemm(g, B, st);
+        // hand d(net_in) to block i-1 in a buffer that survives: g0/g1 are free again -> copy into the one not used next
+        if (i > 0) {
+            (void)hipMemcpyAsync(t.g0, dnet, (size_t)B * C * P * 4, hipMemcpyDeviceToDevice, st);
+            dnet_next = t.g0;
+        } else {
+            // block 0: + conv_rgb0 path below, then out
+            dnet_next = dnet;
+        }
+    }
+    // rgb_0 = up(conv_rgb0(x)): adjoint of up at side S0 -> 2 S0, then the conv
+    {
+        const int S = d.side[0];
+        const long P = (long)S * S;
+        hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * 3 * 4 * P)), dim3(256), 0, st, drgb, drgb_tmp, (long)B * 3, 2 * S, 2 * S, 1);
+        hipLaunchKernelGGL(bilinear2x_adj_kernel, dim3(blocks_for((long)B * 3 * P)), dim3(256), 0, st, drgb_tmp, drgb, (long)B * 3, S, S);
+        if (G.rgb_w[0] || G.rgb_b[0])
+            hipLaunchKernelGGL(rgb_conv_bwd_weight_kernel, dim3(d.ch[0] + 1), dim3(256), 0, st, drgb, p->x, d.ch[0], P, B, G.rgb_w[0], G.rgb_b[0]);
+        hipLaunchKernelGGL(rgb_conv_bwd_data_kernel, dim3(blocks_for((long)B * P)), dim3(256), 0, st, drgb, d.ch[0], P, B, w->rgb_w[0],
+                           dnet_next, 1, (const float*)nullptr);
+        if (d_x) (void)hipMemcpyAsync(d_x, dnet_next, (size_t)B * d.ch[0] * P * 4, hipMemcpyDeviceToDevice, st);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("gnr_upsample_bwd: launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+}  // extern "C"

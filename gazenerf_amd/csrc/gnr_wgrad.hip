@@ -42,6 +42,10 @@ struct WgradParams {
     float* colsum_part;           // [batch*spi][tiles_n*128]
     const float* vec;             // [M] or NULL
     float* vec_part;              // [batch*spi][tiles_k*128]
+    // operand addressing (floats): element (image b, local chunk lc, channel n, sample j) at
+    //   b*img + lc*chunk + n*row + j.  CCM dumps: row = 32, chunk = 32*ld, img = chunks_per_image*32*ld;
+    //   channels-first images [B][C][P]: row = P, chunk = 32, img = C*P.
+    long a_row, a_chunk, a_img, b_row, b_chunk, b_img;
 };
 
 // LDS position (in floats) of 16-byte piece `c` (0..7) of tile row `n` (0..127)
@@ -83,11 +87,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams wp) {
         const int f = tid + 256 * q, r = f >> 3, c = f & 7;
         int n = tn * WG_TN + r; if (n >= wp.lda) n = wp.lda - 1;
         int k = tk * WG_TK + r; if (k >= wp.ldb) k = wp.ldb - 1;
-        ga[q] = wp.A + (long)n * CHUNK + 4 * c;
-        gb[q] = wp.B + (long)k * CHUNK + 4 * c;
+        ga[q] = wp.A + (long)b * wp.a_img + (long)n * wp.a_row + 4 * c - (long)b * wp.chunks_per_image * wp.a_chunk;
+        gb[q] = wp.B + (long)b * wp.b_img + (long)k * wp.b_row + 4 * c - (long)b * wp.chunks_per_image * wp.b_chunk;
         lpos[q] = swz(r, c);
     }
-    const long strideA = (long)CHUNK * wp.lda, strideB = (long)CHUNK * wp.ldb;
+    const long strideA = wp.a_chunk, strideB = wp.b_chunk;
     f32x4 ra[4], rb[4];
     auto gload = [&](long c) {
 #pragma unroll
@@ -429,11 +433,19 @@ size_t wgrad_scratch_floats() {
 
 // dW[n_valid x k_valid] (+ col_off, optional encoding-slot map) = A^T B over all chunks.
 // Optional: colsum_out[b][n] = per-image column sums of A; vec_out[k] = vec^T B.
-void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, int batch,
-                  long chunks_per_image, float* dW, int ldw, int col_off, int enc_map, float* colsum_out,
-                  int colsum_ld, const float* vec, float* vec_out, float* scratch, hipStream_t stream, bool bf16x3) {
+static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, int batch,
+                              long chunks_per_image, float* dW, int ldw, int col_off, int enc_map, float* colsum_out,
+                              int colsum_ld, const float* vec, float* vec_out, float* scratch, hipStream_t stream,
+                              bool bf16x3, long pixels_per_image) {
     WgradParams wp{};
     wp.A = A; wp.B = B; wp.lda = lda; wp.ldb = ldb; wp.n_valid = n_valid; wp.k_valid = k_valid;
+    if (pixels_per_image > 0) {       // channels-first images [B][C][P]
+        wp.a_row = pixels_per_image; wp.a_chunk = CHUNK; wp.a_img = (long)lda * pixels_per_image;
+        wp.b_row = pixels_per_image; wp.b_chunk = CHUNK; wp.b_img = (long)ldb * pixels_per_image;
+    } else {                          // chunk-channel-major dumps
+        wp.a_row = CHUNK; wp.a_chunk = (long)CHUNK * lda; wp.a_img = chunks_per_image * wp.a_chunk;
+        wp.b_row = CHUNK; wp.b_chunk = (long)CHUNK * ldb; wp.b_img = chunks_per_image * wp.b_chunk;
+    }
     wp.tiles_n = (n_valid + WG_TN - 1) / WG_TN;
     wp.tiles_k = (k_valid + WG_TK - 1) / WG_TK;
     const int tiles = wp.tiles_n * wp.tiles_k;
@@ -472,6 +484,22 @@ void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb,
     rp.vec_part = vec_part; rp.vec_out = vec_out ? vec_out : nullptr;
     const long total = (long)n_valid * k_valid;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, rp);
+}
+
+void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, int batch,
+                  long chunks_per_image, float* dW, int ldw, int col_off, int enc_map, float* colsum_out,
+                  int colsum_ld, const float* vec, float* vec_out, float* scratch, hipStream_t stream, bool bf16x3) {
+    launch_wgrad_impl(A, lda, n_valid, B, ldb, k_valid, batch, chunks_per_image, dW, ldw, col_off, enc_map, colsum_out,
+                      colsum_ld, vec, vec_out, scratch, stream, bf16x3, 0);
+}
+
+// dW[n_valid x k_valid] = sum over images and pixels of A[b][n][p] * B[b][k][p] for channels-first fp32 images
+// ([B][lda][P] and [B][ldb][P], P % 32 == 0); colsum_out[b][n] = sum_p A[b][n][p].  Exact fp32 MFMA.
+void launch_wgrad_img(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, int batch,
+                      long pixels_per_image, float* dW, int ldw, float* colsum_out, int colsum_ld, float* scratch,
+                      hipStream_t stream) {
+    launch_wgrad_impl(A, lda, n_valid, B, ldb, k_valid, batch, pixels_per_image / CHUNK, dW, ldw, 0, 0, colsum_out,
+                      colsum_ld, nullptr, nullptr, scratch, stream, false, pixels_per_image);
 }
 
 // per-image sum of a per-sample vector: out[b] = sum_{s in image b} v[s]   (density bias gradient)

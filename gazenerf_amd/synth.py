@@ -156,6 +156,42 @@ def hash_mlp_params(stream: str, seed: int = 0, hidden: int = HIDDEN, vp_ch: int
     return out
 
 
+def renderer_param_shapes(feat_nc: int = FEAT_NC, n_blocks: int = 3, min_feat: int = 32, out_dim: int = 3):
+    """Parameter names/shapes of NeuralRenderer (models/neural_renderer.py:57-98) minus bg_featmap:
+    feat_upsample_list.{i}.layer_{1,2} (PixelShuffleUpsample, pixel_shuffle_upsample.py:25-29),
+    feat_2_rgb_list.{0..n}, feat_layers.{i}; all Conv2d 1x1."""
+    ch = [max(feat_nc // (2 ** i), min_feat) for i in range(n_blocks + 1)]
+    shapes = OrderedDict()
+    for i in range(n_blocks):
+        shapes["feat_upsample_list.%d.layer_1" % i] = (2 * ch[i], ch[i])
+        shapes["feat_upsample_list.%d.layer_2" % i] = (4 * ch[i], 2 * ch[i])
+    for i in range(n_blocks + 1):
+        shapes["feat_2_rgb_list.%d" % i] = (out_dim, ch[i])
+    for i in range(n_blocks):
+        shapes["feat_layers.%d" % i] = (ch[i + 1], ch[i])
+    return shapes
+
+
+def hash_renderer_params(seed: int = 0, feat_nc: int = FEAT_NC, n_blocks: int = 3, min_feat: int = 32,
+                         weight_scale: float = 1.0):
+    """NeuralRenderer parameters from PyTorch's Conv2d default init distribution
+    (U(+-1/sqrt(fan_in)) for weight and bias), as a counter-based hash like hash_mlp_params."""
+    out = OrderedDict()
+    for name, (cout, cin) in renderer_param_shapes(feat_nc, n_blocks, min_feat).items():
+        bound = 1.0 / math.sqrt(cin)
+        u = hash_uniform(cout * cin, _key("renderer." + name + ".weight", seed))
+        ub = hash_uniform(cout, _key("renderer." + name + ".bias", seed))
+        out[name + ".weight"] = torch.from_numpy(((2.0 * u - 1.0) * bound * weight_scale).astype(np.float32).reshape(cout, cin, 1, 1))
+        out[name + ".bias"] = torch.from_numpy(((2.0 * ub - 1.0) * bound).astype(np.float32))
+    return out
+
+
+def synth_featmap(batch: int, feat_nc: int, side: int, seed: int = 0):
+    """A feature map shaped like the renderer's input: U(-0.5, 1.5) per element."""
+    u = hash_uniform(batch * feat_nc * side * side, _key("featmap", seed))
+    return torch.from_numpy((2.0 * u - 0.5).astype(np.float32).reshape(batch, feat_nc, side, side))
+
+
 def synth_codes(batch: int, seed: int = 0):
     """shape_code ~ 0.5 N(0,1) [B,179], appea_code ~ 0.5 N(0,1) [B,127], gaze ~ U(-.5,.5) [B,2]."""
     n = SHAPE_DIMS + APPEA_DIMS

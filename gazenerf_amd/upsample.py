@@ -1,0 +1,167 @@
+"""The 2-D upsampler after the hot path: NeuralRenderer on MI355X.
+
+``neural_render`` replaces ``NeuralRenderer.forward`` (models/neural_renderer.py:100-113) including
+``PixelShuffleUpsample`` (models/pixel_shuffle_upsample.py:33-42) and ``Blur`` (:7-16) by the HIP kernels
+behind ``gnr_upsample_fwd`` / ``gnr_upsample_bwd``; ``NeuralRendererAMD`` is an ``nn.Module`` with the
+reference's parameter names and shapes (``feat_upsample_list.i.layer_{1,2}``, ``feat_2_rgb_list.i``,
+``feat_layers.i``, ``bg_featmap``) so ``check_dict["net"]`` entries under ``neural_render.*`` load into it.
+CUDA (ROCm) float32 tensors only; no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict
+
+import torch
+from torch import nn
+
+from . import _lib
+from .render import _check_tensor, _stream_ptr
+
+
+def renderer_param_names(n_blocks: int):
+    names = []
+    for i in range(n_blocks):
+        names += ["feat_upsample_list.%d.layer_1" % i, "feat_upsample_list.%d.layer_2" % i]
+    names += ["feat_2_rgb_list.%d" % i for i in range(n_blocks + 1)]
+    names += ["feat_layers.%d" % i for i in range(n_blocks)]
+    return [n + s for n in names for s in (".weight", ".bias")]
+
+
+def _channels(feat_nc, n_blocks, min_feat):
+    return [max(feat_nc // (2 ** i), min_feat) for i in range(n_blocks + 1)]
+
+
+def _weights_struct(params: Dict[str, torch.Tensor], n_blocks, cls=_lib.GnrUpsampleWeights):
+    w = cls()
+    get = lambda k: params[k].data_ptr() if params.get(k) is not None else None
+    for i in range(n_blocks):
+        w.up1_w[i], w.up1_b[i] = get("feat_upsample_list.%d.layer_1.weight" % i), get("feat_upsample_list.%d.layer_1.bias" % i)
+        w.up2_w[i], w.up2_b[i] = get("feat_upsample_list.%d.layer_2.weight" % i), get("feat_upsample_list.%d.layer_2.bias" % i)
+        w.feat_w[i], w.feat_b[i] = get("feat_layers.%d.weight" % i), get("feat_layers.%d.bias" % i)
+    for i in range(n_blocks + 1):
+        w.rgb_w[i], w.rgb_b[i] = get("feat_2_rgb_list.%d.weight" % i), get("feat_2_rgb_list.%d.bias" % i)
+    return w
+
+
+def _expected_shapes(feat_nc, n_blocks, min_feat):
+    ch = _channels(feat_nc, n_blocks, min_feat)
+    shp = {}
+    for i in range(n_blocks):
+        shp["feat_upsample_list.%d.layer_1" % i] = (2 * ch[i], ch[i])
+        shp["feat_upsample_list.%d.layer_2" % i] = (4 * ch[i], 2 * ch[i])
+        shp["feat_layers.%d" % i] = (ch[i + 1], ch[i])
+    for i in range(n_blocks + 1):
+        shp["feat_2_rgb_list.%d" % i] = (3, ch[i])
+    return shp
+
+
+class _UpsampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cfg, x, *flat):
+        lib = _lib.load()
+        n_blocks, min_feat, final = cfg["n_blocks"], cfg["min_feat"], cfg["final_actvn"]
+        names = renderer_param_names(n_blocks)
+        _check_tensor("x", x)
+        if x.dim() != 4 or x.shape[2] != x.shape[3]:
+            raise ValueError("x must be [B, C, S, S], got %s" % (tuple(x.shape),))
+        B, Cn, S, _ = x.shape
+        shapes = _expected_shapes(Cn, n_blocks, min_feat)
+        params = {}
+        for name, t in zip(names, flat):
+            _check_tensor(name, t)
+            base = name.rsplit(".", 1)[0]
+            want = shapes[base] if name.endswith(".weight") else (shapes[base][0],)
+            t2 = t.reshape(t.shape[0], -1) if name.endswith(".weight") else t
+            if tuple(t2.shape) != want:
+                raise ValueError("%s must have shape %s (+[1,1]), got %s" % (name, want, tuple(t.shape)))
+            params[name] = t2.contiguous()
+        xc = x.contiguous()
+        p = _lib.GnrUpsampleProblem()
+        p.batch, p.feat_nc, p.featmap_size, p.n_blocks, p.min_feat, p.final_sigmoid = B, Cn, S, n_blocks, min_feat, int(final)
+        p.x = xc.data_ptr()
+        dev = x.device
+        with torch.cuda.device(dev):
+            nbytes = lib.gnr_upsample_workspace_bytes(C.byref(p), _lib.UP_WS_FWD)
+            if nbytes == 0:
+                _lib.check(1, lib)
+            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+            img = torch.empty(B, 3, S << n_blocks, S << n_blocks, device=dev, dtype=torch.float32)
+            w = _weights_struct(params, n_blocks)
+            rc = lib.gnr_upsample_fwd(C.byref(p), C.byref(w), C.c_void_p(img.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(),
+                                      _stream_ptr(dev))
+            _lib.check(rc, lib)
+        need_grad = any(ctx.needs_input_grad[1:])
+        ctx.cfg, ctx.p, ctx.xc, ctx.params, ctx.names = cfg, p, xc, params, names
+        ctx.ws = ws if need_grad else None
+        ctx.flat_shapes = [t.shape for t in flat]
+        return img
+
+    @staticmethod
+    def backward(ctx, g_img):
+        lib = _lib.load()
+        if ctx.ws is None:
+            raise RuntimeError("neural_render: backward without a saved workspace")
+        p, params, names = ctx.p, ctx.params, ctx.names
+        n_blocks = ctx.cfg["n_blocks"]
+        dev = ctx.xc.device
+        g = g_img.contiguous()
+        dx = torch.empty_like(ctx.xc)
+        grads = {k: torch.empty_like(v) for k, v in params.items()}
+        with torch.cuda.device(dev):
+            nbytes = lib.gnr_upsample_workspace_bytes(C.byref(p), _lib.UP_WS_BWD)
+            scratch = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+            w = _weights_struct(params, n_blocks)
+            dw = _weights_struct(grads, n_blocks, _lib.GnrUpsampleWeightGrads)
+            rc = lib.gnr_upsample_bwd(C.byref(p), C.byref(w), C.c_void_p(g.data_ptr()), C.c_void_p(dx.data_ptr()), C.byref(dw),
+                                      C.c_void_p(ctx.ws.data_ptr()), ctx.ws.numel(), C.c_void_p(scratch.data_ptr()),
+                                      scratch.numel(), _stream_ptr(dev))
+            _lib.check(rc, lib)
+        ctx.ws = None
+        return (None, dx) + tuple(grads[n].reshape(s) for n, s in zip(names, ctx.flat_shapes))
+
+
+def neural_render(x, params: Dict[str, torch.Tensor], n_blocks: int = 3, min_feat: int = 32, final_actvn: bool = True):
+    """x [B, feat_nc, S, S] -> image [B, 3, S*2^n, S*2^n].  ``params``: the reference's NeuralRenderer state-dict
+    entries (weights [out,in,1,1] or [out,in]); gradients flow to x and to every parameter."""
+    names = renderer_param_names(n_blocks)
+    cfg = dict(n_blocks=int(n_blocks), min_feat=int(min_feat), final_actvn=bool(final_actvn))
+    return _UpsampleFn.apply(cfg, x, *[params[n] for n in names])
+
+
+class _PSU(nn.Module):
+    """Parameter holder named like PixelShuffleUpsample (pixel_shuffle_upsample.py:25-29)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.layer_1 = nn.Conv2d(c, 2 * c, 1, 1, padding=0)
+        self.layer_2 = nn.Conv2d(2 * c, 4 * c, 1, 1, padding=0)
+
+
+class NeuralRendererAMD(nn.Module):
+    """Drop-in for models/neural_renderer.py:NeuralRenderer (same constructor arguments, parameter names,
+    shapes and initialisation; ``forward`` runs on the HIP kernels)."""
+
+    def __init__(self, bg_type="white", feat_nc=258, out_dim=3, final_actvn=True, min_feat=32, featmap_size=64,
+                 img_size=512, **kwargs):
+        super().__init__()
+        if out_dim != 3:
+            raise ValueError("only out_dim = 3 (the reference's value, gaze_nerf.py:114) is supported")
+        if bg_type not in ("white", "black"):
+            raise ValueError("bg_type must be 'white' or 'black' (neural_renderer.py:37-52)")
+        self.n_feat, self.min_feat, self.final_actvn, self.featmap_size = feat_nc, min_feat, final_actvn, featmap_size
+        self.n_blocks = int(math.log2(img_size) - math.log2(featmap_size))
+        ch = _channels(feat_nc, self.n_blocks, min_feat)
+        self.feat_upsample_list = nn.ModuleList([_PSU(ch[i]) for i in range(self.n_blocks)])
+        self.feat_2_rgb_list = nn.ModuleList([nn.Conv2d(ch[i], 3, 1, 1, padding=0) for i in range(self.n_blocks + 1)])
+        self.feat_layers = nn.ModuleList([nn.Conv2d(ch[i], ch[i + 1], 1, 1, padding=0) for i in range(self.n_blocks)])
+        fill = torch.ones if bg_type == "white" else torch.zeros
+        self.bg_featmap = nn.Parameter(fill((1, feat_nc, featmap_size, featmap_size), dtype=torch.float32))
+
+    def get_bg_featmap(self):
+        return self.bg_featmap
+
+    def forward(self, x):
+        params = {k: v for k, v in self.named_parameters() if k != "bg_featmap"}
+        return neural_render(x, params, self.n_blocks, self.min_feat, self.final_actvn)

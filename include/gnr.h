@@ -206,6 +206,47 @@ int gnr_merge_bwd(const GnrMergeProblem* p, const float* g_merge_face, const flo
                   float* d_bg_alpha_eyes, float* d_bg_featmap, float* d_gaze,
                   void* scratch, size_t scratch_bytes, void* stream);
 
+/* ---- N1: the 2-D upsampler after the hot path ------------------------------------------
+ * NeuralRenderer.forward (models/neural_renderer.py:100-113) with PixelShuffleUpsample
+ * (models/pixel_shuffle_upsample.py:33-42) and Blur (:7-16; kornia filter2d, reflect border, normalised):
+ * [B, feat_nc, S, S] feature map -> [B, 3, S*2^n, S*2^n] image, n = log2(img_size / featmap_size).
+ * Channel schedule ch[i] = max(feat_nc >> i, min_feat) (neural_renderer.py:57-98).  Weights are the
+ * reference's Conv2d tensors ([out,in,1,1] == row-major [out,in]) under their state-dict names:
+ *   up1_* = feat_upsample_list.i.layer_1 [2c,c], up2_* = ...layer_2 [4c,2c], feat_* = feat_layers.i [c',c],
+ *   rgb_* = feat_2_rgb_list.i [3,c_i], i = 0..n.  bg_featmap is not an input of forward(). */
+#define GNR_UPSAMPLE_MAX_BLOCKS 4
+enum { GNR_UP_WS_FWD = 0, GNR_UP_WS_BWD = 1 };
+
+typedef struct GnrUpsampleProblem {
+    int32_t batch, feat_nc, featmap_size, n_blocks, min_feat;
+    int32_t final_sigmoid;          /* NeuralRenderer(final_actvn=True) in the reference (gaze_nerf.py:115) */
+    const float* x;                 /* [B, feat_nc, S, S]; S a power of two >= 16 */
+} GnrUpsampleProblem;
+
+typedef struct GnrUpsampleWeights {
+    const float* up1_w[GNR_UPSAMPLE_MAX_BLOCKS];  const float* up1_b[GNR_UPSAMPLE_MAX_BLOCKS];
+    const float* up2_w[GNR_UPSAMPLE_MAX_BLOCKS];  const float* up2_b[GNR_UPSAMPLE_MAX_BLOCKS];
+    const float* feat_w[GNR_UPSAMPLE_MAX_BLOCKS]; const float* feat_b[GNR_UPSAMPLE_MAX_BLOCKS];
+    const float* rgb_w[GNR_UPSAMPLE_MAX_BLOCKS + 1]; const float* rgb_b[GNR_UPSAMPLE_MAX_BLOCKS + 1];
+} GnrUpsampleWeights;
+
+typedef struct GnrUpsampleWeightGrads {     /* same shapes; NULL == not wanted; written, not accumulated */
+    float* up1_w[GNR_UPSAMPLE_MAX_BLOCKS];  float* up1_b[GNR_UPSAMPLE_MAX_BLOCKS];
+    float* up2_w[GNR_UPSAMPLE_MAX_BLOCKS];  float* up2_b[GNR_UPSAMPLE_MAX_BLOCKS];
+    float* feat_w[GNR_UPSAMPLE_MAX_BLOCKS]; float* feat_b[GNR_UPSAMPLE_MAX_BLOCKS];
+    float* rgb_w[GNR_UPSAMPLE_MAX_BLOCKS + 1]; float* rgb_b[GNR_UPSAMPLE_MAX_BLOCKS + 1];
+} GnrUpsampleWeightGrads;
+
+/* GNR_UP_WS_FWD: workspace of gnr_upsample_fwd (it keeps what the backward needs and must stay untouched
+ * until gnr_upsample_bwd); GNR_UP_WS_BWD: scratch of gnr_upsample_bwd.  0 + gnr_last_error() on bad input. */
+size_t gnr_upsample_workspace_bytes(const GnrUpsampleProblem* p, int kind);
+int gnr_upsample_fwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, float* img, void* workspace,
+                     size_t ws_bytes, void* stream);
+/* d_img [B,3,S*2^n,S*2^n] -> d_x [B,feat_nc,S,S] (NULL == not wanted) and the weight gradients. */
+int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, const float* d_img, float* d_x,
+                     const GnrUpsampleWeightGrads* dw, void* saved_workspace, size_t saved_bytes, void* scratch,
+                     size_t scratch_bytes, void* stream);
+
 const char* gnr_last_error(void);
 
 #ifdef __cplusplus

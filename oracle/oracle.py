@@ -223,6 +223,57 @@ def merge_featmaps(feat_face, bg_alpha_face, feat_eyes, bg_alpha_eyes, bg_featma
     return merge_face, eyes_planes, torch.maximum(merge_face, eyes_planes)             # :203
 
 
+# --------------------------------------------------------------------------- N1
+def kornia_filter2d(x, kernel, normalized=True):
+    """kornia.filters.filter2d of kornia 0.6.4 (requirements.txt:9; absent here, so restated from its
+    published source kornia/filters/filter.py -- Blur parity is UNPINNED by the reference):
+    kernel [1,kh,kw]; normalize_kernel2d divides by sum|k|; input padded with border_type='reflect' by
+    (kh//2, kw//2); depthwise cross-correlation."""
+    k = kernel.to(x)
+    if normalized:
+        k = k / k.abs().sum(dim=(-2, -1), keepdim=True)
+    c = x.shape[1]
+    kh, kw = k.shape[-2:]
+    xp = F.pad(x, (kw // 2, kw // 2, kh // 2, kh // 2), mode="reflect")
+    return F.conv2d(xp, k.reshape(1, 1, kh, kw).expand(c, 1, kh, kw), groups=c)
+
+
+def blur(x):
+    """models/pixel_shuffle_upsample.py:7-16: f = [1,2,1]; filter2d(x, f (x) f, normalized=True)."""
+    f = torch.tensor([1.0, 2.0, 1.0], dtype=x.dtype)
+    return kornia_filter2d(x, f[None, None, :] * f[None, :, None], normalized=True)
+
+
+def _conv(params, name, x):
+    return F.conv2d(x, params[name + ".weight"].to(x.dtype), params[name + ".bias"].to(x.dtype))
+
+
+def pixel_shuffle_upsample(params, prefix, x):
+    """models/pixel_shuffle_upsample.py:33-42."""
+    y = x.repeat(1, 4, 1, 1)
+    out = F.leaky_relu(_conv(params, prefix + ".layer_1", x), 0.2)
+    out = F.leaky_relu(_conv(params, prefix + ".layer_2", out), 0.2)
+    return blur(F.pixel_shuffle(out + y, 2))
+
+
+def rgb_upsample(x):
+    """models/neural_renderer.py:65-67: bilinear x2 (align_corners=False) then Blur."""
+    return blur(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False))
+
+
+def neural_renderer(params, x, n_blocks=3, final_actvn=True):
+    """NeuralRenderer.forward, models/neural_renderer.py:100-113."""
+    rgb = rgb_upsample(_conv(params, "feat_2_rgb_list.0", x))
+    net = x
+    for i in range(n_blocks):
+        hid = _conv(params, "feat_layers.%d" % i, pixel_shuffle_upsample(params, "feat_upsample_list.%d" % i, net))
+        net = F.leaky_relu(hid, 0.2)
+        rgb = rgb + _conv(params, "feat_2_rgb_list.%d" % (i + 1), net)
+        if i < n_blocks - 1:
+            rgb = rgb_upsample(rgb)
+    return torch.sigmoid(rgb) if final_actvn else rgb
+
+
 def synthetic_loss(out):
     """loss = sum_streams(mean(feat^2) + mean(bg_alpha))."""
     return sum((out["feat_" + t] ** 2).mean() + out["bg_alpha_" + t].mean() for t in ("face", "eyes"))

@@ -1,0 +1,163 @@
+"""NeuralRenderer + PixelShuffleUpsample + Blur.
+
+CPU: the oracle restatement reproduces the fixtures captured from the reference's own NeuralRenderer
+(oracle/gen_golden_n1.py; Blur through the kornia 0.6.4 restatement -- "unpinned", see its header).
+GPU: the HIP kernels behind gnr_upsample_fwd / gnr_upsample_bwd against the same fixtures and the live oracle.
+Tolerances: image 1e-4 max-abs (the north-star bound, applied to the sigmoid image); gradients rel-L2 1e-3
+(exact-fp32 MFMA GEMMs; only the summation order differs from the reference).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from gazenerf_amd import synth
+from oracle import oracle as O
+
+
+def _case(name):
+    g = load_golden(name)
+    cfg = {k[4:]: int(g[k]) for k in g if k.startswith("cfg_")}
+    n_blocks = int(g["n_blocks"])
+    params = synth.hash_renderer_params(seed=int(g["weight_seed"]), feat_nc=cfg["feat_nc"], n_blocks=n_blocks,
+                                        min_feat=cfg["min_feat"], weight_scale=float(g["weight_scale"]))
+    if "x" in g:
+        x = g["x"]
+    else:
+        x = synth.synth_featmap(1, cfg["feat_nc"], cfg["featmap_size"], seed=int(g["x_seed"]))
+    return g, cfg, n_blocks, params, x
+
+
+def _loss(img):
+    wgt = torch.linspace(0.5, 1.5, img.numel(), dtype=img.dtype, device=img.device).reshape(img.shape)
+    return ((img * wgt) ** 2).mean()
+
+
+def _subsample(name, t, full):
+    if not full:
+        return t
+    if name == "out_img":
+        return t[:, :, ::8, ::8]
+    if name == "grad_x":
+        return t[:, ::8, ::4, ::4]
+    t2 = t.reshape(t.shape[0], -1)
+    return t2[::16] if t2.numel() > 8192 else t2
+
+
+def _rel_l2(a, b):
+    a, b = a.double().cpu(), torch.as_tensor(b).double()
+    return float((a.reshape(b.shape) - b).norm() / max(float(b.norm()), 1e-30))
+
+
+@pytest.mark.parametrize("name", ["g8_upsampler_tiny", "g8_upsampler_full"])
+def test_oracle_vs_reference_fixture(name):
+    g, cfg, n_blocks, params, x = _case(name)
+    full = name.endswith("full")
+    if full:
+        torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    xg = x.clone().requires_grad_(True)
+    pg = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    img = O.neural_renderer(pg, xg, n_blocks)
+    assert float((_subsample("out_img", img.detach(), full) - g["out_img"]).abs().max()) <= 1e-6
+    _loss(img).backward()
+    assert _rel_l2(_subsample("grad_x", xg.grad, full), g["grad_x"]) <= 1e-5
+    for k, v in pg.items():
+        assert _rel_l2(_subsample(k, v.grad, full), g["gradw_" + k]) <= 1e-4, k
+
+
+def test_blur_matches_its_definition():
+    """reflect-padded [1,2,1] x [1,2,1] / 16 (kornia filter2d, border_type='reflect', normalized=True), written out
+    by hand on a small image, corners and edges included."""
+    x = torch.arange(30, dtype=torch.float64).reshape(1, 1, 5, 6) ** 1.5
+    got = O.blur(x)[0, 0]
+    k = [1.0, 2.0, 1.0]
+    refl = lambda i, n: -i if i < 0 else (2 * n - 2 - i if i >= n else i)
+    for y in range(5):
+        for xx in range(6):
+            acc = 0.0
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    acc += k[dy + 1] * k[dx + 1] * float(x[0, 0, refl(y + dy, 5), refl(xx + dx, 6)])
+            assert abs(acc / 16.0 - float(got[y, xx])) < 1e-9
+
+
+# ----------------------------------------------------------------------------- GPU
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _run_hip(x, params, n_blocks, min_feat, dev):
+    from gazenerf_amd import neural_render
+    xg = x.to(dev).clone().requires_grad_(True)
+    pg = {k: v.to(dev).clone().requires_grad_(True) for k, v in params.items()}
+    img = neural_render(xg, pg, n_blocks=n_blocks, min_feat=min_feat)
+    _loss(img).backward()
+    return img.detach(), xg.grad, {k: v.grad for k, v in pg.items()}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["g8_upsampler_tiny", "g8_upsampler_full"])
+def test_hip_vs_reference_fixture(name):
+    dev = _dev()
+    g, cfg, n_blocks, params, x = _case(name)
+    full = name.endswith("full")
+    img, dx, dp = _run_hip(x, params, n_blocks, cfg["min_feat"], dev)
+    assert float((_subsample("out_img", img.cpu(), full) - g["out_img"]).abs().max()) <= 1e-4
+    assert _rel_l2(_subsample("grad_x", dx.cpu(), full), g["grad_x"]) <= 1e-3
+    for k, v in dp.items():
+        assert _rel_l2(_subsample(k, v.cpu(), full), g["gradw_" + k]) <= 1e-3, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("feat_nc,side,img,min_feat,batch", [(20, 16, 128, 6, 2), (258, 32, 64, 32, 1), (7, 32, 256, 3, 3)])
+def test_hip_vs_oracle_live(feat_nc, side, img, min_feat, batch):
+    """Other shapes: 3 blocks from a 16x16 map, a single block, odd channel counts that are no multiple of 4."""
+    dev = _dev()
+    n_blocks = int(np.log2(img) - np.log2(side))
+    params = synth.hash_renderer_params(seed=9, feat_nc=feat_nc, n_blocks=n_blocks, min_feat=min_feat, weight_scale=2.0)
+    x = synth.synth_featmap(batch, feat_nc, side, seed=3)
+    xg = x.clone().requires_grad_(True)
+    pg = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = O.neural_renderer(pg, xg, n_blocks)
+    _loss(ref).backward()
+    got, dx, dp = _run_hip(x, params, n_blocks, min_feat, dev)
+    assert float((got.cpu() - ref.detach()).abs().max()) <= 1e-4
+    assert _rel_l2(dx.cpu(), xg.grad) <= 1e-3
+    for k in pg:
+        assert _rel_l2(dp[k].cpu(), pg[k].grad) <= 1e-3, k
+
+
+@pytest.mark.gpu
+def test_module_has_reference_state_dict_and_is_deterministic():
+    from gazenerf_amd import NeuralRendererAMD
+    dev = _dev()
+    torch.manual_seed(0)
+    net = NeuralRendererAMD(feat_nc=258, featmap_size=64, img_size=512).to(dev)
+    want = set(synth.renderer_param_shapes().keys())
+    have = {k.rsplit(".", 1)[0] for k in net.state_dict() if k != "bg_featmap"}
+    assert have == want and tuple(net.bg_featmap.shape) == (1, 258, 64, 64)
+    for name, (co, ci) in synth.renderer_param_shapes().items():
+        assert tuple(net.state_dict()[name + ".weight"].shape) == (co, ci, 1, 1)
+    x = synth.synth_featmap(1, 258, 64, seed=1).to(dev)
+    a = net(x)
+    a.square().mean().backward()
+    g1 = {k: v.grad.clone() for k, v in net.named_parameters() if v.grad is not None}
+    net.zero_grad()
+    b = net(x)
+    b.square().mean().backward()
+    assert torch.equal(a, b) and a.shape == (1, 3, 512, 512) and bool((a > 0).all()) and bool((a < 1).all())
+    for k, v in net.named_parameters():
+        if k != "bg_featmap":
+            assert torch.equal(v.grad, g1[k]), k
+
+
+@pytest.mark.gpu
+def test_bad_inputs_are_rejected():
+    from gazenerf_amd import _lib, neural_render
+    dev = _dev()
+    params = {k: v.to(dev) for k, v in synth.hash_renderer_params(feat_nc=12, n_blocks=1, min_feat=4).items()}
+    with pytest.raises(_lib.GnrError, match="featmap_size"):
+        neural_render(torch.zeros(1, 12, 8, 8, device=dev), params, n_blocks=1, min_feat=4)
+    with pytest.raises(ValueError):
+        neural_render(torch.zeros(1, 13, 16, 16, device=dev), params, n_blocks=1, min_feat=4)
