@@ -4,7 +4,8 @@ Public surface:
     render_two_stream, importance_resample, sample_zvals   (gazenerf_amd.render)
     merge_featmaps                                         (gazenerf_amd.merge)
     neural_render, NeuralRendererAMD                       (gazenerf_amd.upsample)
-    HotPathRenderer, MLPParams                             (gazenerf_amd.module)
+    HotPathRenderer, MLPParams, GazeNeRFNetAMD             (gazenerf_amd.module; the last one is the whole
+                                                           reference network: hot path -> merge -> upsampler x4)
     synth                                                  synthetic input recipe
     build.build()                                          compile libgnr.so for gfx950
 """
@@ -12,4 +13,4 @@ from . import synth  # noqa: F401
 from .render import importance_resample, render_two_stream, sample_zvals  # noqa: F401
 from .merge import merge_featmaps  # noqa: F401
 from .upsample import NeuralRendererAMD, neural_render  # noqa: F401
-from .module import HotPathRenderer, MLPParams  # noqa: F401
+from .module import GazeNeRFNetAMD, HotPathRenderer, MLPParams  # noqa: F401

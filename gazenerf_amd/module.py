@@ -67,8 +67,11 @@ class HotPathRenderer(nn.Module):
     def __init__(self, num_sample_coarse: int = 64, num_sample_fine: int = 128, world_z1: float = 2.5,
                  world_z2: float = -3.5, hidden: int = 384, featmap_nc: int = 258,
                  shape_dims: int = synth.SHAPE_DIMS, gaze_dims: int = synth.GAZE_DIMS,
-                 appea_dims: int = synth.APPEA_DIMS, hier_sampling: bool = False):
+                 appea_dims: int = synth.APPEA_DIMS, hier_sampling: bool = False, precision: str = "fp32"):
         super().__init__()
+        if precision not in ("fp32", "bf16x3"):
+            raise ValueError("precision must be 'fp32' or 'bf16x3'")
+        self.precision = precision
         self.num_sample_coarse, self.num_sample_fine = num_sample_coarse, num_sample_fine
         self.world_z1, self.world_z2 = world_z1, world_z2
         self.hidden, self.featmap_nc = hidden, featmap_nc
@@ -91,7 +94,7 @@ class HotPathRenderer(nn.Module):
             batch_xy, batch_Rmats, batch_Tvecs, batch_inv_inmats, shape_code, gaze_code, appea_code,
             self.fg_CD_predictor_face.param_list(), self.fg_CD_predictor_eyes.param_list(),
             n_samples=n_p, world_z1=self.world_z1, world_z2=self.world_z2, t_rand=t_rand,
-            return_weights=want_w, hidden=self.hidden, feat_nc=self.featmap_nc)
+            return_weights=want_w, hidden=self.hidden, feat_nc=self.featmap_nc, precision=self.precision)
         if self.hier_sampling:
             zv = R_.sample_zvals(batch_xy, batch_Rmats.detach(), batch_Tvecs.detach(), batch_inv_inmats,
                                  n_samples=n_p, world_z1=self.world_z1, world_z2=self.world_z2, t_rand=t_rand)
@@ -102,7 +105,41 @@ class HotPathRenderer(nn.Module):
                 batch_xy, batch_Rmats, batch_Tvecs, batch_inv_inmats, shape_code, gaze_code, appea_code,
                 self.fine_fg_CD_predictor.param_list(), None,
                 n_samples=n_p + self.num_sample_fine, world_z1=self.world_z1, world_z2=self.world_z2,
-                z_edges=edges, hidden=self.hidden, feat_nc=self.featmap_nc)
+                z_edges=edges, hidden=self.hidden, feat_nc=self.featmap_nc, precision=self.precision)
             out["feat_fine"], out["bg_alpha_fine"] = fine["feat_face"], fine["bg_alpha_face"]
             out["fine_edges"] = edges
         return out
+
+
+class GazeNeRFNetAMD(HotPathRenderer):
+    """The reference's ``GazeNeRFNet`` (models/gaze_nerf.py) end to end on MI355X: hot path (render op) ->
+    feature-map merge (gaze_nerf.py:164-203) -> ``NeuralRenderer`` x4 (:176,200,201,205).
+
+    Same submodule / parameter names as the reference (``fg_CD_predictor_{face,eyes}.*``,
+    ``neural_render.*`` including ``bg_featmap``), so ``load_state_dict(check_dict["net"])`` works strictly
+    for the default (non-hierarchical) configuration.  ``forward`` takes the reference's arguments
+    (gaze_nerf.py:318-331) plus ``t_rand`` to pin the train-mode jitter, and returns
+    ``{"coarse_dict": {"merge_img_face", "merge_img_eyes", "merge_img", "bg_img"}}`` like the reference."""
+
+    def __init__(self, featmap_size: int = 64, pred_img_size: int = 512, bg_type: str = "white", **kw):
+        super().__init__(**kw)
+        from .upsample import NeuralRendererAMD
+        self.featmap_size, self.pred_img_size = featmap_size, pred_img_size
+        self.neural_render = NeuralRendererAMD(bg_type=bg_type, feat_nc=self.featmap_nc, out_dim=3, final_actvn=True,
+                                               min_feat=32, featmap_size=featmap_size, img_size=pred_img_size)
+
+    def forward(self, mode, batch_xy, batch_uv, bg_code, shape_code, appea_code, gaze_code, batch_Rmats, batch_Tvecs,
+                batch_inv_inmats, dist_expr=False, t_rand: Optional[torch.Tensor] = None, **kwargs):
+        from .merge import merge_featmaps
+        assert mode in ("train", "test") and bg_code is None
+        out = HotPathRenderer.forward(self, batch_xy, batch_Rmats, batch_Tvecs, batch_inv_inmats, shape_code, appea_code,
+                                      gaze_code, for_train=(mode == "train"), t_rand=t_rand)
+        B, S, C = batch_xy.shape[0], self.featmap_size, self.featmap_nc
+        if batch_xy.shape[2] != S * S:
+            raise ValueError("batch_xy must cover the %dx%d feature map" % (S, S))
+        bg = self.neural_render.get_bg_featmap()
+        mf, ep, m = merge_featmaps(out["feat_face"], out["bg_alpha_face"], out["feat_eyes"], out["bg_alpha_eyes"],
+                                   bg.reshape(1, C, S * S), gaze_code.reshape(-1, 2))
+        img = lambda t: self.neural_render(t.reshape(-1, C, S, S))
+        res = {"merge_img_face": img(mf), "merge_img_eyes": img(ep), "merge_img": img(m), "bg_img": img(bg)}
+        return {"coarse_dict": res}

@@ -130,6 +130,15 @@ def neural_render(x, params: Dict[str, torch.Tensor], n_blocks: int = 3, min_fea
     return _UpsampleFn.apply(cfg, x, *[params[n] for n in names])
 
 
+class _BlurBuf(nn.Module):
+    """Holds Blur's registered buffer ``f = [1, 2, 1]`` (pixel_shuffle_upsample.py:8-11) so that the
+    reference's state-dict keys ``*.blur_layer.f`` / ``rgb_upsample.1.f`` exist here too (strict loading)."""
+
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("f", torch.tensor([1.0, 2.0, 1.0]))
+
+
 class _PSU(nn.Module):
     """Parameter holder named like PixelShuffleUpsample (pixel_shuffle_upsample.py:25-29)."""
 
@@ -137,6 +146,7 @@ class _PSU(nn.Module):
         super().__init__()
         self.layer_1 = nn.Conv2d(c, 2 * c, 1, 1, padding=0)
         self.layer_2 = nn.Conv2d(2 * c, 4 * c, 1, 1, padding=0)
+        self.blur_layer = _BlurBuf()
 
 
 class NeuralRendererAMD(nn.Module):
@@ -154,6 +164,7 @@ class NeuralRendererAMD(nn.Module):
         self.n_blocks = int(math.log2(img_size) - math.log2(featmap_size))
         ch = _channels(feat_nc, self.n_blocks, min_feat)
         self.feat_upsample_list = nn.ModuleList([_PSU(ch[i]) for i in range(self.n_blocks)])
+        self.rgb_upsample = nn.Sequential(nn.Identity(), _BlurBuf())      # key "rgb_upsample.1.f" (neural_renderer.py:65-67)
         self.feat_2_rgb_list = nn.ModuleList([nn.Conv2d(ch[i], 3, 1, 1, padding=0) for i in range(self.n_blocks + 1)])
         self.feat_layers = nn.ModuleList([nn.Conv2d(ch[i], ch[i + 1], 1, 1, padding=0) for i in range(self.n_blocks)])
         fill = torch.ones if bg_type == "white" else torch.zeros

@@ -17,7 +17,8 @@ def pytest_configure(config):
 
 def load_golden(name):
     z = np.load(os.path.join(GOLD, name + ".npz"))
-    return {k: (torch.from_numpy(z[k]) if z[k].ndim > 0 else z[k].item()) for k in z.files}
+    conv = lambda a: a.item() if a.ndim == 0 else (a if a.dtype.kind in "US" else torch.from_numpy(a))
+    return {k: conv(z[k]) for k in z.files}
 
 
 def golden_problem(g, device="cpu"):

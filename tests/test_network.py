@@ -1,0 +1,96 @@
+"""The whole reference network (GazeNeRFNet: hot path -> merge -> NeuralRenderer x4) against fixture g9, which was
+captured from the reference's own class with hash-generated parameters (oracle/gen_golden_e2e.py).
+
+CPU: the oracle's composition reproduces the four images; GazeNeRFNetAMD exposes exactly the reference's
+state-dict keys.  GPU: GazeNeRFNetAMD forward (<= 1e-4 on the images) and backward (camera / latent gradients and a
+sample of parameter gradients) for both precisions of the hot path."""
+import pytest
+import torch
+
+from conftest import load_golden
+from gazenerf_amd import synth
+from oracle import oracle as O
+
+IMGS = ("merge_img_face", "merge_img_eyes", "merge_img", "bg_img")
+
+
+def _setup():
+    g = load_golden("g9_network")
+    side, n_p = int(g["side"]), int(g["n_samples"])
+    face = synth.hash_mlp_params("face", seed=int(g["weight_seed"]), density_scale=float(g["density_scale"]))
+    eyes = synth.hash_mlp_params("eyes", seed=int(g["weight_seed"]), density_scale=float(g["density_scale"]))
+    ren = synth.hash_renderer_params(seed=int(g["renderer_seed"]))
+    bg = 0.5 + 0.5 * synth.synth_featmap(1, 258, side, seed=int(g["bg_seed"]))
+    prob = synth.synth_problem(side, batch=2, camera=str(int(g["camera"])), seed=int(g["problem_seed"]))
+    return g, side, n_p, face, eyes, ren, bg, prob
+
+
+def _loss(res):
+    tot = 0.0
+    for i, k in enumerate(IMGS):
+        img = res[k]
+        wgt = torch.linspace(0.5, 1.5, img.numel(), dtype=img.dtype, device=img.device).reshape(img.shape)
+        tot = tot + (i + 1) * ((img * wgt) ** 2).mean()
+    return tot
+
+
+def test_oracle_composition_vs_reference_network():
+    g, side, n_p, face, eyes, ren, bg, prob = _setup()
+    with torch.no_grad():
+        hot = O.render_two_stream(prob["xy"], prob["R"], prob["T"], prob["Kinv"], prob["shape_code"], prob["gaze"],
+                                  prob["appea_code"], face, eyes, n_p)
+        v4 = lambda t, c: t.view(2, c, side, side)
+        mf, ep, m = O.merge_featmaps(v4(hot["feat_face"], 258), v4(hot["bg_alpha_face"], 1), v4(hot["feat_eyes"], 258),
+                                     v4(hot["bg_alpha_eyes"], 1), bg, prob["gaze"])
+        res = {"merge_img_face": O.neural_renderer(ren, mf), "merge_img_eyes": O.neural_renderer(ren, ep),
+               "merge_img": O.neural_renderer(ren, m), "bg_img": O.neural_renderer(ren, bg)}
+    for k in IMGS:
+        assert float((res[k][:, :, ::2, ::2] - g["out_" + k]).abs().max()) <= 1e-6, k
+
+
+def test_module_state_dict_keys_equal_the_reference_network():
+    from gazenerf_amd import GazeNeRFNetAMD
+    g = load_golden("g9_network")
+    want = sorted(str(k) for k in g["state_dict_keys"])
+    net = GazeNeRFNetAMD(featmap_size=int(g["side"]), pred_img_size=int(g["img"]), num_sample_coarse=int(g["n_samples"]))
+    assert sorted(net.state_dict().keys()) == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_network_forward_backward_vs_reference_fixture(precision):
+    from gazenerf_amd import GazeNeRFNetAMD
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda:0")
+    g, side, n_p, face, eyes, ren, bg, prob = _setup()
+    net = GazeNeRFNetAMD(featmap_size=side, pred_img_size=int(g["img"]), num_sample_coarse=n_p, precision=precision)
+    sd = {}
+    for k, v in face.items():
+        sd["fg_CD_predictor_face." + k] = v
+    for k, v in eyes.items():
+        sd["fg_CD_predictor_eyes." + k] = v
+    for k, v in ren.items():
+        sd["neural_render." + k] = v
+    sd["neural_render.bg_featmap"] = bg
+    res = net.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys and all(k.endswith(".f") for k in res.missing_keys)
+    net = net.to(dev)
+    p = {k: v.to(dev) for k, v in prob.items()}
+    leaves = {k: p[k].clone().requires_grad_(True) for k in ("R", "T", "shape_code", "gaze", "appea_code")}
+    out = net("test", p["xy"], None, None, leaves["shape_code"], leaves["appea_code"], leaves["gaze"], leaves["R"],
+              leaves["T"], p["Kinv"])["coarse_dict"]
+    for k in IMGS:
+        assert float((out[k].detach().cpu()[:, :, ::2, ::2] - g["out_" + k]).abs().max()) <= 1e-4, k
+    _loss(out).backward()
+
+    def rel(a, b):
+        a, b = a.detach().double().cpu(), b.double()
+        return float((a.reshape(b.shape) - b).norm() / max(float(b.norm()), 1e-30))
+
+    # camera / latent gradients pass through the ReLU-masked hot path: same noise bound as tests/test_parity_gpu.py
+    for k, v in leaves.items():
+        assert rel(v.grad, g["grad_" + k]) <= 2e-2, k
+    pg = dict(net.named_parameters())
+    for k in g:
+        if k.startswith("gradw_"):
+            assert rel(pg[k[6:]].grad, g[k]) <= 2e-2, k
