@@ -39,7 +39,8 @@ constexpr int UP_MAX = GNR_UPSAMPLE_MAX_BLOCKS;
 // C[M][N] = epilogue(A[M][K] B[K][N])
 // ---------------------------------------------------------------------------------------------
 struct GemmParams {
-    const float* A; long a_rs, a_cs;               // A(m,k) = A[m*a_rs + k*a_cs]
+    const float* A; long a_rs, a_cs;               // A(m,k) = A[m*a_rs + k*a_cs]  (source of the packed copy)
+    const float* At; int Mp;                       // packed k-major copy: At[k*Mp + m], zero padded to Kp x Mp
     const float* B; long b_batch;                  // B(b,k,n) = B[b*b_batch + k*N + n]
     float* C; long c_batch;                        // C(b,m,n) = C[b*c_batch + m*N + n]   (plain store)
     int M, K, N;                                   // N % 128 == 0
@@ -49,39 +50,44 @@ struct GemmParams {
     int accumulate;                                // C += result
     int shuffle, W;                                // PixelShuffleUpsample tail: n = y*W + x
     const float* res; long res_batch;              // residual res(b, m % (M/4), n)
-    unsigned char* sign_out; long sign_batch;      // (acc + bias > 0) per (b,m,n)
+    unsigned char* sign_out; long sign_batch;      // shuffle: bit e of byte (b, m/4, n) = (acc + bias > 0) of channel 4(m/4)+e
 };
 
 constexpr int GT = 128, GK = 16;
 
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams gp) {
+// At[k][m] = A(m,k) for k < K, m < M, else 0; Kp % 16 == 0, Mp % 128 == 0.  The weights are tiny (<= 2 MB):
+// re-laying them out per call makes every A-tile load an aligned, unconditional float4.
+__global__ void pack_a_kernel(const float* __restrict__ A, long a_rs, long a_cs, int M, int K, int Mp, int Kp,
+                              float* __restrict__ At) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)Mp * Kp) return;
+    const int k = (int)(i / Mp), m = (int)(i - (long)k * Mp);
+    At[i] = (m < M && k < K) ? A[(long)m * a_rs + (long)k * a_cs] : 0.0f;
+}
+
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams gp) {
     __shared__ __attribute__((aligned(16))) float As[2][GK][GT], Bs[2][GK][GT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5, wm = wave >> 1, wn = wave & 1;
     const int n0 = blockIdx.x * GT, m0 = blockIdx.y * GT, b = blockIdx.z;
     const float* Bb = gp.B + (long)b * gp.b_batch;
-    // staging roles
-    const int am = tid & 127, akq = tid >> 7;              // A: row am, k = akq*8 + e
-    const int bk = tid >> 5, bn4 = tid & 31;               // B: rows bk and bk+8, float4 column bn4
-    float ra[8];
-    f32x4 rb[2];
+    // staging: rows bk and bk+8 of both k-major tiles, float4 column bn4
+    const int bk = tid >> 5, bn4 = tid & 31;
+    f32x4 ra[2], rb[2];
     auto gload = [&](int k0) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = k0 + akq * 8 + e, m = m0 + am;
-            ra[e] = (m < gp.M && k < gp.K) ? gp.A[(long)m * gp.a_rs + (long)k * gp.a_cs] : 0.0f;
-        }
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int k = k0 + bk + 8 * e;
+            ra[e] = *(const f32x4*)(gp.At + (long)k * gp.Mp + m0 + 4 * bn4);
             rb[e] = k < gp.K ? *(const f32x4*)(Bb + (long)k * gp.N + n0 + 4 * bn4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) As[buf][akq * 8 + e][am] = ra[e];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) *(f32x4*)&Bs[buf][bk + 8 * e][4 * bn4] = rb[e];
+        for (int e = 0; e < 2; ++e) {
+            *(f32x4*)&As[buf][bk + 8 * e][4 * bn4] = ra[e];
+            *(f32x4*)&Bs[buf][bk + 8 * e][4 * bn4] = rb[e];
+        }
     };
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     f32x16 acc[2][2] = {{zero, zero}, {zero, zero}};
@@ -106,6 +112,39 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams gp) {
         __syncthreads();
     }
     const int Cq = gp.M / 4;
+    if (gp.shuffle) {
+        // PixelShuffleUpsample tail.  A lane's registers 4q..4q+3 are in-channels 4c..4c+3 of one pixel, i.e. the
+        // 2x2 output block of out-channel c: two float2 stores; the four pre-activation signs go into one nibble.
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int mb = m0 + 64 * wm + 32 * x + 8 * q + 4 * lh;      // multiple of 4
+                    const int n = n0 + 64 * wn + 32 * y + li;
+                    if (mb >= gp.M) continue;
+                    float v[4];
+                    unsigned nib = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int m = mb + e;
+                        float t = acc[x][y][4 * q + e] + gp.bias[m];
+                        nib |= (t > 0.0f ? 1u : 0u) << e;
+                        t = t > 0.0f ? t : LEAK * t;
+                        // x.repeat(1,4,1,1): in-channel m reads x channel m % (M/4)
+                        v[e] = t + gp.res[(long)b * gp.res_batch + (long)(m % Cq) * gp.N + n];
+                    }
+                    gp.sign_out[(long)b * gp.sign_batch + (long)(mb >> 2) * gp.N + n] = (unsigned char)nib;
+                    // pixel_shuffle(2): in-channel 4c + 2i + j -> out (c, 2y+i, 2x+j)
+                    const int py = n / gp.W, px = n - py * gp.W;
+                    float* dst = gp.C + (long)b * gp.c_batch + (long)(mb >> 2) * (4L * gp.N) + (long)(2 * py) * (2 * gp.W) + 2 * px;
+                    *(f32x2*)dst = f32x2{v[0], v[1]};
+                    *(f32x2*)(dst + 2 * gp.W) = f32x2{v[2], v[3]};
+                }
+        return;
+    }
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -117,24 +156,26 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmParams gp) {
                 if (m >= gp.M) continue;
                 float v = acc[x][y][r];
                 if (gp.bias) v += gp.bias[m];
-                if (gp.sign_out) gp.sign_out[(long)b * gp.sign_batch + (long)m * gp.N + n] = v > 0.0f ? 1 : 0;
                 if (gp.leaky) v = v > 0.0f ? v : LEAK * v;
                 if (gp.mask_ref) v *= gp.mask_ref[(long)b * gp.mask_batch + (long)m * gp.N + n] > 0.0f ? 1.0f : LEAK;
-                if (gp.shuffle) {
-                    // x.repeat(1,4,1,1) + pixel_shuffle(2): in-channel m = 4c + 2i + j -> out (c, 2y+i, 2x+j)
-                    v += gp.res[(long)b * gp.res_batch + (long)(m % Cq) * gp.N + n];
-                    const int c = m >> 2, i = (m >> 1) & 1, j = m & 1;
-                    const int py = n / gp.W, px = n - py * gp.W;
-                    gp.C[(long)b * gp.c_batch + (long)c * (4L * gp.N) + (long)(2 * py + i) * (2 * gp.W) + 2 * px + j] = v;
-                } else {
-                    float* dst = gp.C + (long)b * gp.c_batch + (long)m * gp.N + n;
-                    *dst = gp.accumulate ? *dst + v : v;
-                }
+                float* dst = gp.C + (long)b * gp.c_batch + (long)m * gp.N + n;
+                *dst = gp.accumulate ? *dst + v : v;
             }
 }
 
-static void launch_gemm(const GemmParams& gp, int batch, hipStream_t st) {
-    hipLaunchKernelGGL(conv_gemm_kernel, dim3(gp.N / GT, (gp.M + GT - 1) / GT, batch), dim3(256), 0, st, gp);
+static size_t pack_floats(int M, int K) {      // padded size of one packed operand, either orientation
+    auto one = [](int m, int k) { return (size_t)((m + GT - 1) / GT * GT) * ((k + GK - 1) / GK * GK); };
+    const size_t a = one(M, K), b = one(K, M);
+    return a > b ? a : b;
+}
+
+static void launch_gemm(GemmParams gp, int batch, float* pack, hipStream_t st) {
+    gp.Mp = (gp.M + GT - 1) / GT * GT;
+    const int Kp = (gp.K + GK - 1) / GK * GK;
+    hipLaunchKernelGGL(pack_a_kernel, dim3((unsigned)(((long)gp.Mp * Kp + 255) / 256)), dim3(256), 0, st, gp.A, gp.a_rs, gp.a_cs,
+                       gp.M, gp.K, gp.Mp, Kp, pack);
+    gp.At = pack;
+    hipLaunchKernelGGL(conv_gemm_kernel, dim3(gp.N / GT, gp.Mp / GT, batch), dim3(256), 0, st, gp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -268,14 +309,19 @@ __global__ __launch_bounds__(256) void rgb_conv_bwd_data_kernel(const float* __r
     }
 }
 
-// dW[o][c] = sum_{b,p} drgb(b,o,p) net(b,c,p);  db[o] = sum drgb(b,o,p).  One block per c (c == C: bias), fixed order.
+// dW[o][c] = sum_{b,p} drgb(b,o,p) net(b,c,p);  db[o] = sum drgb(b,o,p)  (channel c == C stands for the bias).
+// Grid (C+1, RGBW_SPLITS): each block reduces a contiguous slice of the (b,p) range; rgb_wsum_kernel adds the
+// slices in a fixed order (deterministic).
+constexpr int RGBW_SPLITS = 32;
+
 __global__ __launch_bounds__(256) void rgb_conv_bwd_weight_kernel(const float* __restrict__ drgb, const float* __restrict__ net,
-                                                                  int C, long P, int batch, float* __restrict__ dw,
-                                                                  float* __restrict__ db) {
+                                                                  int C, long P, int batch, float* __restrict__ part) {
     __shared__ float red[3][256];
-    const int c = blockIdx.x, tid = threadIdx.x;
+    const int c = blockIdx.x, sp = blockIdx.y, tid = threadIdx.x;
+    const long total = (long)batch * P, per = (total + RGBW_SPLITS - 1) / RGBW_SPLITS;
+    const long i0 = (long)sp * per, i1 = i0 + per < total ? i0 + per : total;
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-    for (long i = tid; i < (long)batch * P; i += 256) {
+    for (long i = i0 + tid; i < i1; i += 256) {
         const long b = i / P, p = i - b * P;
         const float v = c < C ? net[b * C * P + (long)c * P + p] : 1.0f;
         const float* gp = drgb + b * 3 * P + p;
@@ -287,10 +333,17 @@ __global__ __launch_bounds__(256) void rgb_conv_bwd_weight_kernel(const float* _
         if (tid < s) { red[0][tid] += red[0][tid + s]; red[1][tid] += red[1][tid + s]; red[2][tid] += red[2][tid + s]; }
         __syncthreads();
     }
-    if (tid < 3) {
-        if (c < C) { if (dw) dw[tid * C + c] = red[tid][0]; }
-        else if (db) db[tid] = red[tid][0];
-    }
+    if (tid < 3) part[((long)c * RGBW_SPLITS + sp) * 3 + tid] = red[tid][0];
+}
+
+__global__ void rgb_wsum_kernel(const float* __restrict__ part, int C, float* __restrict__ dw, float* __restrict__ db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (c, o)
+    if (i >= (C + 1) * 3) return;
+    const int c = i / 3, o = i - 3 * c;
+    float a = 0.0f;
+    for (int sp = 0; sp < RGBW_SPLITS; ++sp) a += part[((long)c * RGBW_SPLITS + sp) * 3 + o];
+    if (c < C) { if (dw) dw[o * C + c] = a; }
+    else if (db) db[o] = a;
 }
 
 // d(rgb) = d(img) * img * (1 - img)
@@ -302,7 +355,7 @@ __global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restric
 
 // ---------------------------------------------------------------------------------------------
 // PixelShuffleUpsample tail, backward: du [B][C][2H][2W] ->
-//   dpre2(b,k,p) = G(b,k,p) * (sign(b,k,p) ? 1 : 0.2),  G(b, 4c+2i+j, y*W+x) = du(b, c, 2y+i, 2x+j)      (k < 4C)
+//   dpre2(b,k,p) = G(b,k,p) * (bit k&3 of sign(b,k>>2,p) ? 1 : 0.2),  G(b, 4c+2i+j, y*W+x) = du(b, c, 2y+i, 2x+j)
 //   dres(b,c,p)  = sum_{q<4} G(b, c + q C, p)                                                    (x.repeat adjoint)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void unshuffle_bwd_kernel(const float* __restrict__ du, const unsigned char* __restrict__ sign,
@@ -320,7 +373,7 @@ __global__ __launch_bounds__(256) void unshuffle_bwd_kernel(const float* __restr
         const long b = idx / (4L * C * P), rem = idx - b * 4L * C * P;
         const int k = (int)(rem / P);
         const long p = rem - (long)k * P;
-        dpre2[idx] = G(b, k, p) * (sign[idx] ? 1.0f : LEAK);
+        dpre2[idx] = G(b, k, p) * (((sign[(b * C + (k >> 2)) * P + p] >> (k & 3)) & 1) ? 1.0f : LEAK);
     } else if (idx < n2 + n1) {
         const long e = idx - n2;
         const long b = e / ((long)C * P), rem = e - b * (long)C * P;
@@ -365,7 +418,8 @@ static int up_dims(const GnrUpsampleProblem* p, UpDims* d) {
 
 struct UpSaved {                        // kept for the backward
     float* a1[UP_MAX];                  // [B][2C][P]
-    unsigned char* sign2[UP_MAX];       // [B][4C][P]
+    unsigned char* sign2[UP_MAX];       // [B][C][P]    four pre-activation sign bits per (out-channel quad, pixel)
+    float* pack;                        // packed A operand of the GEMM in flight
     float* v[UP_MAX];                   // [B][C][4P]   blurred
     float* net[UP_MAX];                 // [B][C'][4P]  block output
     float* img;                         // [B][3][Pn]
@@ -382,13 +436,20 @@ static size_t up_carve(const GnrUpsampleProblem* p, const UpDims& d, char* base,
     for (int i = 0; i < d.n_blocks; ++i) {
         const size_t C = d.ch[i], Cn = d.ch[i + 1], P = (size_t)d.side[i] * d.side[i];
         z.a1[i] = (float*)take(B * 2 * C * P * 4);
-        z.sign2[i] = (unsigned char*)take(B * 4 * C * P);
+        z.sign2[i] = (unsigned char*)take(B * C * P);
         z.v[i] = (float*)take(B * C * 4 * P * 4);
         z.net[i] = (float*)take(B * Cn * 4 * P * 4);
         if (B * C * 4 * P * 4 > umax) umax = B * C * 4 * P * 4;
     }
     const size_t Pn = (size_t)d.side[d.n_blocks] * d.side[d.n_blocks];
     z.img = (float*)take(B * 3 * Pn * 4);
+    size_t pk = 0;
+    for (int i = 0; i < d.n_blocks; ++i) {
+        const int C = d.ch[i], Cn = d.ch[i + 1];
+        const size_t c3[3] = {pack_floats(2 * C, C), pack_floats(4 * C, 2 * C), pack_floats(Cn, C)};
+        for (size_t v : c3) if (v > pk) pk = v;
+    }
+    z.pack = (float*)take(pk * 4);
     z.u = (float*)take(umax);
     z.rgb_a = (float*)take(B * 3 * Pn * 4);
     z.rgb_b = (float*)take(B * 3 * Pn * 4);
@@ -420,7 +481,9 @@ static size_t up_carve_bwd(const GnrUpsampleProblem* p, const UpDims& d, char* b
     z.g1 = (float*)take(big);
     z.drgb_a = (float*)take(B * 3 * Pn * 4);
     z.drgb_b = (float*)take(B * 3 * Pn * 4);
-    z.colsum = (float*)take(B * (size_t)(mmax + 128) * 4);
+    size_t cs_floats = B * (size_t)(mmax + 128);
+    if (cs_floats < (size_t)(mmax + 1) * RGBW_SPLITS * 3) cs_floats = (size_t)(mmax + 1) * RGBW_SPLITS * 3;
+    z.colsum = (float*)take(cs_floats * 4);
     z.wg = (float*)take(wgrad_scratch_floats() * 4);
     if (s) *s = z;
     return off;
@@ -491,13 +554,13 @@ int gnr_upsample_fwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, f
         // a1 = lrelu(W1 net + b1)
         g.A = w->up1_w[i]; g.a_rs = C; g.a_cs = 1; g.B = net; g.b_batch = (long)C * P; g.C = s.a1[i]; g.c_batch = 2L * C * P;
         g.M = 2 * C; g.K = C; g.N = (int)P; g.bias = w->up1_b[i]; g.leaky = 1;
-        launch_gemm(g, B, st);
+        launch_gemm(g, B, s.pack, st);
         // u = pixel_shuffle(lrelu(W2 a1 + b2) + repeat(net))
         g = GemmParams{};
         g.A = w->up2_w[i]; g.a_rs = 2 * C; g.a_cs = 1; g.B = s.a1[i]; g.b_batch = 2L * C * P; g.C = s.u; g.c_batch = 4L * C * P;
         g.M = 4 * C; g.K = 2 * C; g.N = (int)P; g.bias = w->up2_b[i]; g.leaky = 1; g.shuffle = 1; g.W = S;
-        g.res = net; g.res_batch = (long)C * P; g.sign_out = s.sign2[i]; g.sign_batch = 4L * C * P;
-        launch_gemm(g, B, st);
+        g.res = net; g.res_batch = (long)C * P; g.sign_out = s.sign2[i]; g.sign_batch = (long)C * P;
+        launch_gemm(g, B, s.pack, st);
         // v = blur(u)
         hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * C * 4 * P)), dim3(256), 0, st, s.u, s.v[i], (long)B * C, 2 * S,
                            2 * S, 0);
@@ -505,7 +568,7 @@ int gnr_upsample_fwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, f
         g = GemmParams{};
         g.A = w->feat_w[i]; g.a_rs = C; g.a_cs = 1; g.B = s.v[i]; g.b_batch = 4L * C * P; g.C = s.net[i]; g.c_batch = 4L * Cn * P;
         g.M = Cn; g.K = C; g.N = (int)(4 * P); g.bias = w->feat_b[i]; g.leaky = 1;
-        launch_gemm(g, B, st);
+        launch_gemm(g, B, s.pack, st);
         // rgb += conv_rgb(i+1)(net');  last block: img = sigmoid(rgb) (or rgb itself)
         const bool last = i == d.n_blocks - 1;
         hipLaunchKernelGGL(rgb_conv_kernel, dim3(blocks_for((long)B * 4 * P)), dim3(256), 0, st, s.net[i], Cn, 4 * P, B,
@@ -563,9 +626,10 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
                                2 * S, 2 * S);
         }
         // conv_rgb(i+1): weight/bias gradients, then dhid = (dnet' + Wr^T drgb) * lrelu'(net')
-        if (G.rgb_w[i + 1] || G.rgb_b[i + 1])
-            hipLaunchKernelGGL(rgb_conv_bwd_weight_kernel, dim3(Cn + 1), dim3(256), 0, st, drgb, s.net[i], Cn, P4, B, G.rgb_w[i + 1],
-                               G.rgb_b[i + 1]);
+        if (G.rgb_w[i + 1] || G.rgb_b[i + 1]) {
+            hipLaunchKernelGGL(rgb_conv_bwd_weight_kernel, dim3(Cn + 1, RGBW_SPLITS), dim3(256), 0, st, drgb, s.net[i], Cn, P4, B, t.colsum);
+            hipLaunchKernelGGL(rgb_wsum_kernel, dim3((3 * (Cn + 1) + 63) / 64), dim3(64), 0, st, t.colsum, Cn, G.rgb_w[i + 1], G.rgb_b[i + 1]);
+        }
         float* dhid = dnet_next ? dnet_next : t.g0;
         hipLaunchKernelGGL(rgb_conv_bwd_data_kernel, dim3(blocks_for((long)B * P4)), dim3(256), 0, st, drgb, Cn, P4, B, w->rgb_w[i + 1],
                            dhid, dnet_next ? 1 : 0, s.net[i]);
@@ -576,7 +640,7 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
         GemmParams g{};
         g.A = w->feat_w[i]; g.a_rs = 1; g.a_cs = C; g.B = dhid; g.b_batch = (long)Cn * P4; g.C = other; g.c_batch = (long)C * P4;
         g.M = C; g.K = Cn; g.N = (int)P4;
-        launch_gemm(g, B, st);                                           // other = dv
+        launch_gemm(g, B, s.pack, st);                                           // other = dv
         // du = blur^T dv  (into dhid's buffer)
         hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * C * P4)), dim3(256), 0, st, other, dhid, (long)B * C, 2 * S, 2 * S, 1);
         float* du = dhid;
@@ -592,14 +656,14 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
         g = GemmParams{};
         g.A = w->up2_w[i]; g.a_rs = 1; g.a_cs = 2 * C; g.B = dpre2; g.b_batch = 4L * C * P; g.C = dpre1; g.c_batch = 2L * C * P;
         g.M = 2 * C; g.K = 4 * C; g.N = (int)P; g.mask_ref = s.a1[i]; g.mask_batch = 2L * C * P;
-        launch_gemm(g, B, st);
+        launch_gemm(g, B, s.pack, st);
         // layer_1: dW1 = dpre1 net_in^T, db1; dnet += W1^T dpre1
         launch_wgrad_img(dpre1, 2 * C, 2 * C, net_in, C, C, B, P, G.up1_w[i], C, t.colsum, 2 * C + 128, t.wg, st);
         if (G.up1_b[i]) hipLaunchKernelGGL(sum_batch_kernel, dim3((2 * C + 63) / 64), dim3(64), 0, st, t.colsum, B, 2 * C, 2 * C + 128, G.up1_b[i]);
         g = GemmParams{};
         g.A = w->up1_w[i]; g.a_rs = 1; g.a_cs = C; g.B = dpre1; g.b_batch = 2L * C * P; g.C = dnet; g.c_batch = (long)C * P;
         g.M = C; g.K = 2 * C; g.N = (int)P; g.accumulate = 1;
-        launch_gemm(g, B, st);
+        launch_gemm(g, B, s.pack, st);
         // hand d(net_in) to block i-1 in a buffer that survives: g0/g1 are free again -> copy into the one not used next
         if (i > 0) {
             (void)hipMemcpyAsync(t.g0, dnet, (size_t)B * C * P * 4, hipMemcpyDeviceToDevice, st);
@@ -615,8 +679,10 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
         const long P = (long)S * S;
         hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * 3 * 4 * P)), dim3(256), 0, st, drgb, drgb_tmp, (long)B * 3, 2 * S, 2 * S, 1);
         hipLaunchKernelGGL(bilinear2x_adj_kernel, dim3(blocks_for((long)B * 3 * P)), dim3(256), 0, st, drgb_tmp, drgb, (long)B * 3, S, S);
-        if (G.rgb_w[0] || G.rgb_b[0])
-            hipLaunchKernelGGL(rgb_conv_bwd_weight_kernel, dim3(d.ch[0] + 1), dim3(256), 0, st, drgb, p->x, d.ch[0], P, B, G.rgb_w[0], G.rgb_b[0]);
+        if (G.rgb_w[0] || G.rgb_b[0]) {
+            hipLaunchKernelGGL(rgb_conv_bwd_weight_kernel, dim3(d.ch[0] + 1, RGBW_SPLITS), dim3(256), 0, st, drgb, p->x, d.ch[0], P, B, t.colsum);
+            hipLaunchKernelGGL(rgb_wsum_kernel, dim3((3 * (d.ch[0] + 1) + 63) / 64), dim3(64), 0, st, t.colsum, d.ch[0], G.rgb_w[0], G.rgb_b[0]);
+        }
         hipLaunchKernelGGL(rgb_conv_bwd_data_kernel, dim3(blocks_for((long)B * P)), dim3(256), 0, st, drgb, d.ch[0], P, B, w->rgb_w[0],
                            dnet_next, 1, (const float*)nullptr);
         if (d_x) (void)hipMemcpyAsync(d_x, dnet_next, (size_t)B * d.ch[0] * P * 4, hipMemcpyDeviceToDevice, st);
