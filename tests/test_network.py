@@ -94,3 +94,34 @@ def test_network_forward_backward_vs_reference_fixture(precision):
     for k in g:
         if k.startswith("gradw_"):
             assert rel(pg[k[6:]].grad, g[k]) <= 2e-2, k
+
+
+@pytest.mark.gpu
+def test_inference_is_hip_graph_capturable():
+    """The C ABI only enqueues on the caller's stream (no allocation, no host synchronisation), so the whole
+    network forward can be captured once and replayed (torch.cuda.CUDAGraph == hipGraph on ROCm)."""
+    from gazenerf_amd import GazeNeRFNetAMD
+    dev = torch.device("cuda:0")
+    g, side, n_p, face, eyes, ren, bg, prob = _setup()
+    net = GazeNeRFNetAMD(featmap_size=side, pred_img_size=int(g["img"]), num_sample_coarse=n_p).to(dev).eval()
+    p = {k: v.to(dev) for k, v in prob.items()}
+    args = ("test", p["xy"], None, None, p["shape_code"], p["appea_code"], p["gaze"], p["R"], p["T"], p["Kinv"])
+    with torch.no_grad():
+        eager = net(*args)["coarse_dict"]["merge_img"].clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            net(*args)
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = net(*args)["coarse_dict"]["merge_img"]
+        g0 = p["gaze"].clone()
+        p["gaze"].copy_(g0 + 0.1)                # new input in the captured buffers
+        graph.replay()
+        torch.cuda.synchronize()
+        changed = out.clone()
+        p["gaze"].copy_(g0)
+        graph.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(out, eager) and not torch.equal(changed, eager)
