@@ -154,9 +154,16 @@ __device__ __forceinline__ void ring_init(WRing& w, const float* packed, unsigne
 }
 
 // first rows into registers: call after ring_init, with no other barrier in between
+// s_barrier is IntrNoMem for the compiler: it may move LDS loads across it.  The ring reads that follow a
+// barrier must stay behind it, so every barrier here is followed by a compiler-only memory fence.
+__device__ __forceinline__ void ring_barrier() {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ void ring_start(WRing& w) {
     wait_vm<2 * DEPTH>();
-    __builtin_amdgcn_s_barrier();
+    ring_barrier();
     ring_read_pair(w, 0, 0, w.g[0]);
 }
 
@@ -185,7 +192,7 @@ __device__ __forceinline__ void ring_layer(WRing& w, PairFn pair, StoresFn store
 #pragma unroll
         for (int d = 1; d < DEPTH; ++d) allow += (ph - d >= 0 && !(ABL & 64)) ? stores(ph - d) : 0;
         if (!(ABL & 16)) wait_vm_n(allow);
-        if (!(ABL & 2)) __builtin_amdgcn_s_barrier();
+        if (!(ABL & 2)) ring_barrier();
         ring_request(w);
         ring_read_pair(w, w.rd, 1, w.g[1]);
         pair(2 * ph, w.g[0]);
