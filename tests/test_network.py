@@ -125,3 +125,30 @@ def test_inference_is_hip_graph_capturable():
         graph.replay()
         torch.cuda.synchronize()
     assert torch.equal(out, eager) and not torch.equal(changed, eager)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_network_training_steps_lower_an_image_loss(precision):
+    """Three Adam steps on every parameter of the network (MLPs, upsampler, bg_featmap) plus the latent codes
+    against a fixed target image: the loss must go down -- gradients of the whole chain point the right way."""
+    from gazenerf_amd import GazeNeRFNetAMD
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = GazeNeRFNetAMD(featmap_size=16, pred_img_size=64, num_sample_coarse=32, precision=precision).to(dev)
+    p = {k: v.to(dev) for k, v in synth.synth_problem(16, batch=2, camera="4", seed=3).items()}
+    codes = [p[k].clone().requires_grad_(True) for k in ("shape_code", "appea_code", "gaze")]
+    target = torch.rand(2, 3, 64, 64, device=dev)
+    opt = torch.optim.Adam(list(net.parameters()) + codes, lr=2e-3)
+    losses = []
+    for _ in range(4):
+        opt.zero_grad()
+        t_rand = synth.synth_jitter(2, 256, 32, seed=len(losses)).to(dev)
+        res = net("train", p["xy"], None, None, codes[0], codes[1], codes[2], p["R"], p["T"], p["Kinv"], t_rand=t_rand)["coarse_dict"]
+        loss = sum(((res[k] - target) ** 2).mean() for k in ("merge_img_face", "merge_img_eyes", "merge_img"))
+        loss = loss + ((res["bg_img"] - 1.0) ** 2).mean()            # gazenerf_loss.py: bg_img -> bg_value
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0], losses
+    assert net.neural_render.bg_featmap.grad is not None and float(net.neural_render.bg_featmap.grad.abs().sum()) > 0
