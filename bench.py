@@ -220,14 +220,14 @@ def main():
         achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         # HBM-side bytes per launch: PMC FETCH_SIZE/WRITE_SIZE of this kernel, collected with rocprofv3
         # in separate passes and committed under profiles/ (counters cannot be read from inside this
-        # process); scaled per ray to this launch size.  Inference variant only.
+        # process); scaled per ray to this launch size.
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r1_pmc_fwd.json")
-        if args.mode == "fwd" and os.path.exists(pmc):
+        pmc = os.path.join(ROOT, "profiles", "r1_pmc_fwd.json" if args.mode == "fwd" else "r1_pmc_fwd_save.json")
+        if os.path.exists(pmc):
             with open(pmc) as f:
                 pj = json.load(f)
             traffic = pj["hbm_bytes_per_ray"] * rays_per_launch
-            traffic_src = "profiles/r1_pmc_fwd.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, per ray x rays per launch)"
+            traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, per ray x rays per launch)" % os.path.basename(pmc)
         x3 = args.precision == "bf16x3"
         peak = PEAK_BF16X3_TFLOPS if x3 else PEAK_FP32_MFMA_TFLOPS
         kname = ("gnr::fwd3_kernel<%s>" if x3 else "gnr::fwd_kernel<%s>") % ("true" if args.mode == "fwdbwd" else "false")
@@ -266,9 +266,15 @@ def main():
             nbytes = m * (288 * 4 + 8 + 8) + micro * (288 * 4 + 4 + 8)
             a = sum(aux_ms) / len(aux_ms)
             gbs = nbytes / (a * 1e-3) / 1e9
+            hbm_traffic = None
+            pmc_cb = os.path.join(ROOT, "profiles", "r1_pmc_comp_bwd.json")
+            if os.path.exists(pmc_cb):
+                with open(pmc_cb) as f:
+                    hbm_traffic = json.load(f)["hbm_bytes_per_ray"] * micro
             res["roofline_hbm"] = {"bound": "hbm", "kernel": "gnr::comp_bwd_kernel", "achieved": gbs, "peak": 8000.0,
                                    "unit": "GB/s", "frac": gbs / 8000.0, "bytes_per_launch": nbytes,
-                                   "avg_launch_ms": a, "launches_timed": len(aux_ms), "traffic": None}
+                                   "avg_launch_ms": a, "launches_timed": len(aux_ms), "traffic": hbm_traffic,
+                                   "traffic_source": "profiles/r1_pmc_comp_bwd.json (rocprofv3 --pmc, per ray x rays per launch)"}
         if alt is not None:
             adt, akm, _ = alt
             a_avg = sum(akm) / max(1, len(akm))
