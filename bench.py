@@ -282,8 +282,9 @@ def main():
             res["bf16x3"] = {
                 "note": "same workload, same timing protocol, dense layers (forward, dgrad chain, weight-gradient "
                         "GEMMs) on bf16 MFMA with a 3-term hi/lo split, fp32 accumulate; feature map within "
-                        "1e-4 of the reference (measured <= 6e-6), gradients inside the reference's own "
-                        "fp32-vs-fp64 noise (tests/test_parity_gpu.py, DESIGN.md)",
+                        "1e-4 of the reference (<= 6e-6 on the fixtures); against fp64 as close to exact as the "
+                        "reference's own fp32 run; gradients inside the reference's fp32-vs-fp64 noise "
+                        "(tests/test_parity_gpu.py, DESIGN.md section 4)",
                 "value": world * n_rays * args.steps / adt, "unit": "rays/s", "ms_per_step": adt / args.steps * 1e3,
                 "speedup_vs_fp32": dt / adt,
                 "roofline": {"bound": "mfma", "kernel": "gnr::fwd3_kernel<%s>" % ("true" if args.mode == "fwdbwd" else "false"),

@@ -138,10 +138,12 @@ int gnr_fwd(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes,
  * a*b ~ a_hi*b_hi + a_lo*b_hi + a_hi*b_lo, fp32 accumulate): ~16 mantissa bits per operand at 5.3x the
  * fp32-MFMA rate.  Same arguments, workspace sizes and outputs as gnr_fwd / gnr_bwd, but the saved
  * activations use a different internal layout: gnr_bwd_bf16x3 must follow gnr_fwd_bf16x3 (and gnr_bwd
- * must follow gnr_fwd) on the same saved workspace.  Forward results agree with gnr_fwd to
- * that path's own rounding noise (feature map <= ~6e-6, bg_alpha <= ~3e-5 on the reference fixtures:
- * inside the 1e-4 contract); gradients stay inside the reference's own fp32-vs-fp64 noise on every
- * tensor.  The weight-gradient GEMMs (dW = dY^T X) use the same split; bias, latent-code,
+ * must follow gnr_fwd) on the same saved workspace.  Accuracy: measured against the reference run in fp64,
+ * these kernels are as close to the exact result as the reference's own fp32 arithmetic in every case tried
+ * (DESIGN.md section 4); against the reference's fp32 output the feature map stays within the 1e-4 contract
+ * (<= 6e-6 on the test-mode fixtures, <= 6e-5 under the x50 opaque-head + train-jitter stress), bg_alpha
+ * within 3e-5 on the fixtures and within ~1.2e-4 under that stress -- there the reference's fp32 run is itself
+ * 1.5e-4 from its fp64 run.  Gradients stay inside the reference's own fp32-vs-fp64 noise on every tensor.  The weight-gradient GEMMs (dW = dY^T X) use the same split; bias, latent-code,
  * density-head and geometry gradients, the compositing backward and all reductions stay fp32. */
 int gnr_fwd_bf16x3(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes,
                    const GnrOutputs* out, int save_for_backward, void* workspace, size_t ws_bytes,
