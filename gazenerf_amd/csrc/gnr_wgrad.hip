@@ -452,8 +452,9 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
     // Split count: the kernel places split s on XCD s % 8 (32 CUs x 2 resident workgroups = 64 slots
     // per XCD).  Every XCD must get the SAME number of workgroups and fill whole rounds, otherwise
     // the launch waits for one XCD's straggler round (113 splits instead of 112 cost 40 %):
-    // splits = 8 * floor(2 rounds * 64 slots / tiles), made divisible by the batch.
-    long splits_total = 8L * ((2 * 64) / tiles);
+    // splits = 8 * floor(64 slots / tiles), made divisible by the batch: ONE round of workgroups.  (Two rounds
+    // ran the GEMM no faster and doubled the partial tiles the reduce kernel has to sum: 60 -> 27 us per layer.)
+    long splits_total = 8L * (64 / tiles);
     if (splits_total < 8) splits_total = 8;
     long spi = splits_total / batch;
     if (spi < 1) spi = 1;
