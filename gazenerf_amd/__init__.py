@@ -6,10 +6,12 @@ Public surface:
     neural_render, NeuralRendererAMD                       (gazenerf_amd.upsample)
     HotPathRenderer, MLPParams, GazeNeRFNetAMD             (gazenerf_amd.module; the last one is the whole
                                                            reference network: hot path -> merge -> upsampler x4)
+    losses                                                 image losses + per-sample fitting step (SURVEY 8(f) N4,
+                                                           the terms without a pretrained network)
     synth                                                  synthetic input recipe
     build.build()                                          compile libgnr.so for gfx950
 """
-from . import synth  # noqa: F401
+from . import losses, synth  # noqa: F401
 from .render import importance_resample, render_two_stream, sample_zvals  # noqa: F401
 from .merge import merge_featmaps  # noqa: F401
 from .upsample import NeuralRendererAMD, neural_render  # noqa: F401
