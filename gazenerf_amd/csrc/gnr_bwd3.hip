@@ -6,7 +6,7 @@
 // density-head term), dumps the result -- that layer's dY, the A operand of the weight-gradient GEMMs,
 // fp32 in the channel-quad layout of gnr_chain3.h (one 16-byte store per quad) -- and splits it into
 // bf16 hi/lo.  Needs the saved workspace of gnr_fwd_bf16x3 (encoding and activations in that layout).
-// tools/cpu_bf16x3_grad_probe.py: gradients of a bf16x3 step sit inside the reference's own fp32-vs-fp64
+// tests/diagnostics/cpu_bf16x3_grad_probe.py: gradients of a bf16x3 step sit inside the reference's own fp32-vs-fp64
 // noise on every tensor (worst rel-L2 9.96e-3 against 1.01e-2 for plain fp32; 3e-5 where fp32 has 3e-6).
 #include "gnr_bwd_common.h"
 #include "gnr_chain3.h"

@@ -2,7 +2,7 @@
 Compares gradients of the oracle run in fp32 and of an emulated bf16x3 run (every dense layer's forward, dgrad and
 wgrad products through the split) against the oracle in fp64.  Same problem as tools/gpu_grad_probe.py."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import torch.nn.functional as F
 from gazenerf_amd import synth

@@ -1,6 +1,6 @@
 """Scratch: bf16x3 forward vs the oracle + timing."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from gazenerf_amd import render, synth
 from gazenerf_amd.hiptime import KernelTimer

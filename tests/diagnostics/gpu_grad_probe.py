@@ -1,6 +1,6 @@
 """Scratch: per-tensor gradient errors of the HIP backward vs the oracle's autograd."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from gazenerf_amd import render, synth
 from oracle import oracle as O

@@ -1,6 +1,6 @@
 """Scratch: max-abs error of feat / bg_alpha vs the fp64 oracle over a sweep of stress problems, both precisions."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from gazenerf_amd import render, synth
 from oracle import oracle as O

@@ -1,6 +1,6 @@
 """Scratch probe for the GPU box: error stats vs the oracle + quick timings (not a test)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from gazenerf_amd import render, synth
 from oracle import oracle as O

@@ -1,6 +1,6 @@
 """Scratch: accuracy and timing of the N1 upsampler (HIP vs the oracle's CPU run)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from gazenerf_amd import synth, neural_render
 from oracle import oracle as O

@@ -233,7 +233,7 @@ def test_errors_are_exceptions():
 # ----------------------------------------------------------------------------- backward
 # Gradient tolerances.  The function is piecewise (ReLU) with sin/cos of arguments up to ~1.7e3 rad, so
 # an fp32 ulp in a pre-activation near zero flips a mask and moves the gradients of a whole channel.
-# Calibration (tools/gpu_grad_probe.py and the same script on CPU, 2 x 40 rays x 64 samples): the
+# Calibration (tests/diagnostics/gpu_grad_probe.py and the same script on CPU, 2 x 40 rays x 64 samples): the
 # reference's own fp32 autograd differs from its fp64 run by rel-L2 up to 1.0e-2 (dR) / 6.7e-3 (trunk
 # weights) and max-abs up to 1.6e-2 of scale; the HIP backward differs from fp64 by no more than that
 # on every tensor (5.3e-3 on dR), and by ~1e-6 on the layers above the first ReLU mask.  A wrong kernel
