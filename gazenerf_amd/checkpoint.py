@@ -81,6 +81,13 @@ def renderer_kwargs_from_options(opt) -> Dict:
                 gaze_dims=opt.eye_code_dims, appea_dims=opt.text_code_dims + opt.illu_code_dims)
 
 
+def network_kwargs_from_options(opt) -> Dict:
+    """GazeNeRFNetAMD(**kwargs) matching a checkpoint's ``para`` entry (models/gaze_nerf.py:40-46, 111-119)."""
+    kw = renderer_kwargs_from_options(opt)
+    kw.update(featmap_size=opt.featmap_size, pred_img_size=opt.pred_img_size, bg_type=getattr(opt, "bg_type", "white"))
+    return kw
+
+
 def update_from_renderer(ckpt: Dict, renderer) -> Dict:
     """Write the renderer's parameters back into ckpt["net"] (other entries untouched)."""
     net = ckpt["net"]

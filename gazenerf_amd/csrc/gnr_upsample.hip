@@ -406,6 +406,9 @@ static int up_dims(const GnrUpsampleProblem* p, UpDims* d) {
     if (p->featmap_size < 16 || (p->featmap_size & (p->featmap_size - 1)))
         return fail("gnr_upsample: featmap_size must be a power of two >= 16 (got %d)", p->featmap_size);
     if (p->min_feat < 1) return fail("gnr_upsample: min_feat must be >= 1");
+    if (p->feat_nc < p->min_feat)
+        return fail("gnr_upsample: feat_nc (%d) < min_feat (%d): the reference's NeuralRenderer builds its first block for "
+                    "max(feat_nc, min_feat) input channels and cannot run this configuration either", p->feat_nc, p->min_feat);
     if (!p->x) return fail("gnr_upsample: x is NULL");
     d->n_blocks = p->n_blocks;
     for (int i = 0; i <= p->n_blocks; ++i) {

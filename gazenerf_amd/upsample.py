@@ -165,7 +165,10 @@ class NeuralRendererAMD(nn.Module):
         ch = _channels(feat_nc, self.n_blocks, min_feat)
         self.feat_upsample_list = nn.ModuleList([_PSU(ch[i]) for i in range(self.n_blocks)])
         self.rgb_upsample = nn.Sequential(nn.Identity(), _BlurBuf())      # key "rgb_upsample.1.f" (neural_renderer.py:65-67)
-        self.feat_2_rgb_list = nn.ModuleList([nn.Conv2d(ch[i], 3, 1, 1, padding=0) for i in range(self.n_blocks + 1)])
+        # entry 0 is built from feat_nc itself, the others from max(feat_nc >> i, min_feat) (neural_renderer.py:69-82);
+        # the two differ only for feat_nc < min_feat, a configuration the reference constructs but cannot run
+        self.feat_2_rgb_list = nn.ModuleList([nn.Conv2d(feat_nc if i == 0 else ch[i], 3, 1, 1, padding=0)
+                                              for i in range(self.n_blocks + 1)])
         self.feat_layers = nn.ModuleList([nn.Conv2d(ch[i], ch[i + 1], 1, 1, padding=0) for i in range(self.n_blocks)])
         fill = torch.ones if bg_type == "white" else torch.zeros
         self.bg_featmap = nn.Parameter(fill((1, feat_nc, featmap_size, featmap_size), dtype=torch.float32))

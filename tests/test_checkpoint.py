@@ -64,3 +64,14 @@ def test_round_trip_keeps_every_other_entry(tmp_path):
     # the file names the reference's class, so its torch.load resolves its own BaseOptions
     raw = open(out, "rb").read()
     assert b"configs.gazenerf_options" in raw and b"gazenerf_amd.checkpoint" not in raw
+
+
+def test_whole_network_loads_a_reference_checkpoint_strictly():
+    """ckpt["net"] written by the reference's own GazeNeRFNet (oracle/gen_golden.py) -> GazeNeRFNetAMD, strict=True:
+    every key (both MLPs, NeuralRenderer incl. bg_featmap and Blur's buffers) exists with the same shape."""
+    from gazenerf_amd import GazeNeRFNetAMD
+    ck = CK.load_reference_checkpoint(os.path.join(GOLD, "ref_checkpoint_tiny.json"))
+    net = GazeNeRFNetAMD(**CK.network_kwargs_from_options(ck["para"]))
+    res = net.load_state_dict(ck["net"], strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert torch.equal(net.neural_render.bg_featmap.data, ck["net"]["neural_render.bg_featmap"])
