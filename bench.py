@@ -104,7 +104,16 @@ def cpu_baseline(mode, n_rays, n_samples):
         times.append(time.time() - t0)
     times.sort()
     med = times[len(times) // 2]
-    return {"value": n_rays / med, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+    # the reference pins itself to ONE thread (train.py / gazenerf_trainer: torch.set_num_threads(1)); SURVEY.md 8(d)
+    # asks for that figure beside the all-core one: same workload on a 64-ray sample
+    used = torch.get_num_threads()
+    torch.set_num_threads(1)
+    probe()
+    t0 = time.time()
+    probe()
+    one_thread = 64 / (time.time() - t0)
+    torch.set_num_threads(used)
+    return {"value": n_rays / med, "unit": "rays/s", "cores": used, "kind": "port", "value_1_thread": one_thread,
             "sample": "%d rays x %d samples, both streams, %s, median of %d runs (%.2f s each) at the "
                       "fastest of the probed thread counts (%d of %d cores), PyTorch-CPU oracle pinned to "
                       "the reference by tests/golden" % (n_rays, n_samples, mode, len(times), med, best_t, cores)}
