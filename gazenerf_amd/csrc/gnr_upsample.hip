@@ -196,20 +196,32 @@ __device__ __forceinline__ void blur_taps(int u, int n, bool adjoint, float& wl,
     }
 }
 
+// One thread = 4 consecutive output pixels of a row (W % 4 == 0): three float4 row loads plus the two edge
+// neighbours per row, one float4 store -- the kernel is HBM-bound (reads and writes every plane once).
 __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in, float* __restrict__ out, long planes,
                                                    int H, int W, int adjoint) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const long total = planes * H * W;
-    if (idx >= total) return;
-    const int x = (int)(idx % W), y = (int)((idx / W) % H);
-    const float* p = in + (idx - x - (long)y * W);
-    float xl, xc, xr, yl, yc, yr;
-    blur_taps(x, W, adjoint, xl, xc, xr);
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;              // index of the pixel quad
+    const long total = planes * H * (W / 4);
+    if (q >= total) return;
+    const int xq = (int)(q % (W / 4)), y = (int)((q / (W / 4)) % H);
+    const int x = 4 * xq;
+    const float* p = in + (q / ((long)(W / 4) * H)) * ((long)H * W);
+    float yl, yc, yr;
     blur_taps(y, H, adjoint, yl, yc, yr);
-    const int x0 = x >= 1 ? x - 1 : x, x2 = x + 1 < W ? x + 1 : x;
     const int y0 = y >= 1 ? y - 1 : y, y2 = y + 1 < H ? y + 1 : y;
-    auto row = [&](int yy) { return xl * p[(long)yy * W + x0] + xc * p[(long)yy * W + x] + xr * p[(long)yy * W + x2]; };
-    out[idx] = yl * row(y0) + yc * row(y) + yr * row(y2);
+    float wl[4], wc[4], wr[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) blur_taps(x + e, W, adjoint, wl[e], wc[e], wr[e]);
+    const int xm = x >= 1 ? x - 1 : x, xp = x + 4 < W ? x + 4 : x + 3;
+    auto row = [&](int yy) {
+        const float* r = p + (long)yy * W;
+        const f32x4 c = *(const f32x4*)(r + x);
+        const float l = r[xm], rr = r[xp];
+        return f32x4{wl[0] * l + wc[0] * c.x + wr[0] * c.y, wl[1] * c.x + wc[1] * c.y + wr[1] * c.z,
+                     wl[2] * c.y + wc[2] * c.z + wr[2] * c.w, wl[3] * c.z + wc[3] * c.w + wr[3] * rr};
+    };
+    const f32x4 a = row(y0), b = row(y), c = row(y2);
+    *(f32x4*)(out + (q / ((long)(W / 4) * H)) * ((long)H * W) + (long)y * W + x) = yl * a + yc * b + yr * c;
 }
 
 // bilinear x2, align_corners=False: out[2m] = .25 in[m-1] + .75 in[m] (m = 0: in[0]); out[2m+1] = .75 in[m] + .25 in[m+1]
@@ -508,7 +520,7 @@ static int check_up_weights(const GnrUpsampleWeights* w, int n_blocks) {
 static void up_rgb(const float* in, float* tmp, float* out, int batch, int S, hipStream_t st) {
     const long planes = (long)batch * 3;
     hipLaunchKernelGGL(bilinear2x_kernel, dim3(blocks_for(planes * 4L * S * S)), dim3(256), 0, st, in, tmp, planes, S, S);
-    hipLaunchKernelGGL(blur_kernel, dim3(blocks_for(planes * 4L * S * S)), dim3(256), 0, st, tmp, out, planes, 2 * S, 2 * S, 0);
+    hipLaunchKernelGGL(blur_kernel, dim3(blocks_for(planes * 4L * S * S / 4)), dim3(256), 0, st, tmp, out, planes, 2 * S, 2 * S, 0);
 }
 
 }  // namespace gnr
@@ -565,7 +577,7 @@ int gnr_upsample_fwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, f
         g.res = net; g.res_batch = (long)C * P; g.sign_out = s.sign2[i]; g.sign_batch = (long)C * P;
         launch_gemm(g, B, s.pack, st);
         // v = blur(u)
-        hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * C * 4 * P)), dim3(256), 0, st, s.u, s.v[i], (long)B * C, 2 * S,
+        hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * C * P)), dim3(256), 0, st, s.u, s.v[i], (long)B * C, 2 * S,
                            2 * S, 0);
         // net' = lrelu(Wf v + bf)
         g = GemmParams{};
@@ -623,7 +635,7 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
         // the RGB branch at this resolution: rgb_i = up(rgb_{i-1}) + conv(net') ...; undo the up() that FOLLOWED block i
         if (i < nb - 1) {
             // drgb currently is at side 4S (block i+1's resolution): adjoint of blur o bilinear
-            hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * 3 * 16 * P)), dim3(256), 0, st, drgb, drgb_tmp, (long)B * 3, 4 * S,
+            hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * 3 * 4 * P)), dim3(256), 0, st, drgb, drgb_tmp, (long)B * 3, 4 * S,
                                4 * S, 1);
             hipLaunchKernelGGL(bilinear2x_adj_kernel, dim3(blocks_for((long)B * 3 * P4)), dim3(256), 0, st, drgb_tmp, drgb, (long)B * 3,
                                2 * S, 2 * S);
@@ -645,7 +657,7 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
         g.M = C; g.K = Cn; g.N = (int)P4;
         launch_gemm(g, B, s.pack, st);                                           // other = dv
         // du = blur^T dv  (into dhid's buffer)
-        hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * C * P4)), dim3(256), 0, st, other, dhid, (long)B * C, 2 * S, 2 * S, 1);
+        hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * C * P)), dim3(256), 0, st, other, dhid, (long)B * C, 2 * S, 2 * S, 1);
         float* du = dhid;
         // un-shuffle: dpre2 (-> other) and the residual part of d(net_in) (-> s.u, free in the backward)
         float* dpre2 = other;
@@ -680,7 +692,7 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
     {
         const int S = d.side[0];
         const long P = (long)S * S;
-        hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * 3 * 4 * P)), dim3(256), 0, st, drgb, drgb_tmp, (long)B * 3, 2 * S, 2 * S, 1);
+        hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * 3 * P)), dim3(256), 0, st, drgb, drgb_tmp, (long)B * 3, 2 * S, 2 * S, 1);
         hipLaunchKernelGGL(bilinear2x_adj_kernel, dim3(blocks_for((long)B * 3 * P)), dim3(256), 0, st, drgb_tmp, drgb, (long)B * 3, S, S);
         if (G.rgb_w[0] || G.rgb_b[0]) {
             hipLaunchKernelGGL(rgb_conv_bwd_weight_kernel, dim3(d.ch[0] + 1, RGBW_SPLITS), dim3(256), 0, st, drgb, p->x, d.ch[0], P, B, t.colsum);
