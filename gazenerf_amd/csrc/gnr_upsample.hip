@@ -373,25 +373,35 @@ __global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void unshuffle_bwd_kernel(const float* __restrict__ du, const unsigned char* __restrict__ sign,
                                                             int C, int H, int W, int batch, float* __restrict__ dpre2,
                                                             float* __restrict__ dres) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     const long P = (long)H * W;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const long n2 = (long)batch * 4 * C * P, n1 = (long)batch * C * P;
-    auto G = [&](long b, int k, long p) {
-        const int c = k >> 2, i = (k >> 1) & 1, j = k & 1;
+    const long n1 = (long)batch * C * P;
+    if (idx < n1) {
+        // one out-channel c and pixel p: its 2x2 block of du is the four in-channels 4c..4c+3 (two 8-byte loads)
+        const long b = idx / ((long)C * P), rem = idx - b * (long)C * P;
+        const int c = (int)(rem / P);
+        const long p = rem - (long)c * P;
         const int y = (int)(p / W), x = (int)(p - (long)y * W);
-        return du[(b * C + c) * 4 * P + (long)(2 * y + i) * (2 * W) + 2 * x + j];
-    };
-    if (idx < n2) {
-        const long b = idx / (4L * C * P), rem = idx - b * 4L * C * P;
-        const int k = (int)(rem / P);
-        const long p = rem - (long)k * P;
-        dpre2[idx] = G(b, k, p) * (((sign[(b * C + (k >> 2)) * P + p] >> (k & 3)) & 1) ? 1.0f : LEAK);
-    } else if (idx < n2 + n1) {
-        const long e = idx - n2;
+        const float* src = du + (b * C + c) * 4 * P + (long)(2 * y) * (2 * W) + 2 * x;
+        const f32x2 top = *(const f32x2*)src, bot = *(const f32x2*)(src + 2 * W);
+        const unsigned nib = sign[idx];
+        float* dst = dpre2 + (b * 4 * C + 4 * c) * P + p;
+        dst[0] = top.x * ((nib & 1) ? 1.0f : LEAK);
+        dst[P] = top.y * ((nib & 2) ? 1.0f : LEAK);
+        dst[2 * P] = bot.x * ((nib & 4) ? 1.0f : LEAK);
+        dst[3 * P] = bot.y * ((nib & 8) ? 1.0f : LEAK);
+    } else if (idx < 2 * n1) {
+        // x.repeat adjoint: d(x)(b,c,p) = sum_q G(b, c + q C, p), G(b, k, p) = du(b, k>>2, 2y + ((k>>1)&1), 2x + (k&1))
+        const long e = idx - n1;
         const long b = e / ((long)C * P), rem = e - b * (long)C * P;
         const int c = (int)(rem / P);
         const long p = rem - (long)c * P;
-        dres[e] = (G(b, c, p) + G(b, c + C, p)) + (G(b, c + 2 * C, p) + G(b, c + 3 * C, p));
+        const int y = (int)(p / W), x = (int)(p - (long)y * W);
+        auto G = [&](int k) {
+            return du[(b * C + (k >> 2)) * 4 * P + (long)(2 * y + ((k >> 1) & 1)) * (2 * W) + 2 * x + (k & 1)];
+        };
+        dres[e] = (G(c) + G(c + C)) + (G(c + 2 * C) + G(c + 3 * C));
     }
 }
 
@@ -662,7 +672,7 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
         // un-shuffle: dpre2 (-> other) and the residual part of d(net_in) (-> s.u, free in the backward)
         float* dpre2 = other;
         float* dnet = s.u;
-        hipLaunchKernelGGL(unshuffle_bwd_kernel, dim3(blocks_for((long)B * 5 * C * P)), dim3(256), 0, st, du, s.sign2[i], C, S, S, B, dpre2,
+        hipLaunchKernelGGL(unshuffle_bwd_kernel, dim3(blocks_for((long)B * 2 * C * P)), dim3(256), 0, st, du, s.sign2[i], C, S, S, B, dpre2,
                            dnet);
         // layer_2: dW2 = dpre2 a1^T, db2; dpre1 = (W2^T dpre2) * lrelu'(a1)  (-> du's buffer)
         launch_wgrad_img(dpre2, 4 * C, 4 * C, s.a1[i], 2 * C, 2 * C, B, P, G.up2_w[i], 2 * C, t.colsum, 4 * C + 128, t.wg, st);
