@@ -1,24 +1,19 @@
-// gnr_fwd3.hip -- inference forward with the dense layers on bf16 MFMA via a 3-term split ("bf16x3").
+// gnr_fwd3.hip -- the fused forward (inference and training variants) with the dense layers on bf16 MFMA via a
+// 3-term split ("bf16x3"); building blocks and the arithmetic in gnr_chain3.h.
 //
-// Every fp32 operand x is split x = hi + lo (+ ~2^-17 |x|) with hi = bf16(x), lo = bf16(x - hi), and
-//     a * b  ~=  a_hi b_hi + a_lo b_hi + a_hi b_lo          (fp32 accumulate in the MFMA)
-// i.e. three v_mfma_f32_32x32x16_bf16 (32 matrix-pipe cycles each, 16 k per instruction) instead of
-// eight v_mfma_f32_32x32x2_f32 (64 cycles each): 5.3x the fp32-MFMA rate at ~16 mantissa bits per
-// operand.  Measured against the reference fixtures (emulation in tools, kernels in
-// tests/test_parity_gpu.py): feature map 2e-7 .. 6e-6, bg_alpha <= 3.1e-5 even with the x50 opaque
-// density head -- the same order as the fp32 path's own rounding noise and well inside the 1e-4
-// contract, whereas plain bf16 is off by 1.5e-2.  SURVEY.md section 7 lists this split as the
-// sanctioned "later, measured optimisation"; the fp32 path stays the default.
+// Accuracy (tests/test_parity_gpu.py): against the reference run in fp64 these kernels are as
+// close to the exact result as the reference's own fp32 arithmetic; against its fp32 output the feature map stays
+// within the 1e-4 contract (2e-7 .. 6e-6 on the fixtures), whereas plain bf16 is off by 1.5e-2.  SURVEY.md section 7
+// lists this split as the sanctioned "later, measured optimisation"; the exact-fp32 kernels stay the default.
 //
 // Structure (differences from gnr_fwd.hip):
-//   * a layer's output stays in registers as RAW fp32 accumulators; the NEXT layer converts one
-//     32-channel input tile at a time (bias + ReLU + hi/lo split + bf16 pack: 16 registers), spread
-//     between its own MFMA batches -- the conversion never stalls the matrix pipe as a block, and only
-//     one converted tile (+ the one being built) is live, which frees ~170 registers;
-//   * those registers hold a deeper weight prefetch: bf16x3 consumes 2 KiB of weights (hi + lo rows)
-//     per 96 matrix-pipe cycles, 5x the fp32 kernel's rate;
-//   * the density head is still an fp32 VALU dot (folded into the conversion of h7); ray geometry,
-//     encoding (fp32 sincosf, then split), compositing and combine are shared with the fp32 path.
+//   * a layer's output stays in registers as RAW fp32 accumulators that were started from the bias; the NEXT layer
+//     converts one 32-channel input tile at a time (ReLU / sign bits / dump, hi/lo split, bf16 pack: 16 registers),
+//     spread between its own MFMA groups, so only one converted tile and the one being built are live;
+//   * the weight stream ([hi][lo] rows of 2 KiB, 2 KiB per 96 matrix-pipe cycles per wave) is fetched once per
+//     workgroup into an LDS ring by LDS-DMA and read from there by all four waves (one barrier per 4 rows);
+//   * the density head is still an fp32 VALU dot (folded into the conversion of h7); ray geometry, encoding (fp32
+//     sincosf, then split), compositing and combine are shared with the fp32 path.
 #include "gnr_chain3.h"
 
 namespace gnr {
