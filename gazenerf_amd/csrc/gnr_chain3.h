@@ -45,10 +45,12 @@ __host__ __device__ inline int dlayout3_channel(int step16, int h, int q) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// weight ring: the workgroup's four waves consume the SAME rows, so the stream goes through LDS once
-// per workgroup instead of four times through the vector L1 (which at 2 KiB per 96 matrix-pipe cycles
-// per wave is past the 64 B/clk the texture path delivers).  LDS-DMA (buffer_load_dwordx4 ... lds)
-// fills a ring of NSLOT batches of RB_ROWS rows; wave w fetches row w of each batch (2 KiB = 2 pieces).
+// weight ring: the workgroup's four waves consume the SAME rows, so the stream goes through LDS once per
+// workgroup instead of four times through the vector L1.  (The first version, every wave loading every row into
+// a 48-register ring, ran at the same speed -- what costs is issuing memory instructions, tools/ubench/feed_cost.hip
+// -- but needed 107 spilled registers; the ring in LDS leaves 3, a quarter of the L1 traffic, and room for the
+// training variants' extra state.)  LDS-DMA (buffer_load_dwordx4 ... lds) fills a ring of NSLOT batches of
+// RB_ROWS rows; wave w fetches row w of each batch (2 KiB = 2 pieces).
 //
 // Per batch k ("phase"), every wave:
 //   s_waitcnt vmcnt(2 (DEPTH-1))   its own share of batch k+1 has landed
