@@ -13,7 +13,8 @@ LIB_PATH = os.path.join(HERE, "libgnr.so")
 N_TRUNK = 8
 N_RGB = 3
 WS_FWD, WS_FWD_SAVE, WS_BWD = 0, 1, 2
-ABI_VERSION = 1
+STAGE_FWD_MLP, STAGE_DGRAD, STAGE_COMP_BWD, STAGE_WGRAD = 0, 1, 2, 3
+ABI_VERSION = 2
 
 _p = C.c_void_p
 
@@ -25,7 +26,7 @@ class GnrProblem(C.Structure):
                 ("world_z1", C.c_float), ("world_z2", C.c_float),
                 ("xy", _p), ("R", _p), ("T", _p), ("Kinv", _p),
                 ("shape_code", _p), ("gaze", _p), ("appea_code", _p),
-                ("t_rand", _p), ("z_edges", _p)]
+                ("t_rand", _p), ("z_edges", _p), ("edges_follow_T", C.c_int32)]
 
 
 class GnrWeights(C.Structure):
@@ -73,10 +74,14 @@ class GnrInputGrads(C.Structure):
     _fields_ = [("R", _p), ("T", _p), ("shape_code", _p), ("gaze", _p), ("appea_code", _p)]
 
 
-EXPORTS = ("gnr_abi_version", "gnr_workspace_bytes", "gnr_fwd", "gnr_fwd_bf16x3", "gnr_bwd", "gnr_bwd_bf16x3", "gnr_resample",
-           "gnr_sample_zvals", "gnr_set_kernel_timing", "gnr_set_aux_timing", "gnr_merge_scratch_bytes",
+EXPORTS = ("gnr_abi_version", "gnr_sizeof", "gnr_workspace_bytes", "gnr_fwd", "gnr_fwd_bf16x3", "gnr_bwd", "gnr_bwd_bf16x3", "gnr_resample",
+           "gnr_sample_zvals", "gnr_set_kernel_timing", "gnr_set_aux_timing", "gnr_set_stage_timing", "gnr_merge_scratch_bytes",
            "gnr_merge_fwd", "gnr_merge_bwd", "gnr_upsample_workspace_bytes", "gnr_upsample_fwd", "gnr_upsample_bwd",
            "gnr_last_error")
+
+# order == the GNR_SIZEOF_* ids of include/gnr.h
+STRUCTS = (GnrProblem, GnrWeights, GnrOutputs, GnrOutputGrads, GnrInputGrads, GnrMergeProblem, GnrUpsampleProblem,
+           GnrUpsampleWeights)
 
 _lib = None
 
@@ -130,10 +135,18 @@ def load():
                                      C.POINTER(GnrUpsampleWeightGrads), _p, C.c_size_t, _p, C.c_size_t, _p]
     lib.gnr_merge_bwd.restype = C.c_int
     lib.gnr_merge_bwd.argtypes = [C.POINTER(GnrMergeProblem)] + [_p] * 10 + [C.c_size_t, _p]
+    lib.gnr_set_stage_timing.restype = C.c_int
+    lib.gnr_set_stage_timing.argtypes = [C.c_int, _p, _p]
     lib.gnr_set_aux_timing.restype = C.c_int
     lib.gnr_set_aux_timing.argtypes = [_p, _p]
     if lib.gnr_abi_version() != ABI_VERSION:
         raise RuntimeError("libgnr.so ABI %d != binding ABI %d; rebuild" % (lib.gnr_abi_version(), ABI_VERSION))
+    lib.gnr_sizeof.restype = C.c_size_t
+    lib.gnr_sizeof.argtypes = [C.c_int]
+    for which, cls in enumerate(STRUCTS):
+        if lib.gnr_sizeof(which) != C.sizeof(cls):
+            raise RuntimeError("libgnr.so: sizeof(%s) is %d in the library, %d in the ctypes binding" % (
+                cls.__name__, lib.gnr_sizeof(which), C.sizeof(cls)))
     _lib = lib
     return lib
 

@@ -19,7 +19,10 @@ size_t bwd_scratch_bytes(const GnrProblem* p, int n_streams);
 
 static thread_local std::string g_err;
 // measurement hooks: process-wide on purpose (see include/gnr.h)
-std::atomic<hipEvent_t> g_ev_start{nullptr}, g_ev_stop{nullptr}, g_aux_start{nullptr}, g_aux_stop{nullptr};
+std::atomic<hipEvent_t> g_stage_ev[GNR_N_STAGES][2];
+void stage_mark(int stage, int which, hipStream_t st) {
+    if (hipEvent_t e = g_stage_ev[stage][which].load()) (void)hipEventRecord(e, st);
+}
 
 int fail(const char* fmt, ...) {
     char buf[512];
@@ -115,16 +118,32 @@ int gnr_abi_version(void) { return GNR_ABI_VERSION; }
 
 const char* gnr_last_error(void) { return g_err.c_str(); }
 
-int gnr_set_aux_timing(void* ev_start, void* ev_stop) {
-    g_aux_start = (hipEvent_t)ev_start;
-    g_aux_stop = (hipEvent_t)ev_stop;
+size_t gnr_sizeof(int which) {
+    switch (which) {
+        case GNR_SIZEOF_PROBLEM: return sizeof(GnrProblem);
+        case GNR_SIZEOF_WEIGHTS: return sizeof(GnrWeights);
+        case GNR_SIZEOF_OUTPUTS: return sizeof(GnrOutputs);
+        case GNR_SIZEOF_OUTPUT_GRADS: return sizeof(GnrOutputGrads);
+        case GNR_SIZEOF_INPUT_GRADS: return sizeof(GnrInputGrads);
+        case GNR_SIZEOF_MERGE_PROBLEM: return sizeof(GnrMergeProblem);
+        case GNR_SIZEOF_UPSAMPLE_PROBLEM: return sizeof(GnrUpsampleProblem);
+        case GNR_SIZEOF_UPSAMPLE_WEIGHTS: return sizeof(GnrUpsampleWeights);
+        default: return 0;
+    }
+}
+
+int gnr_set_stage_timing(int stage, void* ev_start, void* ev_stop) {
+    if (stage < 0 || stage >= GNR_N_STAGES) return fail("gnr_set_stage_timing: unknown stage %d", stage);
+    g_stage_ev[stage][0] = (hipEvent_t)ev_start;
+    g_stage_ev[stage][1] = (hipEvent_t)ev_stop;
     return 0;
 }
 
+int gnr_set_aux_timing(void* ev_start, void* ev_stop) { return gnr_set_stage_timing(GNR_STAGE_COMP_BWD, ev_start, ev_stop); }
+
 int gnr_set_kernel_timing(void* ev_start, void* ev_stop) {
-    g_ev_start = (hipEvent_t)ev_start;
-    g_ev_stop = (hipEvent_t)ev_stop;
-    return 0;
+    gnr_set_stage_timing(GNR_STAGE_FWD_MLP, ev_start, ev_stop);
+    return gnr_set_stage_timing(GNR_STAGE_DGRAD, ev_start, ev_stop);
 }
 
 size_t gnr_workspace_bytes(const GnrProblem* p, int n_streams, int kind) {
@@ -158,10 +177,10 @@ static int fwd_impl(const GnrProblem* p, const GnrWeights* face, const GnrWeight
     const GnrWeights* ws_in[2] = {face, eyes};
     launch_prep(*p, n_streams, ws_in, fp.ws, st, !bf16x3);
     if (bf16x3) launch_prep3(*p, n_streams, ws_in, fp.ws, st);
-    if (hipEvent_t e0 = g_ev_start.load()) (void)hipEventRecord(e0, st);
+    stage_mark(GNR_STAGE_FWD_MLP, 0, st);
     if (bf16x3) launch_fwd3(fp, st);
     else launch_fwd(fp, st);
-    if (hipEvent_t e1 = g_ev_stop.load()) (void)hipEventRecord(e1, st);
+    stage_mark(GNR_STAGE_FWD_MLP, 1, st);
 
     CombineParams cp{};
     cp.prob = *p;

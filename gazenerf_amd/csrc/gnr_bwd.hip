@@ -23,7 +23,7 @@ void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb,
                   long chunks_per_image, float* dW, int ldw, int col_off, int enc_map, float* colsum_out,
                   int colsum_ld, const float* vec, float* vec_out, float* scratch, hipStream_t stream, bool bf16x3);
 void launch_vecsum(const float* v, int batch, long per_image, float* out, int out_stride, hipStream_t stream);
-extern std::atomic<hipEvent_t> g_ev_start, g_ev_stop, g_aux_start, g_aux_stop;
+void stage_mark(int stage, int which, hipStream_t st);
 
 __global__ void packT_kernel(const PackTParams pp) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < PACKEDT_FLOATS;
@@ -348,8 +348,9 @@ __global__ __launch_bounds__(256) void geo_kernel(const GeoParams gp) {
         v[3] = duy * v0; v[4] = duy * v1; v[5] = duy * v2;
         v[6] = duz * v0; v[7] = duz * v1; v[8] = duz * v2;
         v[9] = A0; v[10] = A1;
-        // z edges move with T_z (plane sweep and its jitter): dpts/dT_z += m ; explicit edges do not
-        v[11] = A2 + (p.z_edges ? 0.0f : (mx * A0 + my * A1 - A2));
+        // z edges move with T_z (plane sweep, its jitter, FineSample's merged edges): dpts/dT_z += m, i.e.
+        // dT_z = m . A (m_z = -1); explicit constant edges (edges_follow_T == 0): dT_z = A2
+        v[11] = A2 + ((p.z_edges && !p.edges_follow_T) ? 0.0f : (mx * A0 + my * A1 - A2));
     }
 #pragma unroll
     for (int k = 0; k < 12; ++k) red[k][tid] = v[k];
@@ -532,9 +533,9 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         cb.prob = *p; cb.chunks_per_ray = cpr; cb.gT = sc.gT; cb.g_bg = dout->bg_alpha[s];
         cb.act_feat = ws.act_feat; cb.sigma_raw = ws.sigma_raw; cb.delta = fp.delta;
         cb.wglob = sc.wglob; cb.dsig = sc.dsig; cb.csum = sc.csum; cb.dsig_ray = sc.dsig_ray; cb.accumulate = s > 0;
-        if (hipEvent_t e = g_aux_start.load(); e && s == 0) (void)hipEventRecord(e, st);
+        if (s == 0) stage_mark(GNR_STAGE_COMP_BWD, 0, st);
         hipLaunchKernelGGL(comp_bwd_kernel, dim3((unsigned)((n_rays_total + 3) / 4)), dim3(256), 0, st, cb);
-        if (hipEvent_t e = g_aux_stop.load(); e && s == 0) (void)hipEventRecord(e, st);
+        if (s == 0) stage_mark(GNR_STAGE_COMP_BWD, 1, st);
         // 3. transposed weight stream
         PackTParams pt{};
         auto setl = [&](int l, const float* wp, int ld, int n_valid, int col0, int k_valid, int enc) {
@@ -562,13 +563,13 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         bp.relu_bits = ws.relu_bits; bp.enc = fp.enc; bp.zval = fp.zval;
         bp.dY_h = sc.dY_h; bp.dY_r0 = sc.dY_r0; bp.dY_r1 = sc.dY_r1; bp.dfeat = sc.dfeat;
         bp.geo_chunk = sc.geo_chunk; bp.accumulate_geo = s > 0;
-        if (hipEvent_t e = g_ev_start.load(); e && s == 0) (void)hipEventRecord(e, st);
+        if (s == 0) stage_mark(GNR_STAGE_DGRAD, 0, st);
         if (bf16x3)
             launch_bwd3_chain(bp, st);
         else
             hipLaunchKernelGGL(bwd_chain_kernel, dim3((unsigned)((fp.n_chunks + WAVES_PER_WG - 1) / WAVES_PER_WG)),
                                dim3(256), 0, st, bp);
-        if (hipEvent_t e = g_ev_stop.load(); e && s == 0) (void)hipEventRecord(e, st);
+        if (s == 0) stage_mark(GNR_STAGE_DGRAD, 1, st);
 
         // 5. weight gradients dW = dY^T X; the same kernels emit the per-image column sums of dY
         //    (bias / latent gradients) and, for RGB_layer_0, the density-head gradient dsig^T h7.
@@ -577,6 +578,7 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         auto dyh = [&](int l) { return sc.dY_h + (size_t)l * M * H; };
         auto dbl = [&](int l) { return sc.dbias + (size_t)l * p->batch * H; };
         const long cpi = (long)p->n_rays * cpr;                       // chunks per image
+        if (s == 0) stage_mark(GNR_STAGE_WGRAD, 0, st);
         launch_wgrad(sc.dfeat, FEAT_PAD, p->feat_nc, ws.act_y1, H2, H2, p->batch, cpi, DW.rgb_w[2], H2, 0, 0,
                      dbl(LR2), H, nullptr, nullptr, sc.wg_part, st, bf16x3);
         launch_wgrad(sc.dY_r1, H2, H2, ws.act_y0, H, H, p->batch, cpi, DW.rgb_w[1], H + p->appea_dims, 0, 0,
@@ -597,6 +599,7 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         }
         launch_wgrad(dyh(0), H, H, fp.enc, ENC_PAD, ENC_PAD, p->batch, cpi, DW.fea_w[0], vp, 0, 1, dbl(0), H,
                      nullptr, nullptr, sc.wg_part, st, bf16x3);
+        if (s == 0) stage_mark(GNR_STAGE_WGRAD, 1, st);
         launch_vecsum(sc.dsig_ray, p->batch, p->n_rays, dbl(N_CHAIN), H, st);
 
         // 6. latent gradients from the per-image bias sums

@@ -180,13 +180,9 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel(const FwdParams fp) {
 
 void launch_fwd(const FwdParams& fp, hipStream_t stream) {
     const unsigned grid = (unsigned)((fp.n_chunks + WAVES_PER_WG - 1) / WAVES_PER_WG);
-    // 98 KiB of dynamic LDS (> the 64 KiB default): opt in once per process
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_LDS_BYTES);
-        attr_set = true;
-    }
+    // > 64 KiB of dynamic LDS needs an opt-in per device: set it on every launch (cheap, and correct for
+    // several devices / threads per process -- a process-wide 'done' flag would not be)
+    (void)hipFuncSetAttribute((const void*)(fp.save ? fwd_kernel<true> : fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_LDS_BYTES);
     if (fp.save)
         hipLaunchKernelGGL(fwd_kernel<true>, dim3(grid), dim3(256), FWD_LDS_BYTES, stream, fp);
     else

@@ -251,12 +251,9 @@ void launch_prep3(const GnrProblem& p, int n_streams, const GnrWeights* const* w
 
 void launch_fwd3(const FwdParams& fp, hipStream_t stream) {
     const unsigned grid = (unsigned)((fp.n_chunks + WAVES_PER_WG - 1) / WAVES_PER_WG);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)fwd3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD3_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)fwd3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD3_LDS_BYTES);
-        attr_set = true;
-    }
+    // > 64 KiB of dynamic LDS needs an opt-in per device: set it on every launch (cheap, and correct for
+    // several devices / threads per process -- a process-wide 'done' flag would not be)
+    (void)hipFuncSetAttribute((const void*)(fp.save ? fwd3_kernel<true> : fwd3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD3_LDS_BYTES);
     if (fp.save)
         hipLaunchKernelGGL(fwd3_kernel<true>, dim3(grid), dim3(256), FWD3_LDS_BYTES, stream, fp);
     else

@@ -1,18 +1,69 @@
-"""HIP-event timing of the dominant kernel inside gnr_fwd / gnr_bwd (bench and tests only).
+"""HIP-event timing of single stages inside gnr_fwd / gnr_bwd (bench and tests only).
 
 torch.cuda.Event brackets whole calls; to time ONE kernel inside a C-ABI call the events are
-created with the HIP runtime directly and handed to libgnr (gnr_set_kernel_timing), which records
-them on the launch stream right around that kernel."""
+created with the HIP runtime directly and handed to libgnr (gnr_set_stage_timing), which records
+them on the launch stream right around that stage.
+
+``StageTimer`` owns a pool of event pairs: ``arm()`` hands the next free pair to the library, nothing
+is synchronised while work is being enqueued, and ``collect()`` reads every pair after the caller's
+final ``torch.cuda.synchronize()`` -- so timing adds no host-sync bubbles to the timed region."""
 from __future__ import annotations
 
 import ctypes as C
+from typing import List
 
 from . import _lib
 
+STAGES = {"fwd_mlp": _lib.STAGE_FWD_MLP, "dgrad": _lib.STAGE_DGRAD, "comp_bwd": _lib.STAGE_COMP_BWD,
+          "wgrad": _lib.STAGE_WGRAD}
+
+
+class StageTimer:
+    def __init__(self, stage: str, pool: int = 64):
+        self.stage = STAGES[stage]
+        self.hip = C.CDLL("libamdhip64.so")
+        self.lib = _lib.load()
+        self.pairs = []
+        for _ in range(pool):
+            a, b = C.c_void_p(), C.c_void_p()
+            assert self.hip.hipEventCreate(C.byref(a)) == 0 and self.hip.hipEventCreate(C.byref(b)) == 0
+            self.pairs.append((a, b))
+        self.used = 0
+        self.keep = False
+
+    def reset(self, keep: bool):
+        """keep=False (warm-up): arm() re-uses pair 0 and collect() returns nothing."""
+        self.used, self.keep = 0, keep
+
+    def arm(self):
+        """Give the library the next event pair; the next call that runs this stage records it."""
+        i = self.used if self.keep else 0
+        if i >= len(self.pairs):                      # pool exhausted: keep timing the last pair
+            i = len(self.pairs) - 1
+        elif self.keep:
+            self.used += 1
+        a, b = self.pairs[i]
+        self.lib.gnr_set_stage_timing(self.stage, a, b)
+
+    def disarm(self):
+        self.lib.gnr_set_stage_timing(self.stage, None, None)
+
+    def collect(self) -> List[float]:
+        """Milliseconds of every recorded pair.  Call after torch.cuda.synchronize()."""
+        self.disarm()
+        out = []
+        for a, b in self.pairs[:self.used]:
+            if self.hip.hipEventQuery(b) != 0:
+                continue                               # never recorded (stage did not run)
+            ms = C.c_float()
+            if self.hip.hipEventElapsedTime(C.byref(ms), a, b) == 0:
+                out.append(float(ms.value))
+        return out
+
 
 class KernelTimer:
-    """aux=False: the dominant kernel (gnr_set_kernel_timing); aux=True: the HBM-bound compositing
-    pass of gnr_bwd (gnr_set_aux_timing)."""
+    """One event pair, synchronous read-out (tests and small tools).  aux=False: the fused MLP kernel of gnr_fwd /
+    the dgrad chain of gnr_bwd (gnr_set_kernel_timing); aux=True: the compositing backward (gnr_set_aux_timing)."""
 
     def __init__(self, aux: bool = False):
         self.aux = aux

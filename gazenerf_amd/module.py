@@ -67,8 +67,10 @@ class HotPathRenderer(nn.Module):
     def __init__(self, num_sample_coarse: int = 64, num_sample_fine: int = 128, world_z1: float = 2.5,
                  world_z2: float = -3.5, hidden: int = 384, featmap_nc: int = 258,
                  shape_dims: int = synth.SHAPE_DIMS, gaze_dims: int = synth.GAZE_DIMS,
-                 appea_dims: int = synth.APPEA_DIMS, hier_sampling: bool = False, precision: str = "fp32"):
+                 appea_dims: int = synth.APPEA_DIMS, hier_sampling: bool = False, precision: str = "fp32",
+                 ws_budget_bytes: Optional[int] = None):
         super().__init__()
+        self.ws_budget_bytes = ws_budget_bytes      # None == render.DEFAULT_WS_BUDGET; see render_two_stream
         if precision not in ("fp32", "bf16x3"):
             raise ValueError("precision must be 'fp32' or 'bf16x3'")
         self.precision = precision
@@ -94,7 +96,8 @@ class HotPathRenderer(nn.Module):
             batch_xy, batch_Rmats, batch_Tvecs, batch_inv_inmats, shape_code, gaze_code, appea_code,
             self.fg_CD_predictor_face.param_list(), self.fg_CD_predictor_eyes.param_list(),
             n_samples=n_p, world_z1=self.world_z1, world_z2=self.world_z2, t_rand=t_rand,
-            return_weights=want_w, hidden=self.hidden, feat_nc=self.featmap_nc, precision=self.precision)
+            return_weights=want_w, hidden=self.hidden, feat_nc=self.featmap_nc, precision=self.precision,
+            ws_budget_bytes=self.ws_budget_bytes)
         if self.hier_sampling:
             zv = R_.sample_zvals(batch_xy, batch_Rmats.detach(), batch_Tvecs.detach(), batch_inv_inmats,
                                  n_samples=n_p, world_z1=self.world_z1, world_z2=self.world_z2, t_rand=t_rand)
@@ -105,7 +108,9 @@ class HotPathRenderer(nn.Module):
                 batch_xy, batch_Rmats, batch_Tvecs, batch_inv_inmats, shape_code, gaze_code, appea_code,
                 self.fine_fg_CD_predictor.param_list(), None,
                 n_samples=n_p + self.num_sample_fine, world_z1=self.world_z1, world_z2=self.world_z2,
-                z_edges=edges, hidden=self.hidden, feat_nc=self.featmap_nc, precision=self.precision)
+                z_edges=edges, edges_follow_T=True,       # FineSample detaches only the weights (model_utils.py:418)
+                hidden=self.hidden, feat_nc=self.featmap_nc, precision=self.precision,
+                ws_budget_bytes=self.ws_budget_bytes)
             out["feat_fine"], out["bg_alpha_fine"] = fine["feat_face"], fine["bg_alpha_face"]
             out["fine_edges"] = edges
         return out

@@ -52,40 +52,79 @@ def gather_rays(local: torch.Tensor, n_rays: int, world: int) -> torch.Tensor:
 class GradAllReducer:
     """Sum-all-reduce (then average) of the .grad of `params` in flat buckets.
 
-    bucket_numel defaults to one MLP stream (1 518 979 floats, 6 MB): two buckets for the two
-    streams, so the first can be in flight while the caller still works on the second."""
+    ``params`` may be a flat sequence (cut into buckets of >= bucket_numel elements: by default one MLP stream,
+    1 518 979 floats = 6 MB) or a list of lists (explicit buckets).  xGMI is point-to-point, a ring all-reduce is
+    per-link bound and small messages only pay latency: few flat buckets, not one message per tensor.
 
-    def __init__(self, params: Sequence[torch.Tensor], world_size: int, bucket_numel: int = 1518979,
-                 average: bool = True):
-        self.params: List[torch.Tensor] = list(params)
+    Overlap: ``arm_overlap()`` registers post-accumulate-grad hooks; a bucket whose gradients are all written is
+    flattened and its all-reduce launched at once on the communication stream, while the autograd engine is still
+    working on the layers before it (in the whole network: the NeuralRenderer bucket flies during the hot path's
+    backward).  The two MLP buckets come out of ONE gnr_bwd call together, so they start back to back at its end:
+    there is nothing left to overlap them with.  ``all_reduce()`` launches whatever has not been launched, waits,
+    and writes the averaged gradients back.  ``bytes_per_step`` / ``n_buckets`` describe the exchange."""
+
+    def __init__(self, params, world_size: int, bucket_numel: int = 1518979, average: bool = True):
         self.world = world_size
         self.average = average
         self.buckets: List[List[torch.Tensor]] = []
-        cur, n = [], 0
-        for p in self.params:
-            cur.append(p)
-            n += p.numel()
-            if n >= bucket_numel:
+        params = list(params)
+        if params and isinstance(params[0], (list, tuple)):
+            self.buckets = [list(b) for b in params if len(b)]
+        else:
+            cur, n = [], 0
+            for p in params:
+                cur.append(p)
+                n += p.numel()
+                if n >= bucket_numel:
+                    self.buckets.append(cur)
+                    cur, n = [], 0
+            if cur:
                 self.buckets.append(cur)
-                cur, n = [], 0
-        if cur:
-            self.buckets.append(cur)
+        self.params: List[torch.Tensor] = [p for b in self.buckets for p in b]
+        self.n_buckets = len(self.buckets)
+        self.bytes_per_step = sum(p.numel() for p in self.params) * 4
+        self._inflight = {}
+        self._pending = None
+        self._hooks = []
 
+    # -- overlap -------------------------------------------------------------------------------------------
+    def arm_overlap(self):
+        """Launch a bucket's all-reduce from autograd hooks as soon as its last gradient has been accumulated."""
+        if self.world == 1 or self._hooks:
+            return
+        self._pending = [len(b) for b in self.buckets]
+        for bi, bucket in enumerate(self.buckets):
+            for p in bucket:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+
+    def _make_hook(self, bi):
+        def hook(_param):
+            self._pending[bi] -= 1
+            if self._pending[bi] == 0:
+                self._launch(bi)
+        return hook
+
+    def _launch(self, bi):
+        import torch.distributed as dist
+        bucket = self.buckets[bi]
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        self._inflight[bi] = (dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat)
+
+    # -- the exchange --------------------------------------------------------------------------------------
     def all_reduce(self):
         if self.world == 1:
             return
-        import torch.distributed as dist
-        works = []
-        for bucket in self.buckets:
-            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
-            flat = torch.cat([g.reshape(-1) for g in grads])
-            works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, bucket))
-        for work, flat, bucket in works:
+        for bi in range(self.n_buckets):
+            if bi not in self._inflight:
+                self._launch(bi)
+        for bi in range(self.n_buckets):
+            work, flat = self._inflight.pop(bi)
             work.wait()
             if self.average:
                 flat.div_(self.world)
             off = 0
-            for p in bucket:
+            for p in self.buckets[bi]:
                 n = p.numel()
                 g = flat[off:off + n].view_as(p)
                 if p.grad is None:
@@ -93,3 +132,5 @@ class GradAllReducer:
                 else:
                     p.grad.copy_(g)
                 off += n
+        if self._pending is not None:
+            self._pending = [len(b) for b in self.buckets]

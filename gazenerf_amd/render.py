@@ -20,6 +20,7 @@ PyTorch here is plumbing: it owns the device buffers and the stream.  All inputs
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional, Sequence
 
 import torch
@@ -99,7 +100,7 @@ class _Problem:
     """Validated, contiguous inputs + the ctypes GnrProblem that points at them."""
 
     def __init__(self, xy, R, T, Kinv, shape_code, gaze, appea_code, n_samples, world_z1, world_z2,
-                 t_rand, z_edges, hidden, feat_nc):
+                 t_rand, z_edges, hidden, feat_nc, edges_follow_T=False):
         _check_tensor("batch_xy", xy)
         if xy.dim() != 3 or xy.shape[1] != 2:
             raise ValueError("batch_xy must be [B,2,N_r], got %s" % (tuple(xy.shape),))
@@ -128,6 +129,7 @@ class _Problem:
         p.shape_code, p.gaze, p.appea_code = shape_code.data_ptr(), gaze.data_ptr(), appea_code.data_ptr()
         p.t_rand = t_rand.data_ptr() if t_rand is not None else None
         p.z_edges = z_edges.data_ptr() if z_edges is not None else None
+        p.edges_follow_T = 1 if (edges_follow_T and z_edges is not None) else 0
         self.c = p
         self.B, self.n_r, self.n_p = B, n_r, int(n_samples)
         self.device = xy.device
@@ -174,25 +176,94 @@ def _run_forward(prob: _Problem, streams, save: bool, want_depth: bool, want_wei
     return res, ws
 
 
+def _run_backward(prob: _Problem, streams, gout, saved_ws, bf16x3: bool):
+    """One gnr_bwd call.  ``gout``: per stream (d feat [B,C,N_r] | None, d bg_alpha [B,1,N_r] | None), contiguous
+    fp32.  Returns ([gR, gT, gshape, ggaze, gappea], [[24 parameter gradients] per stream])."""
+    lib = _lib.load()
+    dev = prob.device
+    n_streams = len(streams)
+    dout = _lib.GnrOutputGrads()
+    for s, (gf, ga) in enumerate(gout):
+        dout.feat[s] = gf.data_ptr() if gf is not None else None
+        dout.bg_alpha[s] = ga.data_ptr() if ga is not None else None
+    B = prob.B
+    gin = [torch.empty(B, 3, 3, device=dev), torch.empty(B, 3, 1, device=dev),
+           torch.empty(B, prob.c.shape_dims, device=dev), torch.empty(B, prob.c.gaze_dims, device=dev),
+           torch.empty(B, prob.c.appea_dims, device=dev)]
+    din = _lib.GnrInputGrads()
+    din.R, din.T, din.shape_code, din.gaze, din.appea_code = (t.data_ptr() for t in gin)
+    gparams = [[torch.empty_like(t) for t in streams[s]] for s in range(n_streams)]
+    dw = [_weights_struct(g, _lib.GnrWeightGrads) for g in gparams]
+    w = [_weights_struct(st) for st in streams]
+    with torch.cuda.device(dev):
+        nbytes = lib.gnr_workspace_bytes(C.byref(prob.c), n_streams, _lib.WS_BWD)
+        scratch = _alloc_ws(max(nbytes, 256), dev)
+        bwd = lib.gnr_bwd_bf16x3 if bf16x3 else lib.gnr_bwd
+        rc = bwd(C.byref(prob.c), C.byref(w[0]), C.byref(w[1]) if n_streams > 1 else None,
+                 C.byref(dout), C.byref(din), C.byref(dw[0]),
+                 C.byref(dw[1]) if n_streams > 1 else None,
+                 C.c_void_p(saved_ws.data_ptr()), saved_ws.numel(),
+                 C.c_void_p(scratch.data_ptr()), scratch.numel(), _stream_ptr(dev))
+        _lib.check(rc, lib)
+    return gin, gparams
+
+
+# Saved activations cost ~31.5 KB per sample (both streams): 16.5 GB at cfg3 (2 x 4096 rays x 64), 540 GB for one
+# 512 x 512-ray image.  Above this budget the op switches to ray tiles: the forward runs once without saving
+# (the faster inference kernel), the backward re-runs forward-with-save tile by tile and accumulates -- the same
+# recompute trade the reference would need torch.utils.checkpoint for.  GNR_WS_BUDGET_GB overrides the default.
+DEFAULT_WS_BUDGET = int(float(os.environ.get("GNR_WS_BUDGET_GB", "96")) * (1 << 30))
+_TILE_GRANULE = 256       # rays; tiles are multiples of this (a whole number of workgroups for any chunk count)
+
+
+def plan_ray_tiles(prob: "_Problem", n_streams: int, budget_bytes: Optional[int] = None,
+                   ray_tile: Optional[int] = None):
+    """None == the saved workspace of the whole problem fits the budget (no tiling); otherwise the tile size in
+    rays.  An explicit ``ray_tile`` forces tiling with that size."""
+    if ray_tile is not None:
+        if ray_tile < 1:
+            raise ValueError("ray_tile must be >= 1")
+        return None if ray_tile >= prob.n_r else int(ray_tile)
+    lib = _lib.load()
+    budget = DEFAULT_WS_BUDGET if budget_bytes is None else int(budget_bytes)
+    full = lib.gnr_workspace_bytes(C.byref(prob.c), n_streams, _lib.WS_FWD_SAVE)
+    if full == 0:
+        _lib.check(1, lib)
+    if full <= budget:
+        return None
+    per_ray = full / prob.n_r                         # the workspace is linear in rays up to fixed terms
+    tile = int(budget / per_ray) // _TILE_GRANULE * _TILE_GRANULE
+    return max(_TILE_GRANULE, min(tile, prob.n_r))
+
+
 class _RenderFn(torch.autograd.Function):
     """forward = gnr_fwd, backward = gnr_bwd.  Inputs: 5 differentiable problem tensors, then
-    24 * n_streams parameter tensors; non-differentiable context travels in ``cfg``."""
+    24 * n_streams parameter tensors; non-differentiable context travels in ``cfg``.
+
+    Every tensor the backward reads goes through ``ctx.save_for_backward`` (so autograd's version check catches
+    an in-place update between forward and backward -- e.g. an optimizer step -- and frees / retains them with the
+    graph), including the activation workspace of the un-tiled mode."""
 
     @staticmethod
     def forward(ctx, cfg, R, T, shape_code, gaze, appea_code, *flat_params):
         n_streams = cfg["n_streams"]
         prob = _Problem(cfg["xy"], R, T, cfg["Kinv"], shape_code, gaze, appea_code, cfg["n_samples"],
                         cfg["world_z1"], cfg["world_z2"], cfg["t_rand"], cfg["z_edges"],
-                        cfg["hidden"], cfg["feat_nc"])
+                        cfg["hidden"], cfg["feat_nc"], cfg.get("edges_follow_T", False))
         streams = [_prep_params(flat_params[24 * s:24 * (s + 1)], cfg["hidden"], prob.vp,
                                 prob.c.appea_dims, cfg["feat_nc"], "stream%d" % s)
                    for s in range(n_streams)]
         need_grad = any(ctx.needs_input_grad[1:])
         bf16x3 = cfg.get("precision", "fp32") == "bf16x3"
-        res, ws = _run_forward(prob, streams, need_grad, cfg["want_depth"], cfg["want_weights"], bf16x3)
-        ctx.cfg, ctx.prob, ctx.streams = cfg, prob, streams
-        ctx.saved_ws = ws if need_grad else None
+        tile = plan_ray_tiles(prob, n_streams, cfg.get("ws_budget_bytes"), cfg.get("ray_tile")) if need_grad else None
+        save = need_grad and tile is None
+        res, ws = _run_forward(prob, streams, save, cfg["want_depth"], cfg["want_weights"], bf16x3)
+        ctx.cfg = {k: v for k, v in cfg.items() if not torch.is_tensor(v)}
+        ctx.tile, ctx.need_grad = tile, need_grad
         ctx.param_shapes = [tuple(t.shape) for t in flat_params]
+        if need_grad:
+            ctx.save_for_backward(R, T, shape_code, gaze, appea_code, *flat_params, cfg["xy"], cfg["Kinv"],
+                                  cfg["t_rand"], cfg["z_edges"], ws if save else None)
         outs = []
         nondiff = []
         for feat, bga, dep, wts in res:
@@ -207,60 +278,68 @@ class _RenderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        lib = _lib.load()
-        prob, streams, cfg = ctx.prob, ctx.streams, ctx.cfg
-        if ctx.saved_ws is None:
-            raise RuntimeError("render_two_stream: backward called but forward saved nothing")
-        dev = prob.device
-        n_streams = len(streams)
-        dout = _lib.GnrOutputGrads()
-        keep = []
+        if not ctx.need_grad:
+            raise RuntimeError("render_two_stream: backward called but no input required a gradient in forward")
+        cfg = ctx.cfg
+        saved = ctx.saved_tensors
+        n_streams = cfg["n_streams"]
+        R, T, shape_code, gaze, appea_code = saved[:5]
+        flat_params = saved[5:5 + 24 * n_streams]
+        xy, Kinv, t_rand, z_edges, ws = saved[5 + 24 * n_streams:]
+        bf16x3 = cfg.get("precision", "fp32") == "bf16x3"
+
+        def problem(sl=None):
+            cut = (lambda t, dim: None if t is None else t[(slice(None),) * dim + (sl,)].contiguous()) if sl else (lambda t, dim: t)
+            return _Problem(cut(xy, 2), R, T, Kinv, shape_code, gaze, appea_code, cfg["n_samples"], cfg["world_z1"],
+                            cfg["world_z2"], cut(t_rand, 1), cut(z_edges, 1), cfg["hidden"], cfg["feat_nc"],
+                            cfg.get("edges_follow_T", False))
+
+        streams = None
+        gout_full = []
         gi = 0
-        for s, (has_d, has_w) in enumerate(ctx.out_layout):
+        for has_d, has_w in ctx.out_layout:
             gf, ga = grads[gi], grads[gi + 1]
             gi += 2 + int(has_d) + int(has_w)
-            for g, field in ((gf, dout.feat), (ga, dout.bg_alpha)):
-                if g is not None:
-                    g = g.contiguous().float()
-                    keep.append(g)
-                    field[s] = g.data_ptr()
-                else:
-                    field[s] = None
-        B = prob.B
-        gR = torch.empty(B, 3, 3, device=dev)
-        gT = torch.empty(B, 3, 1, device=dev)
-        gshape = torch.empty(B, prob.c.shape_dims, device=dev)
-        ggaze = torch.empty(B, prob.c.gaze_dims, device=dev)
-        gappea = torch.empty(B, prob.c.appea_dims, device=dev)
-        din = _lib.GnrInputGrads()
-        din.R, din.T = gR.data_ptr(), gT.data_ptr()
-        din.shape_code, din.gaze, din.appea_code = gshape.data_ptr(), ggaze.data_ptr(), gappea.data_ptr()
-        gparams = [[torch.empty_like(t) for t in streams[s]] for s in range(n_streams)]
-        dw = [_weights_struct(g, _lib.GnrWeightGrads) for g in gparams]
-        w = [_weights_struct(st) for st in streams]
-        with torch.cuda.device(dev):
-            nbytes = lib.gnr_workspace_bytes(C.byref(prob.c), n_streams, _lib.WS_BWD)
-            scratch = _alloc_ws(max(nbytes, 256), dev)
-            bwd = lib.gnr_bwd_bf16x3 if cfg.get("precision", "fp32") == "bf16x3" else lib.gnr_bwd
-            rc = bwd(C.byref(prob.c), C.byref(w[0]), C.byref(w[1]) if n_streams > 1 else None,
-                     C.byref(dout), C.byref(din), C.byref(dw[0]),
-                     C.byref(dw[1]) if n_streams > 1 else None,
-                     C.c_void_p(ctx.saved_ws.data_ptr()), ctx.saved_ws.numel(),
-                     C.c_void_p(scratch.data_ptr()), scratch.numel(), _stream_ptr(dev))
-            _lib.check(rc, lib)
-        ctx.saved_ws = None
+            gout_full.append(tuple(None if g is None else g.contiguous().float() for g in (gf, ga)))
+
+        if ctx.tile is None:
+            prob = problem()
+            streams = [_prep_params(flat_params[24 * s:24 * (s + 1)], cfg["hidden"], prob.vp, prob.c.appea_dims,
+                                    cfg["feat_nc"], "stream%d" % s) for s in range(n_streams)]
+            gin, gparams = _run_backward(prob, streams, gout_full, ws, bf16x3)
+        else:
+            gin = gparams = None
+            n_r = xy.shape[2]
+            for r0 in range(0, n_r, ctx.tile):
+                sl = slice(r0, min(n_r, r0 + ctx.tile))
+                prob = problem(sl)
+                if streams is None:
+                    streams = [_prep_params(flat_params[24 * s:24 * (s + 1)], cfg["hidden"], prob.vp,
+                                            prob.c.appea_dims, cfg["feat_nc"], "stream%d" % s) for s in range(n_streams)]
+                _, tws = _run_forward(prob, streams, True, False, False, bf16x3)        # recompute with save
+                gout = [tuple(None if g is None else g[:, :, sl].contiguous() for g in pair) for pair in gout_full]
+                tin, tpar = _run_backward(prob, streams, gout, tws, bf16x3)
+                del tws
+                if gin is None:
+                    gin, gparams = tin, tpar
+                else:                                   # fixed tile order: deterministic accumulation
+                    torch._foreach_add_(gin, tin)
+                    for a, b in zip(gparams, tpar):
+                        torch._foreach_add_(a, b)
         flat = []
         for s in range(n_streams):
             for g, shp in zip(gparams[s], ctx.param_shapes[24 * s:24 * (s + 1)]):
                 flat.append(g.reshape(shp))
-        return (None, gR, gT, gshape, ggaze, gappea, *flat)
+        return (None, *gin, *flat)
 
 
 def render_two_stream(batch_xy, R, T, Kinv, shape_code, gaze, appea_code, face_params, eyes_params=None,
                       *, n_samples: int, world_z1: float = 2.5, world_z2: float = -3.5,
                       t_rand: Optional[torch.Tensor] = None, z_edges: Optional[torch.Tensor] = None,
                       return_depth: bool = False, return_weights: bool = False,
-                      hidden: int = 384, feat_nc: int = 258, precision: str = "fp32"):
+                      hidden: int = 384, feat_nc: int = 258, precision: str = "fp32",
+                      edges_follow_T: bool = False, ray_tile: Optional[int] = None,
+                      ws_budget_bytes: Optional[int] = None):
     """Run the hot path.  Returns a dict with feat_face [B,feat_nc,N_r], bg_alpha_face [B,1,N_r]
     (and *_eyes when ``eyes_params`` is given; depth_* / w_* [B,1,N_r,N_p] on request).
 
@@ -270,6 +349,15 @@ def render_two_stream(batch_xy, R, T, Kinv, shape_code, gaze, appea_code, face_p
     ``precision="bf16x3"`` runs the dense layers (forward and the dgrad chain of the backward) on bf16
     MFMA with a 3-term hi/lo split of both operands; it agrees with the default exact-fp32 path to that
     path's own rounding noise (see gnr_fwd_bf16x3 / gnr_bwd_bf16x3 in include/gnr.h).
+
+    ``edges_follow_T`` (with ``z_edges``): the edges shift 1:1 with T_z, as FineSample's merged edges do in the
+    reference (only the weights are detached, utils/model_utils.py:418, 455-476), so dL/dT is the plane sweep's.
+
+    Training calls whose saved activations exceed ``ws_budget_bytes`` (default 96 GB, env GNR_WS_BUDGET_GB; one
+    512x512-ray image would need 540 GB) run in ray tiles inside the op: forward once without saving, backward
+    recomputes forward-with-save per tile and accumulates the gradients in a fixed order.  ``ray_tile`` forces a
+    tile size.  The reference makes one forward call for the whole image (models/gaze_nerf.py:211-320); so does
+    the caller of this op.
     """
     if precision not in ("fp32", "bf16x3"):
         raise ValueError("precision must be 'fp32' or 'bf16x3'")
@@ -278,7 +366,8 @@ def render_two_stream(batch_xy, R, T, Kinv, shape_code, gaze, appea_code, face_p
         streams.append(params_to_list(eyes_params))
     cfg = dict(xy=batch_xy, Kinv=Kinv, n_samples=int(n_samples), world_z1=world_z1, world_z2=world_z2,
                t_rand=t_rand, z_edges=z_edges, hidden=hidden, feat_nc=feat_nc, n_streams=len(streams),
-               want_depth=return_depth, want_weights=return_weights, precision=precision)
+               want_depth=return_depth, want_weights=return_weights, precision=precision,
+               edges_follow_T=bool(edges_follow_T), ray_tile=ray_tile, ws_budget_bytes=ws_budget_bytes)
     flat = [t for st in streams for t in st]
     outs = _RenderFn.apply(cfg, R, T, shape_code, gaze, appea_code, *flat)
     res: Dict[str, torch.Tensor] = {}

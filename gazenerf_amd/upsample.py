@@ -57,30 +57,40 @@ def _expected_shapes(feat_nc, n_blocks, min_feat):
     return shp
 
 
+def _prep_upsample(cfg, x, flat):
+    """Validated contiguous inputs + the ctypes problem pointing at them."""
+    n_blocks, min_feat, final = cfg["n_blocks"], cfg["min_feat"], cfg["final_actvn"]
+    names = renderer_param_names(n_blocks)
+    _check_tensor("x", x)
+    if x.dim() != 4 or x.shape[2] != x.shape[3]:
+        raise ValueError("x must be [B, C, S, S], got %s" % (tuple(x.shape),))
+    B, Cn, S, _ = x.shape
+    shapes = _expected_shapes(Cn, n_blocks, min_feat)
+    params = {}
+    for name, t in zip(names, flat):
+        _check_tensor(name, t)
+        base = name.rsplit(".", 1)[0]
+        want = shapes[base] if name.endswith(".weight") else (shapes[base][0],)
+        t2 = t.reshape(t.shape[0], -1) if name.endswith(".weight") else t
+        if tuple(t2.shape) != want:
+            raise ValueError("%s must have shape %s (+[1,1]), got %s" % (name, want, tuple(t.shape)))
+        params[name] = t2.contiguous()
+    xc = x.contiguous()
+    p = _lib.GnrUpsampleProblem()
+    p.batch, p.feat_nc, p.featmap_size, p.n_blocks, p.min_feat, p.final_sigmoid = B, Cn, S, n_blocks, min_feat, int(final)
+    p.x = xc.data_ptr()
+    return p, xc, params, names
+
+
 class _UpsampleFn(torch.autograd.Function):
+    """Inputs, parameters and the activation workspace travel through ``ctx.save_for_backward`` (autograd's
+    version check then catches an in-place parameter update between forward and backward)."""
+
     @staticmethod
     def forward(ctx, cfg, x, *flat):
         lib = _lib.load()
-        n_blocks, min_feat, final = cfg["n_blocks"], cfg["min_feat"], cfg["final_actvn"]
-        names = renderer_param_names(n_blocks)
-        _check_tensor("x", x)
-        if x.dim() != 4 or x.shape[2] != x.shape[3]:
-            raise ValueError("x must be [B, C, S, S], got %s" % (tuple(x.shape),))
-        B, Cn, S, _ = x.shape
-        shapes = _expected_shapes(Cn, n_blocks, min_feat)
-        params = {}
-        for name, t in zip(names, flat):
-            _check_tensor(name, t)
-            base = name.rsplit(".", 1)[0]
-            want = shapes[base] if name.endswith(".weight") else (shapes[base][0],)
-            t2 = t.reshape(t.shape[0], -1) if name.endswith(".weight") else t
-            if tuple(t2.shape) != want:
-                raise ValueError("%s must have shape %s (+[1,1]), got %s" % (name, want, tuple(t.shape)))
-            params[name] = t2.contiguous()
-        xc = x.contiguous()
-        p = _lib.GnrUpsampleProblem()
-        p.batch, p.feat_nc, p.featmap_size, p.n_blocks, p.min_feat, p.final_sigmoid = B, Cn, S, n_blocks, min_feat, int(final)
-        p.x = xc.data_ptr()
+        p, xc, params, names = _prep_upsample(cfg, x, flat)
+        B, S, n_blocks = p.batch, p.featmap_size, p.n_blocks
         dev = x.device
         with torch.cuda.device(dev):
             nbytes = lib.gnr_upsample_workspace_bytes(C.byref(p), _lib.UP_WS_FWD)
@@ -92,22 +102,24 @@ class _UpsampleFn(torch.autograd.Function):
             rc = lib.gnr_upsample_fwd(C.byref(p), C.byref(w), C.c_void_p(img.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(),
                                       _stream_ptr(dev))
             _lib.check(rc, lib)
-        need_grad = any(ctx.needs_input_grad[1:])
-        ctx.cfg, ctx.p, ctx.xc, ctx.params, ctx.names = cfg, p, xc, params, names
-        ctx.ws = ws if need_grad else None
-        ctx.flat_shapes = [t.shape for t in flat]
+        ctx.cfg = cfg
+        ctx.need_grad = any(ctx.needs_input_grad[1:])
+        if ctx.need_grad:
+            ctx.save_for_backward(x, ws, *flat)
         return img
 
     @staticmethod
     def backward(ctx, g_img):
         lib = _lib.load()
-        if ctx.ws is None:
-            raise RuntimeError("neural_render: backward without a saved workspace")
-        p, params, names = ctx.p, ctx.params, ctx.names
+        if not ctx.need_grad:
+            raise RuntimeError("neural_render: backward called but no input required a gradient in forward")
+        x, ws = ctx.saved_tensors[:2]
+        flat = ctx.saved_tensors[2:]
+        p, xc, params, names = _prep_upsample(ctx.cfg, x, flat)
         n_blocks = ctx.cfg["n_blocks"]
-        dev = ctx.xc.device
+        dev = xc.device
         g = g_img.contiguous()
-        dx = torch.empty_like(ctx.xc)
+        dx = torch.empty_like(xc)
         grads = {k: torch.empty_like(v) for k, v in params.items()}
         with torch.cuda.device(dev):
             nbytes = lib.gnr_upsample_workspace_bytes(C.byref(p), _lib.UP_WS_BWD)
@@ -115,11 +127,10 @@ class _UpsampleFn(torch.autograd.Function):
             w = _weights_struct(params, n_blocks)
             dw = _weights_struct(grads, n_blocks, _lib.GnrUpsampleWeightGrads)
             rc = lib.gnr_upsample_bwd(C.byref(p), C.byref(w), C.c_void_p(g.data_ptr()), C.c_void_p(dx.data_ptr()), C.byref(dw),
-                                      C.c_void_p(ctx.ws.data_ptr()), ctx.ws.numel(), C.c_void_p(scratch.data_ptr()),
+                                      C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(scratch.data_ptr()),
                                       scratch.numel(), _stream_ptr(dev))
             _lib.check(rc, lib)
-        ctx.ws = None
-        return (None, dx) + tuple(grads[n].reshape(s) for n, s in zip(names, ctx.flat_shapes))
+        return (None, dx.reshape(x.shape)) + tuple(grads[n].reshape(t.shape) for n, t in zip(names, flat))
 
 
 def neural_render(x, params: Dict[str, torch.Tensor], n_blocks: int = 3, min_feat: int = 32, final_actvn: bool = True):

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GNR_ABI_VERSION 1
+#define GNR_ABI_VERSION 2
 #define GNR_N_TRUNK 8          /* FeaExt_module_0..7   (models/mlp_nerf.py:29-58)  */
 #define GNR_N_RGB 3            /* RGB_layer_0..2       (models/mlp_nerf.py:68-93)  */
 
@@ -65,6 +65,11 @@ typedef struct GnrProblem {
                                  or NULL == reference `disturb=False`                         */
     const float* z_edges;     /* [B,N_r,N_p+1] explicit sample edges (the sorted z of
                                  FineSample, model_utils.py:476-481) or NULL == plane sweep    */
+    int32_t edges_follow_T;   /* only read by gnr_bwd when z_edges != NULL.  0: the edges are constants
+                                 (d z / d T = 0).  1: they shift 1:1 with T_z, as FineSample's merged
+                                 edges do -- it detaches only the weights, the coarse z it interpolates
+                                 between are (T_z - world_z) terms (model_utils.py:418, 455-476, 339-357)
+                                 -- so dT is that of the plane sweep.  ABI 2.                   */
 } GnrProblem;
 
 /* Parameters of one MLPforNeRF (models/mlp_nerf.py:13-93).  weight = Conv2d [out,in,1,1] memory
@@ -123,6 +128,13 @@ enum {
 
 int gnr_abi_version(void);
 
+/* sizeof() of the ABI structs as this library was compiled, so a binding in another language can verify its
+ * own declarations at load time (the ctypes binding does).  Unknown id -> 0. */
+enum { GNR_SIZEOF_PROBLEM = 0, GNR_SIZEOF_WEIGHTS = 1, GNR_SIZEOF_OUTPUTS = 2, GNR_SIZEOF_OUTPUT_GRADS = 3,
+       GNR_SIZEOF_INPUT_GRADS = 4, GNR_SIZEOF_MERGE_PROBLEM = 5, GNR_SIZEOF_UPSAMPLE_PROBLEM = 6,
+       GNR_SIZEOF_UPSAMPLE_WEIGHTS = 7 };
+size_t gnr_sizeof(int which);
+
 /* Bytes of workspace `kind` needs for problem `p` with `n_streams` (1 or 2) weight sets. */
 size_t gnr_workspace_bytes(const GnrProblem* p, int n_streams, int kind);
 
@@ -180,6 +192,15 @@ int gnr_sample_zvals(const GnrProblem* p, float* zvals_out, void* stream);
  * gnr_bwd), so a harness can time that kernel alone.  Pass NULLs to switch it off (the default).
  * This is the only process-wide state in the library; it never affects results. */
 int gnr_set_kernel_timing(void* ev_start, void* ev_stop);
+
+/* The same hook per stage (ABI 2): records the event pair around
+ *   GNR_STAGE_FWD_MLP  the fused march-encode-MLP-composite kernel of gnr_fwd (both weight sets),
+ *   GNR_STAGE_DGRAD    the dgrad-chain kernel of gnr_bwd, first weight set,
+ *   GNR_STAGE_COMP_BWD the compositing backward of gnr_bwd, first weight set,
+ *   GNR_STAGE_WGRAD    all weight-gradient GEMMs (+ their reductions) of gnr_bwd, first weight set.
+ * gnr_set_kernel_timing == stages FWD_MLP and DGRAD with one pair; gnr_set_aux_timing == COMP_BWD. */
+enum { GNR_STAGE_FWD_MLP = 0, GNR_STAGE_DGRAD = 1, GNR_STAGE_COMP_BWD = 2, GNR_STAGE_WGRAD = 3, GNR_N_STAGES = 4 };
+int gnr_set_stage_timing(int stage, void* ev_start, void* ev_stop);
 
 /* Same, for the HBM-bound compositing pass of gnr_bwd (CalcRayColor backward over the saved per-sample
  * features, first weight set): lets a harness report achieved GB/s for that pass. */

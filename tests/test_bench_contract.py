@@ -1,6 +1,7 @@
 """GPU: bench.py end to end at a small size -- exactly one JSON line on stdout with the contract's fields, the
-roofline / cpu_baseline objects and the separately timed bf16x3 leg; and the 2-rank launcher path on one GPU
-(gloo override, test-only) producing the whole-job aggregate."""
+roofline / stages / cpu_baseline objects and the separately timed bf16x3 leg; `--gpus 2` WITHOUT a launcher spawning
+two ranks itself (gloo override, both on one GPU: test-only) and reporting the whole-job aggregate with n_gpus = 2; the
+same under an external torch.distributed.run; the cfg4 whole-network step with all 5 015 714 gradients exchanged."""
 import json
 import os
 import subprocess
@@ -12,43 +13,78 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-        "dtype", "data", "config", "roofline"}
+        "dtype", "data", "config", "roofline", "stages"}
+TWO_ON_ONE = {"GNR_BENCH_DEVICE": "0", "GNR_BENCH_BACKEND": "gloo"}
 
 
 def _run(cmd, env=None):
     e = dict(os.environ)
+    e.pop("WORLD_SIZE", None)
     e.update(env or {})
     r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.strip() and not l.startswith("[Gloo]")]   # gloo's own chatter (test-only backend)
-    assert len(lines) == 1, lines
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]   # launcher / gloo chatter is not JSON
+    assert len(lines) == 1, r.stdout[-2000:]
     return json.loads(lines[0])
 
 
 @pytest.mark.parametrize("mode", ["fwdbwd", "fwd"])
 def test_single_gpu_line(mode):
-    # the CPU leg (thread-count probing on a many-core host) takes a minute: keep it in the cheaper forward mode only
-    extra = ["--cpu-rays", "16"] if mode == "fwd" else ["--no-cpu-baseline"]
+    extra = ["--cpu-budget", "6"] if mode == "fwd" else ["--no-cpu-baseline"]
     d = _run([sys.executable, "bench.py", "--side", "64", "--steps", "2", "--warmup", "1", "--mode", mode] + extra)
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
     assert d["unit"] == "rays/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
     assert abs(d["value"] - 64 * 64 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     rf = d["roofline"]
-    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3 and rf["traffic"] is not None
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3
+    # 4096 rays per launch is not a size a PMC capture is committed for: traffic must be null, not a stale number
+    assert rf["traffic"] is None and "traffic_source" in rf
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.1 < rf["frac"] < 1.0
+    stages = {s["stage"]: s for s in d["stages"]}
+    assert set(stages) == ({"fwd_mlp", "dgrad", "wgrad", "comp_bwd"} if mode == "fwdbwd" else {"fwd_mlp"})
+    for s in stages.values():
+        assert s["launches_timed"] == 2 and s["avg_ms"] > 0 and 0.0 < s["frac"] < 1.0
+        assert abs(s["frac"] - s["achieved"] / s["peak"]) < 1e-9
+    assert 0.5 < sum(s["share_of_step"] for s in stages.values()) <= 1.0 + 1e-6
     if mode == "fwd":
         cb = d["cpu_baseline"]
         assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["value_1_thread"] > 0 and "sample" in cb
     x3 = d["bf16x3"]
-    assert x3["value"] > d["value"] and x3["roofline"]["kernel"].startswith("gnr::fwd3_kernel")
+    assert x3["value"] > d["value"] and any(t in x3["roofline"]["kernel"] for t in ("fwd3", "bwd3", "wgrad3"))
     if mode == "fwdbwd":
         assert d["roofline_hbm"]["bound"] == "hbm" and d["roofline_hbm"]["kernel"] == "gnr::comp_bwd_kernel"
 
 
-def test_two_ranks_on_one_gpu_report_the_aggregate():
-    d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-              "--master-port", "29533", "bench.py", "--gpus", "2", "--side", "64", "--steps", "1", "--warmup", "1", "--no-alt"],
-             env={"GNR_BENCH_DEVICE": "0", "GNR_BENCH_BACKEND": "gloo"})
+def test_gpus_flag_launches_the_ranks_itself():
+    """python bench.py --gpus 2, no torchrun: two ranks, n_gpus 2, whole-job aggregate, the exchange described."""
+    d = _run([sys.executable, "bench.py", "--gpus", "2", "--side", "64", "--steps", "1", "--warmup", "1", "--no-alt"], env=TWO_ON_ONE)
     assert d["n_gpus"] == 2 and "cpu_baseline" not in d
     assert abs(d["value"] - 2 * 64 * 64 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    ar = d["allreduce"]
+    assert ar["world_size_formed"] == 2 and ar["floats"] == 2 * 1518979 and ar["buckets"] == 2 and ar["ms"] > 0
+
+
+def test_two_ranks_under_an_external_launcher_report_the_aggregate():
+    d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+              "--master-port", "29533", "bench.py", "--gpus", "2", "--side", "64", "--steps", "1", "--warmup", "1", "--no-alt"],
+             env=TWO_ON_ONE)
+    assert d["n_gpus"] == 2 and "cpu_baseline" not in d
+    assert abs(d["value"] - 2 * 64 * 64 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+
+
+def test_gpus_flag_must_match_the_world_size():
+    e = dict(os.environ)
+    e.update({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--side", "64", "--steps", "1"], cwd=ROOT, env=e,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_cfg4_whole_network_step_reduces_every_gradient():
+    d = _run([sys.executable, "bench.py", "--config", "cfg4", "--gpus", "2", "--steps", "2", "--warmup", "1"], env=TWO_ON_ONE)
+    assert d["n_gpus"] == 2 and d["config"]["trainable_floats"] == 5015714
+    ar = d["allreduce"]
+    assert ar["floats"] == 5015714 and ar["buckets"] == 3 and ar["world_size_formed"] == 2
+    assert abs(d["value"] - 2 * 2 * 4096 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert {s["stage"] for s in d["stages"]} == {"fwd_mlp", "dgrad", "wgrad"}

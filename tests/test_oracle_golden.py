@@ -23,8 +23,11 @@ def _weights(g, hidden=384):
             synth.hash_mlp_params("eyes", seed=seed, hidden=hidden, density_scale=ds))
 
 
+S512 = ["g2b_np64_frontal", "g2b_np64_orbit3", "g2b_np64_opaque", "g2b_np64_train_opaque"]   # featmap_size=512 (cfg2b)
+
+
 @pytest.mark.parametrize("name", ["g2_np32_frontal", "g2_np64_frontal", "g2_np64_orbit3",
-                                  "g3_np64_train", "g4_np64_opaque"])
+                                  "g3_np64_train", "g4_np64_opaque"] + S512)
 def test_forward_fixtures(name):
     g = load_golden(name)
     p = golden_problem(g)
@@ -74,8 +77,9 @@ def test_fine_sample_fixture():
         assert _maxabs(rnd[k], g["rnd_" + k]) <= 1e-5
 
 
-def test_hier_fixture():
-    g = load_golden("g5_hier")
+@pytest.mark.parametrize("name", ["g5_hier", "g5b_hier512"])
+def test_hier_fixture(name):
+    g = load_golden(name)
     p = golden_problem(g)
     face, eyes = _weights(g)
     fine = synth.hash_mlp_params("fine", seed=int(g["weight_seed"]), density_scale=float(g["density_scale"]))
@@ -89,6 +93,40 @@ def test_hier_fixture():
     assert _maxabs(out["samples"]["z_dists"], g["out_z_dists"]) <= 1e-5
     assert _maxabs(out["feat_fine"], g["out_feat_fine"]) <= 2e-5
     assert _maxabs(out["bg_alpha_fine"], g["out_bg_alpha_fine"]) <= 2e-5
+
+
+def test_side512_fixture_geometry():
+    """The side-512 fixtures really are cfg2b geometry: rays from the 512x512 grid (incl. its corners),
+    focal terms of Kinv = the 32x32 value / 16 (utils/render_utils.py:36-40)."""
+    g = load_golden("g2b_np64_frontal")
+    sub = g["ray_subset"]
+    xy = synth.pixel_grid(512)[:, :, sub]
+    assert torch.equal(g["in_xy"], xy) and float(xy.max()) == 511.0 and float(xy.min()) == 0.0
+    assert torch.equal(g["in_Kinv"], synth.scaled_kinv(512))
+    assert abs(float(g["in_Kinv"][0, 0, 0]) - 0.007790804840624332 / 16) < 1e-10
+
+
+def test_backward_fixture_side512():
+    """g6b: reference autograd at side 512 (B=2 x 32 rays x 64, jitter, opaque head) vs the oracle."""
+    g = load_golden("g6b_backward512")
+    p = golden_problem(g)
+    face, eyes = _weights(g)
+    leaves = {k: p[k].clone().requires_grad_(True) for k in ("R", "T", "shape_code", "gaze", "appea_code")}
+    fp = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in face.items())
+    ep = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in eyes.items())
+    out = O.render_two_stream(p["xy"], leaves["R"], leaves["T"], p["Kinv"], leaves["shape_code"], leaves["gaze"],
+                              leaves["appea_code"], fp, ep, int(g["n_samples"]), t_rand=g["t_rand"])
+    O.synthetic_loss(out).backward()
+    for k, v in leaves.items():
+        ref = g["grad_" + k]
+        assert _maxabs(v.grad, ref) <= 1e-4 * max(1.0, float(ref.abs().max())), k
+    for tag, params in (("face", fp), ("eyes", ep)):
+        for name, v in params.items():
+            ref = g["gradw_%s.%s" % (tag, name)]
+            got = v.grad
+            if got.numel() > 4096:
+                got = got.reshape(got.shape[0], -1)[::16]
+            assert _maxabs(got.reshape(ref.shape), ref) <= 1e-4 * max(1.0, float(ref.abs().max())), name
 
 
 def test_synth_is_deterministic():

@@ -97,3 +97,49 @@ def test_world_size_one_is_a_noop():
     parallel.GradAllReducer([p], 1).all_reduce()
     assert torch.equal(p.grad, torch.full((4,), 3.0))
     assert len(PARAM_ORDER) == 24
+
+
+def _overlap_case(rank, world):
+    """Explicit buckets in backward order + hook-driven launch: bucket 0's all-reduce starts from the autograd
+    hook of its last parameter, before the rest of the backward has run (cfg4: the NeuralRenderer bucket flies
+    during the hot path's backward)."""
+    torch.manual_seed(0)
+    a = [torch.nn.Parameter(torch.ones(5)), torch.nn.Parameter(torch.ones(3, 2))]     # "late" layers: grads first
+    b = [torch.nn.Parameter(torch.ones(4))]                                           # "early" layer: grad last
+    red = parallel.GradAllReducer([a, b], world)
+    assert red.n_buckets == 2 and red.bytes_per_step == 4 * (5 + 6 + 4)
+    red.arm_overlap()
+    launched_before_b = []
+    b[0].register_hook(lambda g: launched_before_b.append(0 in red._inflight) or g)    # runs when b's grad is computed
+    ok = True
+    for it in range(2):                                                                # hooks re-arm across steps
+        for p in a + b:
+            p.grad = None
+        x = (b[0] * (rank + 1.0)).sum()                      # b is used first -> its gradient arrives last
+        y = (a[0] * x).sum() * (it + 1.0) + (a[1] * 2.0 * (rank + 1.0)).sum()
+        y.backward()
+        red.all_reduce()
+        rs = [r + 1.0 for r in range(world)]
+        exp_a0 = sum(4.0 * r * (it + 1.0) for r in rs) / world
+        exp_a1 = sum(2.0 * r for r in rs) / world
+        exp_b = sum(5.0 * (it + 1.0) * r for r in rs) / world
+        ok = ok and torch.allclose(a[0].grad, torch.full((5,), exp_a0)) and torch.allclose(a[1].grad, torch.full((3, 2), exp_a1))
+        ok = ok and torch.allclose(b[0].grad, torch.full((4,), exp_b))
+    return bool(ok) and launched_before_b == [True, True]
+
+
+def test_hook_driven_bucket_overlap_two_ranks():
+    res = _run(_overlap_case)
+    assert res == {0: True, 1: True}
+
+
+def test_whole_network_buckets_cover_all_trainable_floats():
+    """cfg4's exchange: NeuralRenderer (incl. bg_featmap) + both MLPs = 5 015 714 floats."""
+    from gazenerf_amd import GazeNeRFNetAMD
+    net = GazeNeRFNetAMD()
+    groups = {pre: [q for n, q in net.named_parameters() if n.startswith(pre)]
+              for pre in ("neural_render.", "fg_CD_predictor_face.", "fg_CD_predictor_eyes.")}
+    red = parallel.GradAllReducer(list(groups.values()), 8)
+    assert red.n_buckets == 3 and red.bytes_per_step == 4 * 5015714
+    assert sum(q.numel() for q in groups["neural_render."]) == 1977756
+    assert len(red.params) == len(list(net.parameters()))
