@@ -20,6 +20,9 @@ SOURCES = ["gnr_api.hip", "gnr_prep.hip", "gnr_fwd.hip", "gnr_bwd.hip", "gnr_wgr
 HEADERS = ["gnr_internal.h", "gnr_device.h", "gnr_chain.h", "gnr_chain3.h", "gnr_bwd_common.h", os.path.join("..", "..", "include", "gnr.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# per-file extras.  gnr_wgrad.hip: the SLP vectoriser packs the scalar rider adds that sit between the MFMAs into
+# v_pk_* with register shuffles around them -- each extra VALU instruction there costs matrix-pipe cycles.
+EXTRA_FLAGS = {"gnr_wgrad.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(target, deps):
@@ -42,7 +45,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(job):
         src, obj = job
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print("[gnr build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -206,70 +206,151 @@ void launch_zvals(const GnrProblem& p, float* out, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// resample: FineSample.forward, utils/model_utils.py:413-490.  One 64-lane wave per ray.
+// resample: FineSample.forward, utils/model_utils.py:413-490.
 //   pdf  = w[1:-1] / sum(w[1:-1] + 1e-5);  cdf = [0, cumsum(pdf)]          (N_c - 1 entries)
 //   inds = searchsorted(cdf, u, right=True); below = max(0, inds-1); above = min(N_c-2, inds)
 //   bins = midpoints of the coarse z;  z_f = bins[below] + t (bins[above]-bins[below])
 //   out  = sort(cat[coarse z, z_f])
+//
+// HBM-bound by nature (reads 2 N_c floats, writes N_c + N_f + 1 per ray: 1.3 KB at 64 + 128), so the kernel is
+// organised around coalesced rows and no serial lane:
+//   * a wave takes a PASS of up to 64 consecutive rays.  Their weight rows are one contiguous block: it is
+//     streamed coalesced into an LDS image with an odd row stride, so that in the next step LANE r walks ROW r
+//     conflict-free;
+//   * cdf: torch.cumsum adds in index order and t = (u - cdf[below]) / (cdf[above] - cdf[below]) divides by
+//     bin masses down to 1e-5, so an ulp of cdf is 6e-3 of a bin: the running sum must keep the sequential
+//     fp32 order.  It is sequential per ray and parallel over the 64 rays of the pass (one ray per lane);
+//   * then ray by ray with the whole wave: the fine samples by binary search in the ray's cdf row, and the
+//     sort as a MERGE of two sorted lists instead of a sort: the coarse z are sorted, a fine sample's position
+//     among them follows from its bin (z_f lies between two bin midpoints: one or two comparisons), its
+//     position among the fine samples is its index (u ascending: the inverse cdf is monotone in fp32 too) or
+//     its rank among the u's (random u); a 65-bin histogram of the fine samples' coarse positions + one wave
+//     scan gives every coarse z its place.  The merged row leaves through LDS as coalesced stores.
 // ---------------------------------------------------------------------------------------------
-constexpr int RS_MAX = 512;     // max merged edges per ray
+constexpr int RS_WAVES = 2;          // waves per workgroup (each on its own pass)
+constexpr int RS_ROW_FLOATS = 4096;  // LDS floats per wave for the transposed weight / cdf rows
 
-__global__ __launch_bounds__(64) void resample_kernel(const float* __restrict__ w,
-                                                      const float* __restrict__ cz,
-                                                      const float* __restrict__ u, long n_rays,
-                                                      int nc, int nf, float* __restrict__ zout) {
-    __shared__ float cdf[RS_MAX];
-    __shared__ float bins[RS_MAX];
-    __shared__ float merged[RS_MAX];
-    const long ray = blockIdx.x;
-    if (ray >= n_rays) return;
-    const int lane = threadIdx.x;
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");     // LDS traffic of this wave is in order; make it visible
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(64 * RS_WAVES) void resample_kernel(const float* __restrict__ w,
+                                                                 const float* __restrict__ cz,
+                                                                 const float* __restrict__ u, long n_rays, int nc,
+                                                                 int nf, int rpp, int stride,
+                                                                 float* __restrict__ zout) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nc2 = nc - 2, nfs = nf + 1, total = nc + nfs;
-    const float* wr = w + ray * nc;
-    const float* zr = cz + ray * nc;
-    // sum(w' + 1e-5): sequential fp32 sum to mirror torch.sum on a short row is not reproducible
-    // bit-for-bit anyway; one lane does it in index order.
-    if (lane == 0) {
-        float ssum = 0.0f;
-        for (int k = 0; k < nc2; ++k) ssum += wr[1 + k] + 1e-5f;
-        float c = 0.0f;
-        cdf[0] = 0.0f;
-        for (int k = 0; k < nc2; ++k) { c += wr[1 + k] / ssum; cdf[k + 1] = c; }
-    }
-    for (int k = lane; k < nc - 1; k += 64) bins[k] = 0.5f * (zr[k + 1] + zr[k]);
-    for (int k = lane; k < nc; k += 64) merged[k] = zr[k];
-    __syncthreads();
-    const float ustep = 1.0f / (float)(nfs - 1);
-    for (int q = lane; q < nfs; q += 64) {
-        float uq;
-        if (u) uq = u[ray * nfs + q];
-        else uq = (q < nfs / 2) ? ustep * (float)q : 1.0f - ustep * (float)(nfs - 1 - q);
-        // searchsorted(right=True): first index with cdf[idx] > uq, over nc2+1 entries
-        int lo = 0, hi = nc2 + 1;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= uq) lo = mid + 1; else hi = mid; }
-        const int below = lo - 1 > 0 ? lo - 1 : 0;
-        const int above = lo < nc2 ? lo : nc2;
-        float denom = cdf[above] - cdf[below];
-        if (denom < 1e-5f) denom = 1.0f;
-        const float t = (uq - cdf[below]) / denom;
-        merged[nc + q] = bins[below] + t * (bins[above] - bins[below]);
-    }
-    __syncthreads();
-    // rank sort (stable for ties by index): total <= 512, 64 lanes
-    for (int a = lane; a < total; a += 64) {
-        const float va = merged[a];
-        int rank = 0;
-        for (int b2 = 0; b2 < total; ++b2) {
-            const float vb = merged[b2];
-            rank += (vb < va) || (vb == va && b2 < a);
+    const int per_wave = rpp * stride + nc + (nc + 1) + total + nfs;
+    float* rows = smem + (size_t)wave * per_wave;       // [rpp][stride]: w' then cdf, row r = ray r of the pass
+    float* zs = rows + rpp * stride;                    // [nc]      coarse z of the current ray
+    int* cnt = (int*)(zs + nc);                         // [nc + 1]  histogram of coarse positions
+    float* merged = (float*)(cnt + nc + 1);             // [total]
+    float* us = merged + total;                         // [nfs]     u of the current ray (random mode)
+    const long pass = (long)blockIdx.x * RS_WAVES + wave;
+    const long ray0 = pass * rpp;
+    if (ray0 >= n_rays) return;
+    const int nr = (int)((n_rays - ray0) < rpp ? (n_rays - ray0) : rpp);
+
+    // 1. weight rows of the pass: one contiguous block, coalesced, into the odd-stride image
+    {
+        const float* src = w + ray0 * nc;
+        const int n = nr * nc;
+        for (int e = lane; e < n; e += 64) {
+            const int r = e / nc, k = e - r * nc;
+            if (k >= 1 && k <= nc2) rows[r * stride + (k - 1)] = src[e];
         }
-        zout[ray * total + rank] = va;
+    }
+    wave_sync();
+    // 2. lane r: sum and sequential cumsum of row r, in place (cdf[k + 1] replaces w'[k + 1] after it was read)
+    if (lane < nr) {
+        float* row = rows + lane * stride;
+        float ssum = 0.0f;
+        for (int k = 0; k < nc2; ++k) ssum += row[k] + 1e-5f;
+        float c = 0.0f, cur = row[0];
+        row[0] = 0.0f;
+        for (int k = 0; k < nc2; ++k) {
+            const float wk = cur;
+            if (k + 1 < nc2) cur = row[k + 1];
+            c += wk / ssum;
+            row[k + 1] = c;
+        }
+    }
+    wave_sync();
+    // 3. ray by ray, the whole wave
+    const float ustep = 1.0f / (float)(nfs - 1);
+    for (int r = 0; r < nr; ++r) {
+        const long ray = ray0 + r;
+        const float* cdf = rows + r * stride;           // nc2 + 1 entries
+        for (int k = lane; k < nc; k += 64) zs[k] = cz[ray * nc + k];
+        for (int k = lane; k <= nc; k += 64) cnt[k] = 0;
+        if (u)
+            for (int q = lane; q < nfs; q += 64) us[q] = u[ray * nfs + q];
+        wave_sync();
+        for (int q = lane; q < nfs; q += 64) {
+            float uq;
+            if (u) uq = us[q];
+            else uq = (q < nfs / 2) ? ustep * (float)q : 1.0f - ustep * (float)(nfs - 1 - q);     // torch.linspace
+            // searchsorted(right=True): first index with cdf[idx] > uq, over nc2 + 1 entries
+            int lo = 0, hi = nc2 + 1;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= uq) lo = mid + 1; else hi = mid; }
+            const int below = lo - 1 > 0 ? lo - 1 : 0;
+            const int above = lo < nc2 ? lo : nc2;
+            const float cb = cdf[below];
+            float denom = cdf[above] - cb;
+            if (denom < 1e-5f) denom = 1.0f;
+            const float t = (uq - cb) / denom;
+            const float bb = __fmul_rn(0.5f, __fadd_rn(zs[below + 1], zs[below]));
+            const float ba = __fmul_rn(0.5f, __fadd_rn(zs[above + 1], zs[above]));
+            const float zf = __fadd_rn(bb, __fmul_rn(t, __fsub_rn(ba, bb)));
+            // position among the coarse z = #{k : z[k] <= zf}: z[0..below] <= bins[below] <= zf <= bins[above]
+            // <= z[above + 1], so at most two more comparisons succeed (more only for duplicate coarse z)
+            int cq = below + 1;
+            while (cq < nc && zs[cq] <= zf) ++cq;
+            // position among the fine samples
+            int rq = q;
+            if (u) {
+                rq = 0;
+                for (int j = 0; j < nfs; ++j) {
+                    const float uj = us[j];
+                    rq += (uj < uq) || (uj == uq && j < q);
+                }
+            }
+            atomicAdd(&cnt[cq], 1);
+            merged[cq + rq] = zf;
+        }
+        wave_sync();
+        // coarse k goes to k + #{fine with coarse position <= k}: inclusive scan of the histogram
+        int carry = 0;
+        for (int k0 = 0; k0 < nc; k0 += 64) {
+            const int k = k0 + lane;
+            int v = k < nc ? cnt[k] : 0;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(v, d);
+                if (lane >= d) v += o;
+            }
+            if (k < nc) merged[k + carry + v] = zs[k];
+            carry += __shfl(v, 63);
+        }
+        wave_sync();
+        for (int i = lane; i < total; i += 64) zout[ray * total + i] = merged[i];
+        wave_sync();
     }
 }
 
 void launch_resample(const float* w, const float* cz, const float* u, long n_rays, int nc, int nf,
                      float* zout, hipStream_t stream) {
-    hipLaunchKernelGGL(resample_kernel, dim3((unsigned)n_rays), dim3(64), 0, stream, w, cz, u, n_rays, nc, nf, zout);
+    const int stride = (nc - 1) | 1;                      // odd: lane r walking row r touches every bank once
+    int rpp = RS_ROW_FLOATS / stride;
+    if (rpp > 64) rpp = 64;
+    const int total = nc + nf + 1;
+    const size_t lds = (size_t)RS_WAVES * ((size_t)rpp * stride + nc + (nc + 1) + total + (nf + 1)) * sizeof(float);
+    const long passes = (n_rays + rpp - 1) / rpp;
+    hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((passes + RS_WAVES - 1) / RS_WAVES)), dim3(64 * RS_WAVES), lds,
+                       stream, w, cz, u, n_rays, nc, nf, rpp, stride, zout);
 }
 
 }  // namespace gnr

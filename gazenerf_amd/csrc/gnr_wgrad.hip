@@ -3,31 +3,57 @@
 //   dW[n][k] = sum_s dY[s][n] * X[s][k]      (s over all M samples of the call)
 //
 // dY and X are the chunk-channel-major ("CCM") dumps of the dgrad chain / training forward:
-// element (chunk c, channel n, sample j) at c*32*C + n*32 + j, so the [128 channels][32 samples]
-// operand tile of one chunk is ONE contiguous 16 KiB block: 256 threads stream it with four fully
-// coalesced float4 loads each.  The contraction index is the sample; its order is free, so lane-half
+// element (chunk c, channel n, sample j) at c*32*C + n*32 + j, so the [rows][32 samples]
+// operand tile of one chunk is ONE contiguous block: the threads stream it with fully coalesced
+// float4 loads.  The contraction index is the sample; its order is free, so lane-half
 // h of v_mfma_f32_32x32x2_f32 takes samples 16h..16h+15 of the chunk and a lane reads its operand
 // values for 4 consecutive MFMA steps with one ds_read_b128.  The LDS image keeps the 128-byte rows
 // but XORs the 16-byte piece index with (row/2)%8, which makes both the ds_write_b128 of the staging
 // pass and the ds_read_b128 of the MFMA pass bank-conflict free (MI355X LDS: 64 banks for b128,
 // non-contiguous 16-lane groups).
 //
-// Tiling: 128(n) x 128(k) per 256-thread workgroup = 2x2 waves of 64x64 (2x2 MFMA tiles, 64
-// accumulator registers), chunks double-buffered through 64 KiB of LDS (next chunk's global loads
-// are in flight during the current chunk's 64 MFMAs per wave), two workgroups per CU.  The sample
-// range is split (per image) over workgroups; the 3x3 tiles of one split are placed on one XCD
-// back-to-back so the operand rows they share hit that XCD's L2.  Per-split partial tiles are summed
-// in a fixed order by wgrad_reduce_kernel (deterministic; the reference trains with
-// cudnn.deterministic, train.py:57).
+// Tiling: a workgroup of WN x WK waves, each wave XN x XK MFMA tiles of 32x32, i.e. a
+// (32 XN WN) x (32 XK WK) workgroup tile.  The layer shapes of the MLP (in 32-channel tiles: 12x12 for
+// the 384^2 layers, 6x12 RGB_layer_1, 9x6 RGB_layer_2, 12x2 for the encoding columns of layers 0 / 5)
+// each get the instantiation that covers them WITHOUT padding:
+//     128 x 128  (2x2 waves of 2x2)   384^2 layers                 -- 64 MFMAs per 16 ds_read_b128
+//     192 x  64  (2x2 waves of 3x1)   RGB_layer_1, encoding columns
+//      96 x  96  (3x1 waves of 1x3)   RGB_layer_2 (258 -> 288 = 3 x 96 rows)
+//      64 x 192  (2x2 waves of 1x3)   wide-K / narrow-N shapes of the upsampler
+// (one 128 x 128 tiling for everything spent 9 % of the weight-gradient MFMAs on padding: 50 % of the
+// tiles of RGB_layer_2 and of the encoding columns, 25 % of RGB_layer_1.)
+// Chunks are double-buffered through LDS (next chunk's global loads are in flight during the current
+// chunk's MFMAs), two workgroups per CU.  The sample range is split (per image) over workgroups; the
+// tiles of one split are placed on one XCD back-to-back so the operand rows they share hit that XCD's
+// L2.  Per-split partial tiles are summed in a fixed order by wgrad_reduce_kernel (deterministic; the
+// reference trains with cudnn.deterministic, train.py:57).
 //
-// Riding along on otherwise idle VALU slots:
-//   * column sums of dY (bias gradients, per image)            -- waves with tile-k == 0
-//   * vec^T X for a per-sample vector (density-head gradient)  -- waves with tile-n == 0
+// Riding along, computed from the staging registers (outside the MFMA stream: every VALU instruction
+// between two fp32 MFMAs costs ~15-25 matrix-pipe cycles), only in the workgroups that own them:
+//   * column sums of dY (bias gradients, per image)            -- workgroups with tile-k == 0
+//   * vec^T X for a per-sample vector (density-head gradient)  -- workgroups with tile-n == 0
+#include <type_traits>
+
 #include "gnr_chain3.h"
 
 namespace gnr {
 
-constexpr int WG_TN = 128, WG_TK = 128;    // workgroup tile: 2x2 waves of 64x64
+// Tuning switches (tools/ubench/wgrad_bench.hip builds the variants side by side):
+//   GNR_WG_RIDERS  how wgrad_kernel computes the bias / density riders.  0 none (timing floor; wrong gradients)
+//                  1 from the staging registers, in the workgroups that own them   2 from the operand registers inside
+//                  the MFMA loop, in the workgroups that own them   3 the same in every workgroup (default: measured
+//                  fastest -- a single round of workgroups ends with its slowest member, and in this two-workgroups-
+//                  per-CU kernel a few VALU adds between the MFMAs cost nothing: 384^2 layer 2.65 / 2.77 / 2.92 /
+//                  2.99 ms for modes 3 / 1 / 2 / 0)
+//   GNR_WG_NOPIPE  route chunk-channel-major operands to wgrad_kernel too (instead of wgrad_pipe_kernel)
+//   GNR_PIPE_ABL   timing experiments on wgrad_pipe_kernel, see there
+//   GNR_WG_CLOCK   store workgroup 0's cycle count (s_memtime) for the effective-clock estimate of the bench
+#ifndef GNR_WG_RIDERS
+#define GNR_WG_RIDERS 3
+#endif
+constexpr int RM = GNR_WG_RIDERS;
+
+constexpr int WG_TN = 128, WG_TK = 128;    // tile of the bf16x3 kernel (and the largest fp32 tile: 16384 floats)
 
 struct WgradParams {
     const float* A;      // dY, CCM with C = lda
@@ -38,22 +64,32 @@ struct WgradParams {
     int batch, spi;               // splits per image
     long chunks_per_image;
     long chunks_per_split;
-    float* partial;               // [batch*spi][tiles_n][tiles_k][128][128]
-    float* colsum_part;           // [batch*spi][tiles_n*128]
+    float* partial;               // [batch*spi][tiles_n][tiles_k][TN][TK]
+    float* colsum_part;           // [batch*spi][tiles_n*TN]
     const float* vec;             // [M] or NULL
-    float* vec_part;              // [batch*spi][tiles_k*128]
+    float* vec_part;              // [batch*spi][tiles_k*TK]
     // operand addressing (floats): element (image b, local chunk lc, channel n, sample j) at
     //   b*img + lc*chunk + n*row + j.  CCM dumps: row = 32, chunk = 32*ld, img = chunks_per_image*32*ld;
     //   channels-first images [B][C][P]: row = P, chunk = 32, img = C*P.
     long a_row, a_chunk, a_img, b_row, b_chunk, b_img;
 };
 
-// LDS position (in floats) of 16-byte piece `c` (0..7) of tile row `n` (0..127)
+template <int N>
+__device__ __forceinline__ void wait_vm_dma() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// LDS position (in floats) of 16-byte piece `c` (0..7) of tile row `n`
 __device__ __forceinline__ int swz(int n, int c) { return n * CHUNK + ((c ^ ((n >> 1) & 7)) << 2); }
 
-template <bool VEC>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams wp) {
-    __shared__ __attribute__((aligned(16))) float lds[2][2][WG_TN * CHUNK];     // [buffer][A/B][row*32 + sample]
+template <int WN, int WK, int XN, int XK, bool VEC>
+__global__ __launch_bounds__(64 * WN * WK, 2) void wgrad_kernel(const WgradParams wp) {
+    constexpr int THREADS = 64 * WN * WK;
+    constexpr int TN = 32 * XN * WN, TK = 32 * XK * WK;
+    constexpr int A_IT = TN * 8 / THREADS, B_IT = TK * 8 / THREADS;      // float4 pieces per thread per chunk
+    static_assert(A_IT * THREADS == TN * 8 && B_IT * THREADS == TK * 8, "tile rows must spread evenly over the threads");
+    constexpr int BUF = (TN + TK) * CHUNK;
+    __shared__ __attribute__((aligned(16))) float lds[2][BUF];              // [buffer][A rows | B rows][32 samples]
     // XCD-aware placement: workgroup id -> (xcd, slot); an XCD runs the tiles of one split back-to-back
     const int tiles = wp.tiles_n * wp.tiles_k;
     const int id = blockIdx.x;
@@ -62,6 +98,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams wp) {
     const int tile = slot % tiles;
     if (split >= wp.batch * wp.spi) return;
     const int tn = tile / wp.tiles_k, tk = tile - tn * wp.tiles_k;
+#ifdef GNR_WG_CLOCK
+    const unsigned long long clk0 = __builtin_readcyclecounter();
+#endif
 
     // Two workgroups share each SIMD's matrix pipe.  With equal priority they advance in lock-step
     // and reach their per-chunk barrier together, idling the pipe; a static priority for the wave
@@ -69,6 +108,240 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams wp) {
     // stages/syncs, and the roles alternate by themselves.
     if (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) __builtin_amdgcn_s_setprio(1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave / WK, wk = wave - wn * WK;
+    const int li = lane & 31, lh = lane >> 5;
+    const int b = split / wp.spi, sp = split - b * wp.spi;
+    const long c0 = (long)b * wp.chunks_per_image + (long)sp * wp.chunks_per_split;
+    long c1 = c0 + wp.chunks_per_split;
+    const long cmax = (long)(b + 1) * wp.chunks_per_image;
+    if (c1 > cmax) c1 = cmax;
+    const bool do_cs = tk == 0, do_vs = VEC && tn == 0;     // workgroup-uniform
+
+    // staging: float4 piece f = tid + THREADS q: tile row f/8, piece f%8 == tid%8 (rows clamped into the
+    // buffer: rows/cols beyond it only feed outputs that are dropped)
+    const int pc = tid & 7;
+    const float* ga[A_IT];
+    const float* gb[B_IT];
+    int lposa[A_IT], lposb[B_IT];
+#pragma unroll
+    for (int q = 0; q < A_IT; ++q) {
+        const int r = (tid + THREADS * q) >> 3;
+        int n = tn * TN + r; if (n >= wp.lda) n = wp.lda - 1;
+        ga[q] = wp.A + (long)b * wp.a_img + (long)n * wp.a_row + 4 * pc - (long)b * wp.chunks_per_image * wp.a_chunk;
+        lposa[q] = swz(r, pc);
+    }
+#pragma unroll
+    for (int q = 0; q < B_IT; ++q) {
+        const int r = (tid + THREADS * q) >> 3;
+        int k = tk * TK + r; if (k >= wp.ldb) k = wp.ldb - 1;
+        gb[q] = wp.B + (long)b * wp.b_img + (long)k * wp.b_row + 4 * pc - (long)b * wp.chunks_per_image * wp.b_chunk;
+        lposb[q] = TN * CHUNK + swz(r, pc);
+    }
+    const long strideA = wp.a_chunk, strideB = wp.b_chunk;
+    const float* pv = VEC ? wp.vec + 4 * pc : nullptr;
+    f32x4 ra[A_IT], rb[B_IT], rv;
+    float cs[A_IT], vs[B_IT];
+#pragma unroll
+    for (int q = 0; q < A_IT; ++q) cs[q] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < B_IT; ++q) vs[q] = 0.0f;
+    auto gload = [&](long c) {
+#pragma unroll
+        for (int q = 0; q < A_IT; ++q) ra[q] = *(const f32x4*)(ga[q] + c * strideA);
+#pragma unroll
+        for (int q = 0; q < B_IT; ++q) rb[q] = *(const f32x4*)(gb[q] + c * strideB);
+        if (RM == 1 && do_vs) rv = *(const f32x4*)(pv + c * CHUNK);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < A_IT; ++q) *(f32x4*)&lds[buf][lposa[q]] = ra[q];
+#pragma unroll
+        for (int q = 0; q < B_IT; ++q) *(f32x4*)&lds[buf][lposb[q]] = rb[q];
+        // riders, from the staging registers (every chunk is staged exactly once)
+        if (RM == 1 && do_cs) {
+#pragma unroll
+            for (int q = 0; q < A_IT; ++q) cs[q] += (ra[q].x + ra[q].y) + (ra[q].z + ra[q].w);
+        }
+        if (RM == 1 && do_vs) {
+#pragma unroll
+            for (int q = 0; q < B_IT; ++q)
+                vs[q] += fmaf(rv.x, rb[q].x, rv.y * rb[q].y) + fmaf(rv.z, rb[q].z, rv.w * rb[q].w);
+        }
+    };
+
+    f32x16 acc[XN][XK];
+#pragma unroll
+    for (int x = 0; x < XN; ++x)
+#pragma unroll
+        for (int y = 0; y < XK; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.0f;
+
+    // operand read positions of this lane: rows wn*32*XN + 32x + li (A) / wk*32*XK + 32y + li (B), pieces 4lh + g
+    int apos[XN][4], bpos[XK][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int x = 0; x < XN; ++x) apos[x][g] = swz(wn * 32 * XN + 32 * x + li, 4 * lh + g);
+#pragma unroll
+        for (int y = 0; y < XK; ++y) bpos[y][g] = TN * CHUNK + swz(wk * 32 * XK + 32 * y + li, 4 * lh + g);
+    }
+
+    if (c0 < c1) {
+        gload(c0);
+        lstore(0);
+    }
+    __syncthreads();
+    // in-loop riders (RM 2/3): from the operand registers of the waves that own the rows
+    float csl[XN], vsl[XK];
+#pragma unroll
+    for (int x = 0; x < XN; ++x) csl[x] = 0.0f;
+#pragma unroll
+    for (int y = 0; y < XK; ++y) vsl[y] = 0.0f;
+    auto loop = [&](auto tag) {
+        constexpr bool RIDE = decltype(tag)::value;
+        const bool my_cs = RIDE && wk == 0 && (RM == 3 || do_cs);
+        const bool my_vs = RIDE && VEC && wn == 0 && (RM == 3 || do_vs);
+        for (long c = c0; c < c1; ++c) {
+            const int buf = (int)((c - c0) & 1);
+            if (c + 1 < c1) gload(c + 1);
+            f32x4 v4[4];
+            if (RIDE && VEC) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) v4[g] = *(const f32x4*)(wp.vec + c * CHUNK + 16 * lh + 4 * g);
+            }
+            // all operand reads of the chunk first (one exposed LDS latency per chunk, not per 4 steps)
+            f32x4 av[XN][4], bv[XK][4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int x = 0; x < XN; ++x) av[x][g] = *(const f32x4*)&lds[buf][apos[x][g]];
+#pragma unroll
+                for (int y = 0; y < XK; ++y) bv[y][g] = *(const f32x4*)&lds[buf][bpos[y][g]];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int x = 0; x < XN; ++x)
+#pragma unroll
+                        for (int y = 0; y < XK; ++y) acc[x][y] = mfma32(av[x][g][e], bv[y][g][e], acc[x][y]);
+                    if (RIDE) {
+                        if (my_cs) {
+#pragma unroll
+                            for (int x = 0; x < XN; ++x) csl[x] += av[x][g][e];
+                        }
+                        if (my_vs) {
+#pragma unroll
+                            for (int y = 0; y < XK; ++y) vsl[y] = fmaf(v4[g][e], bv[y][g][e], vsl[y]);
+                        }
+                    }
+                }
+            }
+            if (c + 1 < c1) lstore(buf ^ 1);
+            __syncthreads();
+        }
+    };
+    if (RM == 3 || (RM == 2 && (do_cs || do_vs))) loop(std::true_type{});
+    else loop(std::false_type{});
+
+#ifdef GNR_WG_CLOCK
+    if (id == 0 && tid == 0) *(unsigned long long*)(wp.vec_part + 1024 * 192 - 2) = __builtin_readcyclecounter() - clk0;
+#endif
+    float* pt = wp.partial + (((long)split * wp.tiles_n + tn) * wp.tiles_k + tk) * (long)(TN * TK);
+#pragma unroll
+    for (int x = 0; x < XN; ++x)
+#pragma unroll
+        for (int y = 0; y < XK; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = wn * 32 * XN + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int jx = wk * 32 * XK + y * 32 + li;
+                pt[i * TK + jx] = acc[x][y][r];
+            }
+    if (RM >= 2) {
+        if (do_cs && wk == 0) {
+#pragma unroll
+            for (int x = 0; x < XN; ++x) {
+                const float t = csl[x] + __shfl_xor(csl[x], 32);
+                if (lh == 0) wp.colsum_part[(long)split * (wp.tiles_n * TN) + tn * TN + wn * 32 * XN + 32 * x + li] = t;
+            }
+        }
+        if (do_vs && wn == 0) {
+#pragma unroll
+            for (int y = 0; y < XK; ++y) {
+                const float t = vsl[y] + __shfl_xor(vsl[y], 32);
+                if (lh == 0) wp.vec_part[(long)split * (wp.tiles_k * TK) + tk * TK + wk * 32 * XK + 32 * y + li] = t;
+            }
+        }
+    }
+    // riders: the eight threads tid%8 = 0..7 of a row hold its eight 4-sample pieces
+    if (RM == 1 && do_cs) {
+#pragma unroll
+        for (int q = 0; q < A_IT; ++q) {
+            float t = cs[q];
+            t += __shfl_xor(t, 1);
+            t += __shfl_xor(t, 2);
+            t += __shfl_xor(t, 4);
+            if (pc == 0) wp.colsum_part[(long)split * (wp.tiles_n * TN) + tn * TN + ((tid + THREADS * q) >> 3)] = t;
+        }
+    }
+    if (RM == 1 && do_vs) {
+#pragma unroll
+        for (int q = 0; q < B_IT; ++q) {
+            float t = vs[q];
+            t += __shfl_xor(t, 1);
+            t += __shfl_xor(t, 2);
+            t += __shfl_xor(t, 4);
+            if (pc == 0) wp.vec_part[(long)split * (wp.tiles_k * TK) + tk * TK + ((tid + THREADS * q) >> 3)] = t;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// wgrad_pipe_kernel: the same GEMM as ONE software-pipelined workgroup per CU (chunk-channel-major operands).
+//
+// Why: in wgrad_kernel every chunk ends with [wait for the global loads, ds_write_b128 x8, barrier, ds_read_b128 x16,
+// wait] before the next MFMA -- ~1350 matrix-pipe cycles per 4096-cycle chunk when a workgroup runs alone on a CU
+// (measured, tools/ubench/wgrad_bench.hip), and the second resident workgroup hides only ~950 of them.  Here one wave
+// per SIMD owns the whole 512-entry register file and nothing waits:
+//   * 2x2 waves of XN x XK MFMA tiles: 3x3 for the 384^2 layers = a 192 x 192 workgroup tile: 144 accumulator
+//     registers, 24 ds_read_b128 per 144 MFMAs (wgrad_kernel: 16 per 64) and 85 staged bytes per MFMA (128);
+//   * the operands of chunk c+1 are read into a SECOND register set underneath the MFMAs of chunk c;
+//   * chunk c+2 arrives by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB per wave instruction, XOR swizzle applied to
+//     the source address) into a ring of three LDS buffers (144 KiB): a DMA has a whole chunk period (~4 us) to
+//     land, and there are no staging registers, no ds_write, no vmcnt wait in front of anything;
+//   * one s_waitcnt vmcnt(0) + s_barrier per chunk, placed where the matrix pipe still has the last MFMAs queued.
+// Riders (bias column sums, density-head dot) come from the operand registers as masked FMAs, the same in every
+// wave and workgroup (a single round of workgroups ends with its slowest member): the 2 tiles_k waves-columns that
+// hold the same dY rows share the 16 k-steps of a lane-half between them (mask per 4-step group), likewise the
+// 2 tiles_n wave-rows for the density vector; wgrad_reduce_kernel adds the shares.
+// ---------------------------------------------------------------------------------------------
+#ifndef GNR_PIPE_ABL
+#define GNR_PIPE_ABL 0      // timing experiments (wrong results): 1 no riders, 2 no DMA requests in the loop, 4 no per-chunk wait + barrier
+#endif
+constexpr int PABL = GNR_PIPE_ABL;
+
+template <int XN, int XK, bool VEC, int CSG>
+__global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradParams wp) {
+    constexpr int TN = 64 * XN, TK = 64 * XK;
+    constexpr int BUF_BYTES = (TN + TK) * CHUNK * 4;
+    constexpr int PA = TN / 8 / 4, PB = TK / 8 / 4;               // 1 KiB DMA pieces per wave per chunk
+    __shared__ __attribute__((aligned(1024))) char lds[3 * BUF_BYTES];
+    const int tiles = wp.tiles_n * wp.tiles_k;
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int split = xcd + 8 * (slot / tiles);
+    const int tile = slot % tiles;
+    if (split >= wp.batch * wp.spi) return;
+    const int tn = tile / wp.tiles_k, tk = tile - tn * wp.tiles_k;
+#ifdef GNR_WG_CLOCK
+    const unsigned long long clk0 = __builtin_readcyclecounter();
+#endif
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave >> 1, wk = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
     const int b = split / wp.spi, sp = split - b * wp.spi;
@@ -76,125 +349,191 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams wp) {
     long c1 = c0 + wp.chunks_per_split;
     const long cmax = (long)(b + 1) * wp.chunks_per_image;
     if (c1 > cmax) c1 = cmax;
+    const int nchunks = (int)(c1 - c0);
 
-    // staging: float4 piece f = tid + 256 q: tile row f/8, piece f%8 (rows clamped into the buffer:
-    // rows/cols beyond it only feed outputs that are dropped)
-    const float* ga[4];
-    const float* gb[4];
-    int lpos[4];
+    // LDS-DMA: descriptor per operand with base = first chunk of this split, tile row 0; num_records = end of the
+    // split, so requests for chunks past it return zeros (no tail branches).
+    const unsigned chunk_a = (unsigned)(wp.lda * CHUNK * 4), chunk_b = (unsigned)(wp.ldb * CHUNK * 4);
+    auto desc = [&](const float* base, long ld, long tile_row0, unsigned chunk_bytes) {
+        const unsigned long long a = (unsigned long long)(base + c0 * (CHUNK * ld) + tile_row0 * CHUNK);
+        long bytes = (long)nchunks * chunk_bytes - tile_row0 * CHUNK * 4;
+        if (bytes < 0) bytes = 0;
+        i32x4 r;
+        r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+        r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+        r.z = __builtin_amdgcn_readfirstlane((int)(unsigned)bytes);
+        r.w = 0x00020000;
+        return r;
+    };
+    const i32x4 rsa = desc(wp.A, wp.lda, (long)tn * TN, chunk_a);
+    const i32x4 rsb = desc(wp.B, wp.ldb, (long)tk * TK, chunk_b);
+    // lane l fills slot l%8 of row 8i + l/8 with source piece (l%8) ^ ((4i + l/16) % 8)
+    const unsigned voff_even = (unsigned)(lane >> 3) * 128u + (unsigned)((lane & 7) ^ (lane >> 4)) * 16u;
+    const unsigned voff_odd = voff_even ^ 64u;
+    const unsigned lds0 = (unsigned)(size_t)&lds[0];
+    // piece j (0 .. PA+PB-1) of this wave's share of chunk c0 + k, into ring buffer `buf`
+    auto dma_piece = [&](int k, int buf, int j) {
+        const bool isa = j < PA;
+        const unsigned i = (unsigned)(isa ? wave * PA + j : wave * PB + (j - PA));
+        const unsigned l = lds0 + (unsigned)buf * BUF_BYTES + (isa ? 0u : (unsigned)(TN * CHUNK * 4)) + i * 1024u;
+        const unsigned so = (unsigned)k * (isa ? chunk_a : chunk_b) + i * 1024u;
+        unsigned keep;
+        if (isa)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"((i & 1) ? voff_odd : voff_even), "s"(rsa), "s"(l), "s"(so) : "memory");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"((i & 1) ? voff_odd : voff_even), "s"(rsb), "s"(l), "s"(so) : "memory");
+    };
+    auto dma_chunk = [&](int k, int buf) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int f = tid + 256 * q, r = f >> 3, c = f & 7;
-        int n = tn * WG_TN + r; if (n >= wp.lda) n = wp.lda - 1;
-        int k = tk * WG_TK + r; if (k >= wp.ldb) k = wp.ldb - 1;
-        ga[q] = wp.A + (long)b * wp.a_img + (long)n * wp.a_row + 4 * c - (long)b * wp.chunks_per_image * wp.a_chunk;
-        gb[q] = wp.B + (long)b * wp.b_img + (long)k * wp.b_row + 4 * c - (long)b * wp.chunks_per_image * wp.b_chunk;
-        lpos[q] = swz(r, c);
+        for (int j = 0; j < PA + PB; ++j) dma_piece(k, buf, j);
+    };
+
+    // operand read offsets (bytes within a ring buffer): rows wn*32*XN + 32x + li (A) / wk*32*XK + 32y + li (B).
+    // The swizzle term depends on (row/2)%8 = (li/2)%8 only, so tile x is a constant +4096 bytes (an instruction
+    // offset): four address registers per operand.
+    //
+    // Rider shares without masks: the contraction order is free, so every wave reads the four 4-step groups of its
+    // lane-half in an order ROTATED by rot (the same for A and B): group slot g holds samples 16 lh + 4 ((g + rot) % 4).
+    // The riders then always take slot(s) g < CSG (static code, 12 CSG FMAs per chunk instead of 48 masked ones:
+    // every VALU instruction between two fp32 MFMAs costs ~13 matrix-pipe cycles, measured), and the rotation makes
+    // the slots of the waves that hold the same rows cover different samples:
+    //   dY rows (tn, wn) are held by the 2 tiles_k wave columns qc = 2 tk + wk: CSG = 4 / (2 tiles_k) slots each;
+    //   X rows (tk, wk) by the 2 tiles_n wave rows qv = 2 tn + wn (VEC: tiles_n = tiles_k = 2, one slot each);
+    //   rot = (qc CSG + qv) % 4 is distinct along either family.
+    const int qc = tk * 2 + wk, qv = tn * 2 + wn;
+    const int rot = (qc * CSG + (VEC ? qv : 0)) & 3;
+    int apos[4], bpos[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        apos[g] = 4 * swz(wn * 32 * XN + li, 4 * lh + ((g + rot) & 3));
+        bpos[g] = 4 * (TN * CHUNK + swz(wk * 32 * XK + li, 4 * lh + ((g + rot) & 3)));
     }
-    const long strideA = wp.a_chunk, strideB = wp.b_chunk;
-    f32x4 ra[4], rb[4];
-    auto gload = [&](long c) {
+    float csl[XN], vsl[XK];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            ra[q] = *(const f32x4*)(ga[q] + c * strideA);
-            rb[q] = *(const f32x4*)(gb[q] + c * strideB);
-        }
-    };
-    auto lstore = [&](int buf) {
+    for (int x = 0; x < XN; ++x) csl[x] = 0.0f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            *(f32x4*)&lds[buf][0][lpos[q]] = ra[q];
-            *(f32x4*)&lds[buf][1][lpos[q]] = rb[q];
-        }
-    };
-
-    f32x16 acc[2][2];
+    for (int y = 0; y < XK; ++y) vsl[y] = 0.0f;
+    f32x16 acc[XN][XK];
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+    for (int x = 0; x < XN; ++x)
 #pragma unroll
-        for (int y = 0; y < 2; ++y)
+        for (int y = 0; y < XK; ++y)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.0f;
-    float cs[2] = {0.0f, 0.0f}, vs[2] = {0.0f, 0.0f};
-    const float* pv = VEC ? wp.vec + 16 * lh : nullptr;
 
-    // operand read positions of this lane: rows wn*64 + 32x + li (A) / wk*64 + 32y + li (B), pieces 4lh + g
-    int apos[2][4], bpos[2][4];
+    f32x4 opa[2][XN][4], opb[2][XK][4], vv[2][1];
+    auto read_ops = [&](int buf, f32x4 (&a)[XN][4], f32x4 (&bb)[XK][4], int g) {
+        const char* pa = lds + buf * BUF_BYTES + apos[g];
+        const char* pb = lds + buf * BUF_BYTES + bpos[g];
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+        for (int x = 0; x < XN; ++x) a[x][g] = *(const f32x4*)(pa + x * (32 * CHUNK * 4));
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            apos[x][g] = swz(wn * 64 + 32 * x + li, 4 * lh + g);
-            bpos[x][g] = swz(wk * 64 + 32 * x + li, 4 * lh + g);
-        }
-
-    if (c0 < c1) {
-        gload(c0);
-        lstore(0);
-    }
-    __syncthreads();
-    for (long c = c0; c < c1; ++c) {
-        const int buf = (int)((c - c0) & 1);
-        if (c + 1 < c1) gload(c + 1);
-        f32x4 v4[4];
+        for (int y = 0; y < XK; ++y) bb[y][g] = *(const f32x4*)(pb + y * (32 * CHUNK * 4));
+    };
+    auto load_vec = [&](int k, f32x4 (&v)[1]) {
         if (VEC) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) v4[g] = *(const f32x4*)(pv + c * CHUNK + 4 * g);
+            const long c = c0 + (k < nchunks ? k : nchunks - 1);
+            v[0] = *(const f32x4*)(wp.vec + c * CHUNK + 16 * lh + 4 * rot);        // the samples of slot 0
         }
-        // all 16 operand reads of the chunk first (one exposed LDS latency per 64 MFMAs, not four)
-        f32x4 av[2][4], bv[2][4];
+    };
+
+    // prologue: chunks 0 and 1 in flight; chunk 0's operands into register set 0
+    dma_chunk(0, 0);
+    dma_chunk(1, 1);
+    load_vec(0, vv[0]);
+    wait_vm_dma<PA + PB>();                                 // everything but the last chunk's pieces
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int g = 0; g < 4; ++g) read_ops(0, opa[0], opb[0], g);
+
+    // One chunk: [chunk k+1 landed -> barrier -> request chunk k+2] then 16 MFMA steps of chunk k from register set S
+    // with the operand reads of chunk k+1 into set S^1 placed in front of each 4-step group.
+    auto chunk = [&](int k, int b1, int b2, auto set_tag) {
+        constexpr int S = decltype(set_tag)::value;
+        if (!(PABL & 4)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // chunk k+1 (requested one chunk ago) has landed
+            __builtin_amdgcn_s_barrier();                         // ... in every wave; ring buffer b2 is free
+        }
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            av[0][g] = *(const f32x4*)&lds[buf][0][apos[0][g]];
-            av[1][g] = *(const f32x4*)&lds[buf][0][apos[1][g]];
-            bv[0][g] = *(const f32x4*)&lds[buf][1][bpos[0][g]];
-            bv[1][g] = *(const f32x4*)&lds[buf][1][bpos[1][g]];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
+            __builtin_amdgcn_sched_barrier(0);
+            read_ops(b1, opa[S ^ 1], opb[S ^ 1], g);
+            // the density vector of chunk k+1: requested AFTER this chunk's last DMA piece and first used right
+            // behind the next chunk's vmcnt(0), before that chunk's first piece -- the compiler's own counted wait
+            // for it (it cannot see the asm requests sharing the in-order vmcnt queue) then never waits on a DMA
+            if (g == 3) load_vec(k + 1, vv[S ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float a0 = av[0][g][e], a1 = av[1][g][e], b0 = bv[0][g][e], b1 = bv[1][g][e];
-                acc[0][0] = mfma32(a0, b0, acc[0][0]);
-                acc[0][1] = mfma32(a0, b1, acc[0][1]);
-                acc[1][0] = mfma32(a1, b0, acc[1][0]);
-                acc[1][1] = mfma32(a1, b1, acc[1][1]);
-                cs[0] += a0;
-                cs[1] += a1;
-                if (VEC) {
-                    vs[0] = fmaf(v4[g][e], b0, vs[0]);
-                    vs[1] = fmaf(v4[g][e], b1, vs[1]);
+#pragma unroll
+                for (int x = 0; x < XN; ++x)
+#pragma unroll
+                    for (int y = 0; y < XK; ++y) acc[x][y] = mfma32(opa[S][x][g][e], opb[S][y][g][e], acc[x][y]);
+                if (!(PABL & 1) && g < CSG) {
+#pragma unroll
+                    for (int x = 0; x < XN; ++x) csl[x] += opa[S][x][g][e];
+                    if (VEC && g == 0) {
+#pragma unroll
+                        for (int y = 0; y < XK; ++y) vsl[y] = fmaf(vv[S][0][e], opb[S][y][g][e], vsl[y]);
+                    }
+                    // the rider adds go between the MFMAs, not in one block
+#pragma unroll
+                    for (int i = 0; i < XN; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, XK, 0);          // XK MFMAs
+                        __builtin_amdgcn_sched_group_barrier(0x002, VEC ? 2 : 1, 0);   // rider VALU
+                    }
+                }
+                // the request for chunk k+2 goes out one piece per MFMA step (an LDS-DMA instruction blocks the
+                // issuing wave for ~60 cycles: twelve in a row would drain the matrix pipe at every chunk start)
+                if (4 * g + e < PA + PB && !(PABL & 2)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    dma_piece(k + 2, b2, 4 * g + e);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
-        if (c + 1 < c1) lstore(buf ^ 1);
-        __syncthreads();
+    };
+    int b0 = 0;                                             // ring buffer of chunk k
+    for (int k = 0; k < nchunks; k += 2) {
+        const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+        chunk(k, b1, b2, std::integral_constant<int, 0>{});
+        if (k + 1 < nchunks) chunk(k + 1, b2, b0, std::integral_constant<int, 1>{});
+        b0 = b2;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the zero-filled tail requests
 
-    float* pt = wp.partial + (((long)split * wp.tiles_n + tn) * wp.tiles_k + tk) * (long)(WG_TN * WG_TK);
+#ifdef GNR_WG_CLOCK
+    if (id == 0 && tid == 0) *(unsigned long long*)(wp.vec_part + 1024 * 192 - 2) = __builtin_readcyclecounter() - clk0;
+#endif
+    float* pt = wp.partial + (((long)split * wp.tiles_n + tn) * wp.tiles_k + tk) * (long)(TN * TK);
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+    for (int x = 0; x < XN; ++x)
 #pragma unroll
-        for (int y = 0; y < 2; ++y)
+        for (int y = 0; y < XK; ++y)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int i = wn * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int jx = wk * 64 + y * 32 + li;
-                pt[i * WG_TK + jx] = acc[x][y][r];
+                const int i = wn * 32 * XN + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int jx = wk * 32 * XK + y * 32 + li;
+                pt[i * TK + jx] = acc[x][y][r];
             }
-    if (tk == 0 && wk == 0) {
+    // rider shares: colsum_part[split][q][tiles_n*TN], vec_part[split][q'][tiles_k*TK]
+    {
+        const int Qc = wp.tiles_k * 2, Qv = wp.tiles_n * 2;
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            const float t = cs[x] + __shfl_xor(cs[x], 32);
-            if (lh == 0) wp.colsum_part[(long)split * (wp.tiles_n * WG_TN) + tn * WG_TN + wn * 64 + 32 * x + li] = t;
+        for (int x = 0; x < XN; ++x) {
+            const float t = csl[x] + __shfl_xor(csl[x], 32);
+            if (lh == 0) wp.colsum_part[((long)split * Qc + qc) * (wp.tiles_n * TN) + tn * TN + wn * 32 * XN + 32 * x + li] = t;
         }
-    }
-    if (VEC && tn == 0 && wn == 0) {
+        if (VEC) {
 #pragma unroll
-        for (int y = 0; y < 2; ++y) {
-            const float t = vs[y] + __shfl_xor(vs[y], 32);
-            if (lh == 0) wp.vec_part[(long)split * (wp.tiles_k * WG_TK) + tk * WG_TK + wk * 64 + 32 * y + li] = t;
+            for (int y = 0; y < XK; ++y) {
+                const float t = vsl[y] + __shfl_xor(vsl[y], 32);
+                if (lh == 0) wp.vec_part[((long)split * Qv + qv) * (wp.tiles_k * TK) + tk * TK + wk * 32 * XK + 32 * y + li] = t;
+            }
         }
     }
 }
@@ -372,6 +711,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const WgradParams wp) {
 struct WgradReduceParams {
     const float* partial;
     int splits, tiles_n, tiles_k;
+    int tn_rows, tk_cols;     // workgroup tile of the GEMM kernel that wrote the partials
+    int cs_q, vs_q;           // rider shares per split (wgrad_pipe_kernel: 2 tiles_k / 2 tiles_n; else 1)
     int n_valid, k_valid;
     float* dW;          // destination matrix (NULL: skip)
     int ldw, col_off;
@@ -387,12 +728,13 @@ __global__ void wgrad_reduce_kernel(const WgradReduceParams rp) {
     if (rp.dW)
         for (long e = gid; e < total; e += gsz) {
             const int n = (int)(e / rp.k_valid), k = (int)(e % rp.k_valid);
-            const int tn = n / WG_TN, i = n % WG_TN, tk = k / WG_TK, j = k % WG_TK;
+            const int tn = n / rp.tn_rows, i = n % rp.tn_rows, tk = k / rp.tk_cols, j = k % rp.tk_cols;
             // fixed summation order (deterministic); 8 loads in flight per thread instead of a
             // load -> add dependency chain over ~112 splits
             float acc = 0.0f;
-            const float* src = rp.partial + ((long)tn * rp.tiles_k + tk) * (long)(WG_TN * WG_TK) + i * WG_TK + j;
-            const long sstride = (long)rp.tiles_n * rp.tiles_k * (WG_TN * WG_TK);
+            const long tsz = (long)rp.tn_rows * rp.tk_cols;
+            const float* src = rp.partial + ((long)tn * rp.tiles_k + tk) * tsz + i * rp.tk_cols + j;
+            const long sstride = (long)rp.tiles_n * rp.tiles_k * tsz;
             int sp = 0;
             for (; sp + 8 <= rp.splits; sp += 8) {
                 float v[8];
@@ -413,22 +755,40 @@ __global__ void wgrad_reduce_kernel(const WgradReduceParams rp) {
         for (long e = gid; e < (long)rp.batch * rp.n_valid; e += gsz) {
             const int b = (int)(e / rp.n_valid), n = (int)(e % rp.n_valid);
             float acc = 0.0f;
-            for (int sp = 0; sp < rp.spi; ++sp)
-                acc += rp.colsum_part[((long)b * rp.spi + sp) * (rp.tiles_n * WG_TN) + n];
+            for (int sp = 0; sp < rp.spi * rp.cs_q; ++sp)
+                acc += rp.colsum_part[((long)b * rp.spi * rp.cs_q + sp) * (rp.tiles_n * rp.tn_rows) + n];
             rp.colsum_out[(long)b * rp.colsum_ld + n] = acc;
         }
     if (rp.vec_out)
         for (long e = gid; e < rp.k_valid; e += gsz) {
             float acc = 0.0f;
-            for (int sp = 0; sp < rp.splits; ++sp) acc += rp.vec_part[(long)sp * (rp.tiles_k * WG_TK) + e];
+            for (int sp = 0; sp < rp.splits * rp.vs_q; ++sp) acc += rp.vec_part[(long)sp * (rp.tiles_k * rp.tk_cols) + e];
             rp.vec_out[e] = acc;
         }
 }
 
 constexpr int WG_MAX_BLOCKS = 1024;       // splits * tiles bound: ~2 rounds of 2 workgroups per CU
+constexpr int WG_MAX_TILE = WG_TN * WG_TK;    // floats; every tile configuration stays below it
+constexpr int WG_RIDER_ROWS = 192;            // largest tile edge
 
 size_t wgrad_scratch_floats() {
-    return (size_t)WG_MAX_BLOCKS * WG_TN * WG_TK + (size_t)WG_MAX_BLOCKS * WG_TN + (size_t)WG_MAX_BLOCKS * WG_TK;
+    return (size_t)WG_MAX_BLOCKS * WG_MAX_TILE + 2 * (size_t)WG_MAX_BLOCKS * WG_RIDER_ROWS;
+}
+
+// fp32 tile configurations: {rows, cols, relative cost per MFMA slot (LDS reads per MFMA, 3-wave workgroups)}
+struct TileCfg { int tn, tk; float cost; };
+static const TileCfg kTileCfgs[4] = {{128, 128, 1.00f}, {192, 64, 1.04f}, {64, 192, 1.04f}, {96, 96, 1.08f}};
+
+static int choose_tile(int n_valid, int k_valid, bool vec) {
+    if (vec) return 0;                                  // the rider variant exists for the 128 x 128 tile only
+    int best = 0;
+    float best_cost = 0.0f;
+    for (int i = 0; i < 4; ++i) {
+        const TileCfg& c = kTileCfgs[i];
+        const float cost = (float)((n_valid + c.tn - 1) / c.tn) * (float)((k_valid + c.tk - 1) / c.tk) * c.tn * c.tk * c.cost;
+        if (i == 0 || cost < best_cost) { best = i; best_cost = cost; }
+    }
+    return best;
 }
 
 // dW[n_valid x k_valid] (+ col_off, optional encoding-slot map) = A^T B over all chunks.
@@ -446,15 +806,26 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
         wp.a_row = CHUNK; wp.a_chunk = (long)CHUNK * lda; wp.a_img = chunks_per_image * wp.a_chunk;
         wp.b_row = CHUNK; wp.b_chunk = (long)CHUNK * ldb; wp.b_img = chunks_per_image * wp.b_chunk;
     }
-    wp.tiles_n = (n_valid + WG_TN - 1) / WG_TN;
-    wp.tiles_k = (k_valid + WG_TK - 1) / WG_TK;
+    const bool with_vec = vec_out != nullptr;
+    // chunk-channel-major fp32 operands of the MLP's shapes go to the pipelined one-workgroup-per-CU kernel
+    // (192-row tiles; K = 64 for the encoding columns); everything else to the two-workgroups-per-CU kernel
+    int pipe_xk = 0;
+#ifndef GNR_WG_NOPIPE
+    if (!bf16x3 && pixels_per_image == 0 && n_valid <= 384 && (k_valid == 64 || k_valid == 192 || k_valid == 384) &&
+        (!with_vec || (n_valid > 192 && k_valid == 384)))        // the density rider needs the 2 x 2 tile grid
+        pipe_xk = k_valid == 64 ? 1 : 3;
+#endif
+    const int cfg = (bf16x3 || pipe_xk) ? 0 : choose_tile(n_valid, k_valid, with_vec);
+    const int TN = pipe_xk ? 192 : kTileCfgs[cfg].tn, TK = pipe_xk ? 64 * pipe_xk : kTileCfgs[cfg].tk;
+    wp.tiles_n = (n_valid + TN - 1) / TN;
+    wp.tiles_k = (k_valid + TK - 1) / TK;
     const int tiles = wp.tiles_n * wp.tiles_k;
     // Split count: the kernel places split s on XCD s % 8 (32 CUs x 2 resident workgroups = 64 slots
-    // per XCD).  Every XCD must get the SAME number of workgroups and fill whole rounds, otherwise
-    // the launch waits for one XCD's straggler round (113 splits instead of 112 cost 40 %):
-    // splits = 8 * floor(64 slots / tiles), made divisible by the batch: ONE round of workgroups.  (Two rounds
-    // ran the GEMM no faster and doubled the partial tiles the reduce kernel has to sum: 60 -> 27 us per layer.)
-    long splits_total = 8L * (64 / tiles);
+    // per XCD; the pipelined kernel runs one workgroup per CU: 32 slots).  Every XCD must get the SAME number of
+    // workgroups and fill whole rounds, otherwise the launch waits for one XCD's straggler round (113 splits instead
+    // of 112 cost 40 %): splits = 8 * floor(slots / tiles), made divisible by the batch: ONE round of workgroups.
+    // (Two rounds ran the GEMM no faster and doubled the partial tiles the reduce kernel has to sum.)
+    long splits_total = 8L * ((pipe_xk ? 32 : 64) / tiles);
     if (splits_total < 8) splits_total = 8;
     long spi = splits_total / batch;
     if (spi < 1) spi = 1;
@@ -464,22 +835,36 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
     wp.chunks_per_image = chunks_per_image;
     wp.chunks_per_split = (chunks_per_image + spi - 1) / spi;
     wp.partial = scratch;
-    float* cs_part = scratch + (size_t)WG_MAX_BLOCKS * WG_TN * WG_TK;
-    float* vec_part = cs_part + (size_t)WG_MAX_BLOCKS * WG_TN;
+    float* cs_part = scratch + (size_t)WG_MAX_BLOCKS * WG_MAX_TILE;
+    float* vec_part = cs_part + (size_t)WG_MAX_BLOCKS * WG_RIDER_ROWS;
     wp.colsum_part = cs_part;
-    wp.vec = vec_out ? vec : nullptr;
+    wp.vec = with_vec ? vec : nullptr;
     wp.vec_part = vec_part;
     const int splits = batch * (int)spi;
     const unsigned blocks = (unsigned)(8 * ((splits + 7) / 8) * tiles);
-    if (bf16x3) {
+    if (pipe_xk) {
+        // CSG = rider slots per wave = 4 / (2 tiles_k)
+        if (pipe_xk == 1) hipLaunchKernelGGL((wgrad_pipe_kernel<3, 1, false, 2>), dim3(blocks), dim3(256), 0, stream, wp);
+        else if (wp.vec) hipLaunchKernelGGL((wgrad_pipe_kernel<3, 3, true, 1>), dim3(blocks), dim3(256), 0, stream, wp);
+        else if (wp.tiles_k == 2) hipLaunchKernelGGL((wgrad_pipe_kernel<3, 3, false, 1>), dim3(blocks), dim3(256), 0, stream, wp);
+        else hipLaunchKernelGGL((wgrad_pipe_kernel<3, 3, false, 2>), dim3(blocks), dim3(256), 0, stream, wp);
+    } else if (bf16x3) {
         if (wp.vec) hipLaunchKernelGGL((wgrad3_kernel<true>), dim3(blocks), dim3(256), 0, stream, wp);
         else hipLaunchKernelGGL((wgrad3_kernel<false>), dim3(blocks), dim3(256), 0, stream, wp);
+    } else if (wp.vec) {
+        hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2, true>), dim3(blocks), dim3(256), 0, stream, wp);
     } else {
-        if (wp.vec) hipLaunchKernelGGL((wgrad_kernel<true>), dim3(blocks), dim3(256), 0, stream, wp);
-        else hipLaunchKernelGGL((wgrad_kernel<false>), dim3(blocks), dim3(256), 0, stream, wp);
+        switch (cfg) {
+            case 0: hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2, false>), dim3(blocks), dim3(256), 0, stream, wp); break;
+            case 1: hipLaunchKernelGGL((wgrad_kernel<2, 2, 3, 1, false>), dim3(blocks), dim3(256), 0, stream, wp); break;
+            case 2: hipLaunchKernelGGL((wgrad_kernel<2, 2, 1, 3, false>), dim3(blocks), dim3(256), 0, stream, wp); break;
+            default: hipLaunchKernelGGL((wgrad_kernel<3, 1, 1, 3, false>), dim3(blocks), dim3(192), 0, stream, wp); break;
+        }
     }
     WgradReduceParams rp{};
     rp.partial = scratch; rp.splits = splits; rp.tiles_n = wp.tiles_n; rp.tiles_k = wp.tiles_k;
+    rp.tn_rows = TN; rp.tk_cols = TK;
+    rp.cs_q = pipe_xk ? 2 * wp.tiles_k : 1; rp.vs_q = pipe_xk ? 2 * wp.tiles_n : 1;
     rp.n_valid = n_valid; rp.k_valid = k_valid; rp.dW = dW; rp.ldw = ldw; rp.col_off = col_off; rp.enc_map = enc_map;
     rp.colsum_part = cs_part; rp.colsum_out = colsum_out; rp.colsum_ld = colsum_ld; rp.batch = batch; rp.spi = (int)spi;
     rp.vec_part = vec_part; rp.vec_out = vec_out ? vec_out : nullptr;

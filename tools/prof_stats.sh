@@ -1,12 +1,14 @@
 #!/bin/bash
-# rocprofv3 kernel-trace stats of one bench.py run on the GPU box -> gpurun_out/<name>_kernel_stats.csv
+# rocprofv3 kernel-trace + stats of a bench.py run on the GPU box; the stats CSV lands in gpurun_out/<name>/.
 # usage: tools/prof_stats.sh <name> <bench args...>
 set -u
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 NAME=$1; shift
-mkdir -p $R/gpurun_out
+OUT=$R/gpurun_out/$NAME
+mkdir -p $OUT
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$NAME -o $NAME -- python $R/bench.py "$@" --no-cpu-baseline > $R/gpurun_out/$NAME.log 2>&1
-f=$(find /tmp/prof_$NAME -name "*kernel_stats.csv" | head -1)
-if [ -n "$f" ]; then cp "$f" $R/gpurun_out/${NAME}_kernel_stats.csv; head -16 "$f" | cut -c1-160; else echo "no stats file"; tail -5 $R/gpurun_out/$NAME.log; fi
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o run -- python $R/bench.py "$@" --no-cpu-baseline > $OUT/bench.log 2>&1
+find $OUT/prof -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+head -40 $OUT/kernel_stats.csv
+tail -c 600 $OUT/bench.log
