@@ -44,6 +44,9 @@ PEAK_FP32_MFMA_TFLOPS = 157.3                 # MI355X_MICROARCH.md chip-level p
 # bf16x3: three bf16 MFMAs per fp32-equivalent product -> a third of the 16x fp32 rate (dense bf16 peak / 3)
 PEAK_BF16X3_TFLOPS = 16.0 * PEAK_FP32_MFMA_TFLOPS / 3.0
 HBM_PEAK_GBS = 8000.0
+# the weight-gradient stage: its main kernel instance first (the 384^2 layers), then what else runs inside the bracket
+WGRAD_KERNEL = {False: "gnr::wgrad_pipe_kernel<3, 3, false, 1> + its other instances + gnr::wgrad_reduce_kernel",
+                True: "gnr::wgrad3_kernel<false> + gnr::wgrad3_kernel<true> + gnr::wgrad_reduce_kernel"}
 
 
 def parse():
@@ -359,7 +362,7 @@ def run_cfg2b(ctx):
             defs += [("dgrad", "dgrad chain (timed on the first stream; runs once per stream)",
                       "gnr::bwd%s_chain_kernel" % sfx, flop_1s, 2),
                      ("wgrad", "weight-gradient GEMMs + split reductions (12 layer GEMMs, timed on the first stream; once per stream)",
-                      "gnr::wgrad%s_kernel + gnr::wgrad_reduce_kernel" % sfx, flop_1s, 2)]
+                      WGRAD_KERNEL[x3], flop_1s, 2)]
         stages = []
         for key, what, kernel, flop, per_step_mult in defs:
             a = mean(stage_ms.get(key, []))
@@ -510,7 +513,7 @@ def run_cfg4(ctx):
     stages = []
     for key, kernel, flop, mult in (("fwd_mlp", "gnr::fwd%s_kernel<true>" % sfx, m * 2 * FLOP_PER_SAMPLE_STREAM, 1),
                                     ("dgrad", "gnr::bwd%s_chain_kernel" % sfx, m * FLOP_PER_SAMPLE_STREAM, 2),
-                                    ("wgrad", "gnr::wgrad%s_kernel + gnr::wgrad_reduce_kernel" % sfx, m * FLOP_PER_SAMPLE_STREAM, 2)):
+                                    ("wgrad", WGRAD_KERNEL[x3], m * FLOP_PER_SAMPLE_STREAM, 2)):
         a = mean(stage_ms[key])
         ach = flop / (a * 1e-3) / 1e12 if a > 0 else 0.0
         stages.append({"stage": key, "kernel": kernel, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
