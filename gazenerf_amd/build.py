@@ -68,5 +68,34 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+TORCH_EXT = os.path.join(HERE, "_gnr_torch.so")
+
+
+def build_torch_ext(force: bool = False, verbose: bool = True) -> str:
+    """Compile the PyTorch-ROCm C++ binding (csrc/gnr_torch.cpp: host code only) in-tree against libgnr.so."""
+    import sysconfig
+
+    import torch
+    from torch.utils import cpp_extension as E
+    src = os.path.join(CSRC, "gnr_torch.cpp")
+    if not (force or _stale(TORCH_EXT, [src, LIB, os.path.join(HERE, "..", "include", "gnr.h")])):
+        return TORCH_EXT
+    inc = list(E.include_paths("cuda")) + [sysconfig.get_paths()["include"], "/opt/rocm/include"]
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = [HIPCC, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
+           "-DTORCH_EXTENSION_NAME=_gnr_torch", "-DTORCH_API_INCLUDE_EXTENSION_H", "-DUSE_ROCM=1",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+    cmd += ["-I" + i for i in inc] + [src, "-o", TORCH_EXT, "-L" + HERE, "-lgnr", "-Wl,-rpath,$ORIGIN",
+                                      "-L" + tlib, "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python"]
+    if verbose:
+        print("[gnr build]", " ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("torch extension build failed:\n%s\n%s" % (r.stdout[-3000:], r.stderr[-3000:]))
+    return TORCH_EXT
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    if "--no-torch-ext" not in sys.argv:
+        print(build_torch_ext(force="--force" in sys.argv))

@@ -25,7 +25,7 @@ from typing import Dict, Optional, Sequence
 
 import torch
 
-from . import _lib
+from . import _lib, _torch_ext
 
 PARAM_ORDER = tuple(
     ["FeaExt_module_%d.%s" % (i, k) for i in range(8) for k in ("weight", "bias")]
@@ -144,7 +144,28 @@ def _alloc_ws(nbytes, device):
     return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
 
 
+def _ext_call(fn, *args):
+    """TORCH_CHECK failures of the C++ binding surface as the same exception class the ctypes binding raises."""
+    try:
+        return fn(*args)
+    except RuntimeError as e:
+        raise _lib.GnrError(str(e).split("\n")[0]) from None
+
+
 def _run_forward(prob: _Problem, streams, save: bool, want_depth: bool, want_weights: bool, bf16x3: bool = False):
+    ext = _torch_ext.active()
+    if ext is not None:                # C++ binding: device guard, current stream, allocation and checks in C++
+        t = prob.tensors
+        flat = _ext_call(ext.render_fwd, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], streams[0],
+                              streams[1] if len(streams) > 1 else [], prob.n_p, prob.c.world_z1, prob.c.world_z2,
+                              prob.c.hidden, prob.c.feat_nc, bool(save), bool(want_depth), bool(want_weights), bool(bf16x3),
+                              bool(prob.c.edges_follow_T))
+        per = 2 + int(want_depth) + int(want_weights)
+        res = []
+        for s in range(len(streams)):
+            o = flat[s * per:(s + 1) * per]
+            res.append((o[0], o[1], o[2] if want_depth else None, o[-1] if want_weights else None))
+        return res, flat[-1]
     lib = _lib.load()
     dev = prob.device
     n_streams = len(streams)
@@ -179,6 +200,14 @@ def _run_forward(prob: _Problem, streams, save: bool, want_depth: bool, want_wei
 def _run_backward(prob: _Problem, streams, gout, saved_ws, bf16x3: bool):
     """One gnr_bwd call.  ``gout``: per stream (d feat [B,C,N_r] | None, d bg_alpha [B,1,N_r] | None), contiguous
     fp32.  Returns ([gR, gT, gshape, ggaze, gappea], [[24 parameter gradients] per stream])."""
+    ext = _torch_ext.active()
+    if ext is not None:
+        t = prob.tensors
+        flat = _ext_call(ext.render_bwd, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], streams[0],
+                              streams[1] if len(streams) > 1 else [], [g[0] for g in gout], [g[1] for g in gout], saved_ws,
+                              prob.n_p, prob.c.world_z1, prob.c.world_z2, prob.c.hidden, prob.c.feat_nc, bool(bf16x3),
+                              bool(prob.c.edges_follow_T))
+        return list(flat[:5]), [list(flat[5 + 24 * s:5 + 24 * (s + 1)]) for s in range(len(streams))]
     lib = _lib.load()
     dev = prob.device
     n_streams = len(streams)

@@ -65,3 +65,20 @@ def test_render_op_refuses_cpu_tensors(lib_built):
     with pytest.raises(RuntimeError, match="no CPU path"):
         render.render_two_stream(prob["xy"], prob["R"], prob["T"], prob["Kinv"], prob["shape_code"],
                                  prob["gaze"], prob["appea_code"], face, face, n_samples=32)
+
+
+def test_torch_extension_builds_and_loads(lib_built):
+    """The PyTorch-ROCm C++ binding (csrc/gnr_torch.cpp) compiles against libgnr.so, imports, reports the same ABI
+    and raises Python exceptions from TORCH_CHECK / gnr_last_error (no GPU needed for those paths)."""
+    import pytest
+    import torch
+    from gazenerf_amd import _lib, _torch_ext, build
+    build.build_torch_ext(verbose=False)
+    ext = _torch_ext.load(required=True)
+    assert ext.abi_version() == _lib.ABI_VERSION
+    assert ext.saved_workspace_bytes(2, 4096, 64, 384, 258, 2) > 15e9          # cfg3: ~17 GB of saved activations
+    with pytest.raises(RuntimeError, match="hidden=384"):
+        ext.saved_workspace_bytes(1, 16, 64, 256, 258, 2)
+    x = torch.zeros(1, 2, 4)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ext.render_fwd(x, x, x, x, x, x, x, None, None, [], [], 32, 2.5, -3.5, 384, 258, False, False, False, False, False)

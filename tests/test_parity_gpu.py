@@ -772,3 +772,33 @@ def test_hierarchical_camera_gradient_follows_the_reference():
                                   _to(fine, dev), None, n_samples=192, z_edges=edges)
     ((fo["feat_face"] ** 2).mean() + fo["bg_alpha_face"].mean()).backward()
     assert float((Tc.grad.cpu() - T.grad).abs().max()) > 0.2 * float(T.grad.abs().max())
+
+
+# ----------------------------------------------------------------------------- the two bindings of the C ABI
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_torch_extension_and_ctypes_bindings_agree(precision, monkeypatch):
+    """The PyTorch C++ extension (default when built) and the ctypes binding call the same C ABI: bit-identical
+    outputs and gradients; and the extension really is the active binding on this box."""
+    from gazenerf_amd import _torch_ext
+    dev = _dev()
+    assert _torch_ext.load(required=True) is not None
+    p = synth.synth_problem(64, batch=2, camera="2", seed=1, ray_subset=torch.arange(80) * 61 % 4096)
+    face = synth.hash_mlp_params("face", seed=0, density_scale=50.0)
+    eyes = synth.hash_mlp_params("eyes", seed=0, density_scale=50.0)
+    t_rand = synth.synth_jitter(2, 80, 64, seed=2)
+    res = {}
+    for binding in ("torch_ext", "ctypes"):
+        monkeypatch.setenv("GNR_BINDING", binding)
+        assert (_torch_ext.active() is not None) == (binding == "torch_ext")
+        res[binding] = _grads_hip(p, face, eyes, 64, t_rand, dev, precision)
+    a, b = res["torch_ext"], res["ctypes"]
+    for k in ("feat_face", "bg_alpha_face", "feat_eyes", "bg_alpha_eyes"):
+        assert torch.equal(a[0][k], b[0][k]), k
+    for i in (1, 2, 3):
+        for k in a[i]:
+            assert torch.equal(a[i][k].grad, b[i][k].grad), k
+    monkeypatch.setenv("GNR_BINDING", "torch_ext")
+    pd = _to(p, dev)
+    with pytest.raises(RuntimeError, match="n_samples"):          # gnr_last_error() through TORCH_CHECK
+        render.render_two_stream(pd["xy"], pd["R"], pd["T"], pd["Kinv"], pd["shape_code"], pd["gaze"], pd["appea_code"],
+                                 _to(face, dev), None, n_samples=1000)
