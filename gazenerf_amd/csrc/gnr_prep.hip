@@ -227,8 +227,9 @@ void launch_zvals(const GnrProblem& p, float* out, hipStream_t stream) {
 //     its rank among the u's (random u); a 65-bin histogram of the fine samples' coarse positions + one wave
 //     scan gives every coarse z its place.  The merged row leaves through LDS as coalesced stores.
 // ---------------------------------------------------------------------------------------------
-constexpr int RS_WAVES = 2;          // waves per workgroup (each on its own pass)
-constexpr int RS_ROW_FLOATS = 4096;  // LDS floats per wave for the transposed weight / cdf rows
+constexpr int RS_WAVES = 4;          // waves per workgroup (each on its own pass)
+constexpr int RS_ROW_FLOATS = 2048;  // LDS floats per wave for the weight / cdf rows: 32 rays per pass at N_c = 64,
+                                     // ~10 KB per wave -> 16 waves per CU (64 rays per pass left 8: latency-bound)
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");     // LDS traffic of this wave is in order; make it visible

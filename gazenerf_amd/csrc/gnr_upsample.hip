@@ -53,129 +53,196 @@ struct GemmParams {
     unsigned char* sign_out; long sign_batch;      // shuffle: bit e of byte (b, m/4, n) = (acc + bias > 0) of channel 4(m/4)+e
 };
 
-constexpr int GT = 128, GK = 16;
+constexpr int GK = 16;             // k per LDS tile: two 4-step groups per lane-half
+constexpr int GN = 256;            // pixels per workgroup tile: 2 waves x 128
 
-// At[k][m] = A(m,k) for k < K, m < M, else 0; Kp % 16 == 0, Mp % 128 == 0.  The weights are tiny (<= 2 MB):
-// re-laying them out per call makes every A-tile load an aligned, unconditional float4.
+// At[k/4][m][k%4] = A(m,k) for k < K, m < M, else 0; Kp % 16 == 0, Mp % 128 == 0.  The weights are tiny (<= 2 MB):
+// re-laying them out per call makes the A tile of a k-group ONE contiguous block for the LDS-DMA, and a lane's
+// ds_read_b128 the four k-steps of its row.
 __global__ void pack_a_kernel(const float* __restrict__ A, long a_rs, long a_cs, int M, int K, int Mp, int Kp,
                               float* __restrict__ At) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)Mp * Kp) return;
-    const int k = (int)(i / Mp), m = (int)(i - (long)k * Mp);
+    const int k4 = (int)(i / (4L * Mp)), r = (int)(i - (long)k4 * 4 * Mp), m = r >> 2, k = 4 * k4 + (r & 3);
     At[i] = (m < M && k < K) ? A[(long)m * a_rs + (long)k * a_cs] : 0.0f;
 }
 
+typedef int gi32x4 __attribute__((ext_vector_type(4)));
+
+// C[M][N] tile of (64 XM) x 256 per 256-thread workgroup: 2 (M) x 2 (N) waves, a wave = XM row tiles x 4 pixel
+// "tiles" of v_mfma_f32_32x32x2_f32.  Operand order: the contraction index k is free, so lane-half h takes the
+// 4-step groups 2q + h of a 16-k tile; the A value of 4 consecutive steps is one ds_read_b128 of the packed weights;
+// a lane's B operand of one step is a ds_read_b128 of FOUR CONSECUTIVE PIXELS of row k -- pixel 4 li + t feeds column
+// li of pixel-tile t, so one read feeds four MFMAs and a lane ends up owning 4 consecutive pixels of each of its
+// rows: float4 stores in the epilogue.  10-12 ds_read_b128 per 32 XM MFMAs (was: one ds_read_b32 per MFMA).
+// Both operand tiles arrive by LDS-DMA (the B rows are 1 KiB contiguous, the packed A groups 16 bytes x rows), rows
+// k >= K read zeros through the buffer descriptor's bound: no staging registers, no VALU, no ds_write.
+template <int XM>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams gp) {
-    __shared__ __attribute__((aligned(16))) float As[2][GK][GT], Bs[2][GK][GT];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int TM = 64 * XM;
+    constexpr int A_BYTES = (GK / 4) * TM * 16, B_BYTES = GK * GN * 4, BUF = A_BYTES + B_BYTES;
+    constexpr int PA = A_BYTES / 1024, PB = B_BYTES / 1024;            // 1 KiB DMA pieces per k-tile
+    __shared__ __attribute__((aligned(1024))) char lds[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5, wm = wave >> 1, wn = wave & 1;
-    const int n0 = blockIdx.x * GT, m0 = blockIdx.y * GT, b = blockIdx.z;
-    const float* Bb = gp.B + (long)b * gp.b_batch;
-    // staging: rows bk and bk+8 of both k-major tiles, float4 column bn4
-    const int bk = tid >> 5, bn4 = tid & 31;
-    f32x4 ra[2], rb[2];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int k = k0 + bk + 8 * e;
-            ra[e] = *(const f32x4*)(gp.At + (long)k * gp.Mp + m0 + 4 * bn4);
-            rb[e] = k < gp.K ? *(const f32x4*)(Bb + (long)k * gp.N + n0 + 4 * bn4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            *(f32x4*)&As[buf][bk + 8 * e][4 * bn4] = ra[e];
-            *(f32x4*)&Bs[buf][bk + 8 * e][4 * bn4] = rb[e];
-        }
-    };
-    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    f32x16 acc[2][2] = {{zero, zero}, {zero, zero}};
+    const int n0 = blockIdx.x * GN, m0 = blockIdx.y * TM, b = blockIdx.z;
     const int nk = (gp.K + GK - 1) / GK;
-    gload(0);
-    lstore(0);
+
+    auto desc = [&](const float* base, long bytes) {
+        const unsigned long long a = (unsigned long long)base;
+        if (bytes > 0xFFFFFFFFL) bytes = 0xFFFFFFFFL;
+        gi32x4 r;
+        r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+        r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+        r.z = __builtin_amdgcn_readfirstlane((int)(unsigned)bytes);
+        r.w = 0x00020000;
+        return r;
+    };
+    // A: packed [Kp/4][Mp][4], tile rows m0.. ; B: image b, [K][N] with the bound at row K
+    const gi32x4 rsa = desc(gp.At + (long)m0 * 4, ((long)nk * (GK / 4) * gp.Mp - m0) * 16);
+    const gi32x4 rsb = desc(gp.B + (long)b * gp.b_batch + n0, ((long)gp.K * gp.N - n0) * 4);
+    const unsigned lds0 = (unsigned)(size_t)&lds[0];
+    const unsigned voff = (unsigned)lane * 16u;
+    auto dma_tile = [&](int kt, int buf) {
+        const unsigned la = lds0 + (unsigned)buf * BUF, lb = la + A_BYTES;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
+#pragma unroll
+        for (int j = wave; j < PA; j += 4) {      // piece j: k-group j / (TM/64), 64-row slice j % (TM/64)
+            const unsigned g = (unsigned)j / (TM / 64), sl = (unsigned)j % (TM / 64);
+            const unsigned so = ((unsigned)(kt * (GK / 4) + g) * (unsigned)gp.Mp + sl * 64u) * 16u;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
+                         :: "v"(voff), "s"(rsa), "s"(la + (unsigned)j * 1024u), "s"(so) : "memory");
+        }
+#pragma unroll
+        for (int j = wave; j < PB; j += 4) {      // piece j: row kt*16 + j, 256 pixels
+            const unsigned so = (unsigned)(kt * GK + j) * (unsigned)gp.N * 4u;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
+                         :: "v"(voff), "s"(rsb), "s"(lb + (unsigned)j * 1024u), "s"(so) : "memory");
+        }
+        asm volatile("s_mov_b32 m0, %0" :: "s"(keep));
+    };
+
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 acc[XM][4];
+#pragma unroll
+    for (int x = 0; x < XM; ++x)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[x][t] = zero;
+    // byte offsets inside a buffer: A group g, row r -> (g*TM + r)*16;  B row k, pixel p -> A_BYTES + (k*256 + p)*4
+    const int a_off = (lh * TM + wm * 32 * XM + li) * 16;                  // + (2q*TM + 32x)*16
+    const int b_off = A_BYTES + (4 * lh * GN + wn * 128 + 4 * li) * 4;    // + ((8q + s)*GN)*4
+
+    dma_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * GK);
+        if (kt + 1 < nk) dma_tile(kt + 1, buf ^ 1);
+        const char* base = lds + buf * BUF;
+        f32x4 av[XM][2], bv[2][4];
 #pragma unroll
-        for (int s = 0; s < GK / 2; ++s) {
-            const int k = 2 * s + lh;
-            const float a0 = As[buf][k][64 * wm + li], a1 = As[buf][k][64 * wm + 32 + li];
-            const float b0 = Bs[buf][k][64 * wn + li], b1 = Bs[buf][k][64 * wn + 32 + li];
-            acc[0][0] = mfma32(a0, b0, acc[0][0]);
-            acc[0][1] = mfma32(a0, b1, acc[0][1]);
-            acc[1][0] = mfma32(a1, b0, acc[1][0]);
-            acc[1][1] = mfma32(a1, b1, acc[1][1]);
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int x = 0; x < XM; ++x) av[x][q] = *(const f32x4*)(base + a_off + (2 * q * TM + 32 * x) * 16);
+#pragma unroll
+            for (int sst = 0; sst < 4; ++sst) bv[q][sst] = *(const f32x4*)(base + b_off + (8 * q + sst) * GN * 4);
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int sst = 0; sst < 4; ++sst)
+#pragma unroll
+                for (int x = 0; x < XM; ++x)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[x][t] = mfma32(av[x][q][sst], bv[q][sst][t], acc[x][t]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+
     const int Cq = gp.M / 4;
+    const int n = n0 + 128 * wn + 4 * li;                                   // this lane's 4 consecutive pixels
     if (gp.shuffle) {
-        // PixelShuffleUpsample tail.  A lane's registers 4q..4q+3 are in-channels 4c..4c+3 of one pixel, i.e. the
-        // 2x2 output block of out-channel c: two float2 stores; the four pre-activation signs go into one nibble.
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        // PixelShuffleUpsample tail.  A lane's registers 4q..4q+3 are in-channels 4c..4c+3 of its 4 pixels, i.e. the
+        // 2x2 output blocks of out-channel c at 4 consecutive x: two rows of 8 consecutive floats (float4 stores); the
+        // four pre-activation signs per pixel go into one nibble, four pixels into one 32-bit store.
+        const int py = n / gp.W, px = n - py * gp.W;
 #pragma unroll
-        for (int x = 0; x < 2; ++x)
+        for (int x = 0; x < XM; ++x)
 #pragma unroll
-            for (int y = 0; y < 2; ++y)
+            for (int q = 0; q < 4; ++q) {
+                const int mb = m0 + 32 * XM * wm + 32 * x + 8 * q + 4 * lh;      // multiple of 4
+                if (mb >= gp.M) continue;
+                float v[4][4];                                                   // [e: channel][t: pixel]
+                unsigned nib = 0;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int mb = m0 + 64 * wm + 32 * x + 8 * q + 4 * lh;      // multiple of 4
-                    const int n = n0 + 64 * wn + 32 * y + li;
-                    if (mb >= gp.M) continue;
-                    float v[4];
-                    unsigned nib = 0;
+                for (int e = 0; e < 4; ++e) {
+                    const int m = mb + e;
+                    const float bias = gp.bias[m];
+                    // x.repeat(1,4,1,1): in-channel m reads x channel m % (M/4)
+                    const f32x4 res = *(const f32x4*)(gp.res + (long)b * gp.res_batch + (long)(m % Cq) * gp.N + n);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int m = mb + e;
-                        float t = acc[x][y][4 * q + e] + gp.bias[m];
-                        nib |= (t > 0.0f ? 1u : 0u) << e;
-                        t = t > 0.0f ? t : LEAK * t;
-                        // x.repeat(1,4,1,1): in-channel m reads x channel m % (M/4)
-                        v[e] = t + gp.res[(long)b * gp.res_batch + (long)(m % Cq) * gp.N + n];
+                    for (int t = 0; t < 4; ++t) {
+                        float u = acc[x][t][4 * q + e] + bias;
+                        nib |= (u > 0.0f ? 1u : 0u) << (8 * t + e);
+                        u = u > 0.0f ? u : LEAK * u;
+                        v[e][t] = u + res[t];
                     }
-                    gp.sign_out[(long)b * gp.sign_batch + (long)(mb >> 2) * gp.N + n] = (unsigned char)nib;
-                    // pixel_shuffle(2): in-channel 4c + 2i + j -> out (c, 2y+i, 2x+j)
-                    const int py = n / gp.W, px = n - py * gp.W;
-                    float* dst = gp.C + (long)b * gp.c_batch + (long)(mb >> 2) * (4L * gp.N) + (long)(2 * py) * (2 * gp.W) + 2 * px;
-                    *(f32x2*)dst = f32x2{v[0], v[1]};
-                    *(f32x2*)(dst + 2 * gp.W) = f32x2{v[2], v[3]};
                 }
+                *(unsigned*)(gp.sign_out + (long)b * gp.sign_batch + (long)(mb >> 2) * gp.N + n) = nib;
+                // pixel_shuffle(2): in-channel 4c + 2i + j -> out (c, 2y+i, 2x+j)
+                float* dst = gp.C + (long)b * gp.c_batch + (long)(mb >> 2) * (4L * gp.N) + (long)(2 * py) * (2 * gp.W) + 2 * px;
+                *(f32x4*)dst = f32x4{v[0][0], v[1][0], v[0][1], v[1][1]};
+                *(f32x4*)(dst + 4) = f32x4{v[0][2], v[1][2], v[0][3], v[1][3]};
+                *(f32x4*)(dst + 2 * gp.W) = f32x4{v[2][0], v[3][0], v[2][1], v[3][1]};
+                *(f32x4*)(dst + 2 * gp.W + 4) = f32x4{v[2][2], v[3][2], v[2][3], v[3][3]};
+            }
         return;
     }
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+    for (int x = 0; x < XM; ++x)
 #pragma unroll
-        for (int y = 0; y < 2; ++y)
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + 32 * XM * wm + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m >= gp.M) continue;
+            f32x4 v = {acc[x][0][r], acc[x][1][r], acc[x][2][r], acc[x][3][r]};
+            if (gp.bias) v += gp.bias[m];
+            if (gp.leaky) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + 64 * wm + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int n = n0 + 64 * wn + 32 * y + li;
-                if (m >= gp.M) continue;
-                float v = acc[x][y][r];
-                if (gp.bias) v += gp.bias[m];
-                if (gp.leaky) v = v > 0.0f ? v : LEAK * v;
-                if (gp.mask_ref) v *= gp.mask_ref[(long)b * gp.mask_batch + (long)m * gp.N + n] > 0.0f ? 1.0f : LEAK;
-                float* dst = gp.C + (long)b * gp.c_batch + (long)m * gp.N + n;
-                *dst = gp.accumulate ? *dst + v : v;
+                for (int t = 0; t < 4; ++t) v[t] = v[t] > 0.0f ? v[t] : LEAK * v[t];
             }
+            if (gp.mask_ref) {
+                const f32x4 mk = *(const f32x4*)(gp.mask_ref + (long)b * gp.mask_batch + (long)m * gp.N + n);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] *= mk[t] > 0.0f ? 1.0f : LEAK;
+            }
+            float* dst = gp.C + (long)b * gp.c_batch + (long)m * gp.N + n;
+            if (gp.accumulate) v += *(const f32x4*)dst;
+            *(f32x4*)dst = v;
+        }
 }
 
 static size_t pack_floats(int M, int K) {      // padded size of one packed operand, either orientation
-    auto one = [](int m, int k) { return (size_t)((m + GT - 1) / GT * GT) * ((k + GK - 1) / GK * GK); };
+    auto one = [](int m, int k) { return (size_t)((m + 127) / 128 * 128) * ((k + GK - 1) / GK * GK); };
     const size_t a = one(M, K), b = one(K, M);
     return a > b ? a : b;
 }
 
 static void launch_gemm(GemmParams gp, int batch, float* pack, hipStream_t st) {
-    gp.Mp = (gp.M + GT - 1) / GT * GT;
+    gp.Mp = (gp.M + 127) / 128 * 128;
     const int Kp = (gp.K + GK - 1) / GK * GK;
     hipLaunchKernelGGL(pack_a_kernel, dim3((unsigned)(((long)gp.Mp * Kp + 255) / 256)), dim3(256), 0, st, gp.A, gp.a_rs, gp.a_cs,
                        gp.M, gp.K, gp.Mp, Kp, pack);
     gp.At = pack;
-    hipLaunchKernelGGL(conv_gemm_kernel, dim3(gp.N / GT, gp.Mp / GT, batch), dim3(256), 0, st, gp);
+    // 64-row tiles where they waste fewer padded rows (M = 129, 258, 516: one channel past a multiple of 128); their
+    // MFMA-per-read ratio is lower, hence the 1.1
+    const long w128 = (long)((gp.M + 127) / 128) * 128, w64 = (long)((gp.M + 63) / 64) * 64;
+    if (w64 * 11 < w128 * 10)
+        hipLaunchKernelGGL((conv_gemm_kernel<1>), dim3(gp.N / GN, (gp.M + 63) / 64, batch), dim3(256), 0, st, gp);
+    else
+        hipLaunchKernelGGL((conv_gemm_kernel<2>), dim3(gp.N / GN, (gp.M + 127) / 128, batch), dim3(256), 0, st, gp);
 }
 
 // ---------------------------------------------------------------------------------------------

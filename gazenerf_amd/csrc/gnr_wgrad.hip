@@ -722,35 +722,56 @@ struct WgradReduceParams {
     const float* vec_part; float* vec_out;                                         // out[k]
 };
 
-__global__ void wgrad_reduce_kernel(const WgradReduceParams rp) {
+// dW: thread (e, g) of a 256-thread block adds the splits sp = g, g + G, g + 2G, ... of output element e in that order
+// (G = 4 groups x 64 elements, or 16 x 16 for small outputs with hundreds of splits), then the G partial sums are
+// combined in LDS in a fixed order: deterministic, coalesced (a wave reads 64 or 16 consecutive floats of one
+// partial tile row), and 4-16x the loads in flight of one thread per element.
+template <int G>
+__device__ __forceinline__ void reduce_dw(const WgradReduceParams& rp, float* sm) {
+    constexpr int E = 256 / G;
     const long total = (long)rp.n_valid * rp.k_valid;
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x, gsz = (long)gridDim.x * blockDim.x;
-    if (rp.dW)
-        for (long e = gid; e < total; e += gsz) {
-            const int n = (int)(e / rp.k_valid), k = (int)(e % rp.k_valid);
+    const int tid = threadIdx.x, el = tid % E, g = tid / E;
+    const long tsz = (long)rp.tn_rows * rp.tk_cols;
+    const long sstride = (long)rp.tiles_n * rp.tiles_k * tsz;
+    for (long e0 = (long)blockIdx.x * E; e0 < total; e0 += (long)gridDim.x * E) {
+        const long e = e0 + el;
+        float acc = 0.0f;
+        int n = 0, k = 0;
+        if (e < total) {
+            n = (int)(e / rp.k_valid); k = (int)(e % rp.k_valid);
             const int tn = n / rp.tn_rows, i = n % rp.tn_rows, tk = k / rp.tk_cols, j = k % rp.tk_cols;
-            // fixed summation order (deterministic); 8 loads in flight per thread instead of a
-            // load -> add dependency chain over ~112 splits
-            float acc = 0.0f;
-            const long tsz = (long)rp.tn_rows * rp.tk_cols;
             const float* src = rp.partial + ((long)tn * rp.tiles_k + tk) * tsz + i * rp.tk_cols + j;
-            const long sstride = (long)rp.tiles_n * rp.tiles_k * tsz;
-            int sp = 0;
-            for (; sp + 8 <= rp.splits; sp += 8) {
-                float v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + (sp + u) * sstride);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc += v[u];
+            int sp = g;
+            for (; sp + 3 * G < rp.splits; sp += 4 * G) {
+                const float v0 = __builtin_nontemporal_load(src + sp * sstride);
+                const float v1 = __builtin_nontemporal_load(src + (sp + G) * sstride);
+                const float v2 = __builtin_nontemporal_load(src + (sp + 2 * G) * sstride);
+                const float v3 = __builtin_nontemporal_load(src + (sp + 3 * G) * sstride);
+                acc += v0; acc += v1; acc += v2; acc += v3;
             }
-            for (; sp < rp.splits; ++sp) acc += src[sp * sstride];
-            int col = k;
-            if (rp.enc_map) {
-                col = enc_channel(k >> 1, k & 1);
-                if (col < 0) continue;
-            }
-            rp.dW[(long)n * rp.ldw + rp.col_off + col] = acc;
+            for (; sp < rp.splits; sp += G) acc += __builtin_nontemporal_load(src + sp * sstride);
         }
+        sm[g * E + el] = acc;
+        __syncthreads();
+        if (g == 0 && e < total) {
+            float t = sm[el];
+#pragma unroll
+            for (int gg = 1; gg < G; ++gg) t += sm[gg * E + el];
+            int col = k;
+            if (rp.enc_map) col = enc_channel(k >> 1, k & 1);
+            if (col >= 0) rp.dW[(long)n * rp.ldw + rp.col_off + col] = t;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceParams rp) {
+    __shared__ float sm[256];
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x, gsz = (long)gridDim.x * blockDim.x;
+    if (rp.dW) {
+        if ((long)rp.n_valid * rp.k_valid >= 16384) reduce_dw<4>(rp, sm);
+        else reduce_dw<16>(rp, sm);
+    }
     if (rp.colsum_out)
         for (long e = gid; e < (long)rp.batch * rp.n_valid; e += gsz) {
             const int b = (int)(e / rp.n_valid), n = (int)(e % rp.n_valid);
@@ -869,7 +890,10 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
     rp.colsum_part = cs_part; rp.colsum_out = colsum_out; rp.colsum_ld = colsum_ld; rp.batch = batch; rp.spi = (int)spi;
     rp.vec_part = vec_part; rp.vec_out = vec_out ? vec_out : nullptr;
     const long total = (long)n_valid * k_valid;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, rp);
+    const long per_block = total >= 16384 ? 64 : 16;            // elements per block, see reduce_dw
+    long rblocks = (total + per_block - 1) / per_block;
+    if (rblocks < 8) rblocks = 8;                               // the rider sums below run grid-stride too
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rblocks), dim3(256), 0, stream, rp);
 }
 
 void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, int batch,
