@@ -708,264 +708,6 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const WgradParams wp) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// wgrad3_pipe_kernel: the bf16x3 weight-gradient GEMM as one 512-thread workgroup per CU with SPECIALISED waves.
-//
-// wgrad3_kernel is "limited by everything at once": every workgroup re-splits the fp32 operands it stages (the same
-// element is converted by three workgroups), and its two resident workgroups only partly hide each other's staging.
-// Here each SIMD hosts one MFMA wave and one converter wave (a VALU-only and an MFMA-only wave on one SIMD run
-// concurrently: the pipes are separate):
-//   * waves 4-7 stream the fp32 operand tiles (channel-quad dumps of the bf16x3 chain kernels) straight into
-//     REGISTERS -- a lane owns 64-byte blocks = 4 channels x 4 samples -- THREE chunks ahead (144 KiB in flight per
-//     CU: with one chunk in flight the kernel was latency-bound at 4.8 TB/s of L2 reads, measured), split sample pairs
-//     into bf16 hi / lo (split_pair) and write the planes into LDS as [quad][hi: 8 blocks x (4 ch x 4 samples) | lo]
-//     with the block slot XORed by the quad index: each element is converted ONCE per workgroup tile, and the
-//     bias / density riders come from the fp32 values the lane holds anyway;
-//   * waves 0-3 (2x2, 3 x XK tiles of v_mfma_f32_32x32x16_bf16 each) only ds_read_b64 their operands (a channel's 8
-//     samples of a K-step = two 8-byte pieces, conflict-free by the slot swizzle) and issue the 3-term products; the
-//     second K-step of a chunk is issued after the barrier, so every operand read has 27 MFMAs in front of its use;
-//   * two LDS buffers (96 KiB at 192 x 192), one barrier per chunk.
-// 192 x 192 tiles read each operand twice through L2 instead of three times; HBM traffic (3.2 GB per 384^2 layer at
-// M = 1 M, fp32 dumps) bounds the kernel at ~0.51 ms per layer (6.3 TB/s) against 0.37 ms of matrix-pipe time.
-// ---------------------------------------------------------------------------------------------
-#ifndef GNR_PIPE3_ABL
-#define GNR_PIPE3_ABL 0     // timing experiments (wrong results): 1 no conversion, 2 no operand loads in the loop, 4 no MFMAs, 8 no operand reads
-#endif
-constexpr int P3ABL = GNR_PIPE3_ABL;
-
-template <int XK, bool VEC>
-__global__ __launch_bounds__(512, 1) void wgrad3_pipe_kernel(const WgradParams wp) {
-    constexpr int XN = 3, TN = 64 * XN, TK = 64 * XK;
-    constexpr int QA = TN / 4, QB = TK / 4;                      // channel quads per operand tile
-    constexpr int A_BYTES = QA * 512, BUF_BYTES = (QA + QB) * 512;
-    constexpr int NBLK = (QA + QB) * 8 / 256;                    // 64-byte blocks per converter lane per chunk
-    static_assert(NBLK * 256 == (QA + QB) * 8, "tile must split evenly over the converter lanes");
-    __shared__ __attribute__((aligned(1024))) char lds[2 * BUF_BYTES];
-    const int tiles = wp.tiles_n * wp.tiles_k;
-    const int id = blockIdx.x;
-    const int xcd = id & 7, slot = id >> 3;
-    const int split = xcd + 8 * (slot / tiles);
-    const int tile = slot % tiles;
-    if (split >= wp.batch * wp.spi) return;
-    const int tn = tile / wp.tiles_k, tk = tile - tn * wp.tiles_k;
-#ifdef GNR_WG_CLOCK
-    const unsigned long long clk0 = __builtin_readcyclecounter();
-#endif
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = split / wp.spi, sp = split - b * wp.spi;
-    const long c0 = (long)b * wp.chunks_per_image + (long)sp * wp.chunks_per_split;
-    long c1 = c0 + wp.chunks_per_split;
-    const long cmax = (long)(b + 1) * wp.chunks_per_image;
-    if (c1 > cmax) c1 = cmax;
-    const int nchunks = (int)(c1 - c0);
-
-    if (wave >= 4) {
-        // ------------------------------------------------------------------ converter waves
-        const int ct = tid - 256;                                // 0..255
-        const int pblk = ct & 7;                                  // sample group (4 samples) of this lane's blocks
-        // block it of this lane: quad it*32 + ct/8 of the tile pair (first QA quads: dY, then X), samples 4 pblk..+3.
-        // Source rows past the tensor's channels are clamped (they only feed outputs that are dropped).
-        const float* src[NBLK];
-        long cstride[NBLK];
-#pragma unroll
-        for (int it = 0; it < NBLK; ++it) {
-            const int quad = it * 32 + (ct >> 3);
-            const bool isa = quad < QA;
-            int gq = isa ? tn * QA + quad : tk * QB + (quad - QA);
-            const int ld = isa ? wp.lda : wp.ldb;
-            if (gq >= ld / 4) gq = ld / 4 - 1;
-            src[it] = (isa ? wp.A : wp.B) + c0 * (long)(CHUNK * ld) + (long)gq * 128 + 16 * pblk;
-            cstride[it] = (long)CHUNK * ld;
-        }
-        float cs[NBLK][4], vs[NBLK][4];
-#pragma unroll
-        for (int it = 0; it < NBLK; ++it)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { cs[it][e] = 0.0f; vs[it][e] = 0.0f; }
-        f32x4 R[3][NBLK][4];                                      // three chunks of raw operands in flight
-        f32x4 V[3];
-        auto gload = [&](int k, auto st) {                        // chunk c0 + k (clamped to the split) into stage ST
-            constexpr int ST = decltype(st)::value;
-            const int kk = k < nchunks ? k : (nchunks > 0 ? nchunks - 1 : 0);
-            if (P3ABL & 2) return;
-#pragma unroll
-            for (int it = 0; it < NBLK; ++it)
-#pragma unroll
-                for (int ss = 0; ss < 4; ++ss) R[ST][it][ss] = *(const f32x4*)(src[it] + kk * cstride[it] + 4 * ss);
-            if (VEC) V[ST] = *(const f32x4*)(wp.vec + (c0 + kk) * CHUNK + 4 * pblk);
-        };
-        auto convert = [&](int k, int buf, auto st) {             // stage ST (chunk c0 + k) -> bf16 planes in LDS buffer
-            constexpr int ST = decltype(st)::value;
-            const float live = k < nchunks ? 1.0f : 0.0f;         // riders: the clamped tail chunks must not count
-            if (P3ABL & 1) return;
-#pragma unroll
-            for (int it = 0; it < NBLK; ++it) {
-                const int quad = it * 32 + (ct >> 3);
-                char* q = lds + buf * BUF_BYTES + quad * 512;
-                u32x4 h01, h23, l01, l23;
-                unsigned hh, ll;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float x0 = R[ST][it][0][e], x1 = R[ST][it][1][e], x2 = R[ST][it][2][e], x3 = R[ST][it][3][e];
-                    split_pair(x0, x1, hh, ll);
-                    (e < 2 ? h01 : h23)[2 * (e & 1)] = hh; (e < 2 ? l01 : l23)[2 * (e & 1)] = ll;
-                    split_pair(x2, x3, hh, ll);
-                    (e < 2 ? h01 : h23)[2 * (e & 1) + 1] = hh; (e < 2 ? l01 : l23)[2 * (e & 1) + 1] = ll;
-                    if (quad < QA) cs[it][e] = fmaf(live, (x0 + x1) + (x2 + x3), cs[it][e]);
-                    else if (VEC) vs[it][e] = fmaf(live, fmaf(V[ST].x, x0, V[ST].y * x1) + fmaf(V[ST].z, x2, V[ST].w * x3), vs[it][e]);
-                }
-                const int sl = (pblk ^ (quad & 7)) * 32;
-                *(u32x4*)(q + sl) = h01;
-                *(u32x4*)(q + sl + 16) = h23;
-                *(u32x4*)(q + 256 + sl) = l01;
-                *(u32x4*)(q + 256 + sl + 16) = l23;
-            }
-        };
-        using S0 = std::integral_constant<int, 0>;
-        using S1 = std::integral_constant<int, 1>;
-        using S2 = std::integral_constant<int, 2>;
-        // prologue: chunks 0, 1, 2 requested; chunk 0 converted into buffer 0; chunk 3 requested into the freed stage
-        gload(0, S0{});
-        gload(1, S1{});
-        gload(2, S2{});
-        convert(0, 0, S0{});
-        gload(3, S0{});
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        // period k: the MFMA waves read chunk k from buffer k&1; convert chunk k+1 (stage (k+1)%3) into buffer (k+1)&1,
-        // then refill that stage with chunk k+4
-        auto period = [&](int k, auto st) {
-            convert(k + 1, (k + 1) & 1, st);
-            gload(k + 4, st);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // converted planes written
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        };
-        for (int k = 0; k < nchunks; k += 3) {
-            period(k, S1{});
-            if (k + 1 < nchunks) period(k + 1, S2{});
-            if (k + 2 < nchunks) period(k + 2, S0{});
-        }
-        // riders: the 8 lanes pblk = 0..7 of a quad hold its 8 sample groups
-#pragma unroll
-        for (int it = 0; it < NBLK; ++it) {
-            const int quad = it * 32 + (ct >> 3);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = quad < QA ? cs[it][e] : vs[it][e];
-                t += __shfl_xor(t, 1);
-                t += __shfl_xor(t, 2);
-                t += __shfl_xor(t, 4);
-                if (pblk == 0) {
-                    if (quad < QA) {
-                        if (tk == 0) wp.colsum_part[(long)split * (wp.tiles_n * TN) + tn * TN + 4 * quad + e] = t;
-                    } else if (VEC && tn == 0) {
-                        wp.vec_part[(long)split * (wp.tiles_k * TK) + tk * TK + 4 * (quad - QA) + e] = t;
-                    }
-                }
-            }
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------------- MFMA waves
-    const int wn = wave >> 1, wk = wave & 1;
-    const int li = lane & 31, lh = lane >> 5;
-    // byte offset of (channel row, sample group p) inside an operand tile: quad q = row/4, e = row%4 ->
-    //   q*512 + ((p ^ (q&7)) * 32) + e*8   (+256 for the lo plane).
-    // Every tile of a wave starts at a multiple of 8 quads, so (q&7) = (li/4)&7 for all of them: one address register
-    // per sample group p = 4 s + 2 lh + u (s: K-step, u: piece), tiles and planes are instruction offsets.
-    int aoff[4], boff[4];
-#pragma unroll
-    for (int su = 0; su < 4; ++su) {
-        const int p = 4 * (su >> 1) + 2 * lh + (su & 1);
-        const int sw = ((p ^ ((li >> 2) & 7)) << 5) + (li & 3) * 8;
-        aoff[su] = ((wn * 32 * XN + li) >> 2) * 512 + sw;
-        boff[su] = A_BYTES + ((wk * 32 * XK + li) >> 2) * 512 + sw;
-    }
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    f32x16 acc[XN][XK];
-#pragma unroll
-    for (int x = 0; x < XN; ++x)
-#pragma unroll
-        for (int y = 0; y < XK; ++y)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.0f;
-    // Operand registers: hi planes of the current K-step (ah, bh) and of the next one (nah, nbh), lo planes of the
-    // current one (al, bl): 72 registers beside the 144 accumulators (two complete operand sets would spill).
-    u32x4 ah[XN], bh[XK], nah[XN], nbh[XK], al[XN], bl[XK];
-    auto rd = [&](const char* base, int o0, int o1, int imm) {
-        const u32x2 p0 = *(const u32x2*)(base + o0 + imm);
-        const u32x2 p1 = *(const u32x2*)(base + o1 + imm);
-        return u32x4{p0.x, p0.y, p1.x, p1.y};
-    };
-    auto read_planes = [&](int buf, int sst, int plane, u32x4 (&a)[XN], u32x4 (&bb)[XK]) {
-        if (P3ABL & 8) return;
-        const char* pb = lds + buf * BUF_BYTES;
-#pragma unroll
-        for (int x = 0; x < XN; ++x) a[x] = rd(pb, aoff[2 * sst], aoff[2 * sst + 1], x * 4096 + 256 * plane);
-#pragma unroll
-        for (int y = 0; y < XK; ++y) bb[y] = rd(pb, boff[2 * sst], boff[2 * sst + 1], y * 4096 + 256 * plane);
-    };
-    auto mma = [&](const u32x4 (&a)[XN], const u32x4 (&bb)[XK]) {
-        if (P3ABL & 4) return;
-#pragma unroll
-        for (int x = 0; x < XN; ++x)
-#pragma unroll
-            for (int y = 0; y < XK; ++y) acc[x][y] = mfma_bf(a[x], bb[y], acc[x][y]);
-    };
-    if (P3ABL & 8) {
-#pragma unroll
-        for (int x = 0; x < XN; ++x) ah[x] = nah[x] = al[x] = u32x4{(unsigned)lane, 1u, 2u, 3u};
-#pragma unroll
-        for (int y = 0; y < XK; ++y) bh[y] = nbh[y] = bl[y] = u32x4{(unsigned)lane, 5u, 6u, 7u};
-    }
-    __builtin_amdgcn_s_barrier();            // the converter's prologue barrier: chunk 0 is in buffer 0
-    asm volatile("" ::: "memory");
-    // a*b ~ ah*bh + al*bh + ah*bl per K-step.  Every group of 9 MFMAs has the LDS reads of a LATER group in front of
-    // it, and the barrier that hands chunk k's buffer back to the converter sits in front of the chunk's last group,
-    // which runs from registers while the first reads of chunk k+1 are in flight.
-    read_planes(0, 0, 0, ah, bh);
-    for (int k = 0; k < nchunks; ++k) {
-        const int buf = k & 1;
-        read_planes(buf, 0, 1, al, bl);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(ah, bh);                         // step 0: hi x hi
-        mma(al, bh);                         //         lo x hi
-        __builtin_amdgcn_sched_barrier(0);
-        read_planes(buf, 1, 0, nah, nbh);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(ah, bl);                         //         hi x lo
-        __builtin_amdgcn_sched_barrier(0);
-        read_planes(buf, 1, 1, al, bl);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(nah, nbh);                       // step 1: hi x hi
-        mma(al, nbh);                        //         lo x hi
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every read of chunk k has landed
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        read_planes(buf ^ 1, 0, 0, ah, bh);   // chunk k+1 (zeros / stale past the end: never used)
-        __builtin_amdgcn_sched_barrier(0);
-        mma(nah, bl);                        //         hi x lo
-    }
-#ifdef GNR_WG_CLOCK
-    if (id == 0 && tid == 0) *(unsigned long long*)(wp.vec_part + 1024 * 192 - 2) = __builtin_readcyclecounter() - clk0;
-#endif
-    float* pt = wp.partial + (((long)split * wp.tiles_n + tn) * wp.tiles_k + tk) * (long)(TN * TK);
-#pragma unroll
-    for (int x = 0; x < XN; ++x)
-#pragma unroll
-        for (int y = 0; y < XK; ++y)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = wn * 32 * XN + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int jx = wk * 32 * XK + y * 32 + li;
-                pt[i * TK + jx] = acc[x][y][r];
-            }
-}
-
 struct WgradReduceParams {
     const float* partial;
     int splits, tiles_n, tiles_k;
@@ -1094,12 +836,6 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
         (!with_vec || (n_valid > 192 && k_valid == 384)))        // the density rider needs the 2 x 2 tile grid
         pipe_xk = k_valid == 64 ? 1 : 3;
 #endif
-#ifndef GNR_WG_NOPIPE3
-    // bf16x3: the converter/MFMA-wave kernel on 192-row tiles (channel-quad dumps of the bf16x3 chain kernels)
-    if (bf16x3 && pixels_per_image == 0 && n_valid <= 384 && lda % 8 == 0 && ldb % 8 == 0 &&
-        (k_valid == 64 || k_valid == 192 || k_valid == 384))
-        pipe_xk = k_valid == 64 ? 1 : 3;
-#endif
     const int cfg = (bf16x3 || pipe_xk) ? 0 : choose_tile(n_valid, k_valid, with_vec);
     const int TN = pipe_xk ? 192 : kTileCfgs[cfg].tn, TK = pipe_xk ? 64 * pipe_xk : kTileCfgs[cfg].tk;
     wp.tiles_n = (n_valid + TN - 1) / TN;
@@ -1127,11 +863,7 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
     wp.vec_part = vec_part;
     const int splits = batch * (int)spi;
     const unsigned blocks = (unsigned)(8 * ((splits + 7) / 8) * tiles);
-    if (pipe_xk && bf16x3) {
-        if (pipe_xk == 1) hipLaunchKernelGGL((wgrad3_pipe_kernel<1, false>), dim3(blocks), dim3(512), 0, stream, wp);
-        else if (wp.vec) hipLaunchKernelGGL((wgrad3_pipe_kernel<3, true>), dim3(blocks), dim3(512), 0, stream, wp);
-        else hipLaunchKernelGGL((wgrad3_pipe_kernel<3, false>), dim3(blocks), dim3(512), 0, stream, wp);
-    } else if (pipe_xk) {
+    if (pipe_xk) {
         // CSG = rider slots per wave = 4 / (2 tiles_k)
         if (pipe_xk == 1) hipLaunchKernelGGL((wgrad_pipe_kernel<3, 1, false, 2>), dim3(blocks), dim3(256), 0, stream, wp);
         else if (wp.vec) hipLaunchKernelGGL((wgrad_pipe_kernel<3, 3, true, 1>), dim3(blocks), dim3(256), 0, stream, wp);
@@ -1153,7 +885,7 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
     WgradReduceParams rp{};
     rp.partial = scratch; rp.splits = splits; rp.tiles_n = wp.tiles_n; rp.tiles_k = wp.tiles_k;
     rp.tn_rows = TN; rp.tk_cols = TK;
-    rp.cs_q = (pipe_xk && !bf16x3) ? 2 * wp.tiles_k : 1; rp.vs_q = (pipe_xk && !bf16x3) ? 2 * wp.tiles_n : 1;
+    rp.cs_q = pipe_xk ? 2 * wp.tiles_k : 1; rp.vs_q = pipe_xk ? 2 * wp.tiles_n : 1;
     rp.n_valid = n_valid; rp.k_valid = k_valid; rp.dW = dW; rp.ldw = ldw; rp.col_off = col_off; rp.enc_map = enc_map;
     rp.colsum_part = cs_part; rp.colsum_out = colsum_out; rp.colsum_ld = colsum_ld; rp.batch = batch; rp.spi = (int)spi;
     rp.vec_part = vec_part; rp.vec_out = vec_out ? vec_out : nullptr;
