@@ -12,26 +12,24 @@
 // pass and the ds_read_b128 of the MFMA pass bank-conflict free (MI355X LDS: 64 banks for b128,
 // non-contiguous 16-lane groups).
 //
-// Tiling: a workgroup of WN x WK waves, each wave XN x XK MFMA tiles of 32x32, i.e. a
-// (32 XN WN) x (32 XK WK) workgroup tile.  The layer shapes of the MLP (in 32-channel tiles: 12x12 for
-// the 384^2 layers, 6x12 RGB_layer_1, 9x6 RGB_layer_2, 12x2 for the encoding columns of layers 0 / 5)
-// each get the instantiation that covers them WITHOUT padding:
-//     128 x 128  (2x2 waves of 2x2)   384^2 layers                 -- 64 MFMAs per 16 ds_read_b128
-//     192 x  64  (2x2 waves of 3x1)   RGB_layer_1, encoding columns
-//      96 x  96  (3x1 waves of 1x3)   RGB_layer_2 (258 -> 288 = 3 x 96 rows)
-//      64 x 192  (2x2 waves of 1x3)   wide-K / narrow-N shapes of the upsampler
-// (one 128 x 128 tiling for everything spent 9 % of the weight-gradient MFMAs on padding: 50 % of the
-// tiles of RGB_layer_2 and of the encoding columns, 25 % of RGB_layer_1.)
-// Chunks are double-buffered through LDS (next chunk's global loads are in flight during the current
-// chunk's MFMAs), two workgroups per CU.  The sample range is split (per image) over workgroups; the
-// tiles of one split are placed on one XCD back-to-back so the operand rows they share hit that XCD's
-// L2.  Per-split partial tiles are summed in a fixed order by wgrad_reduce_kernel (deterministic; the
-// reference trains with cudnn.deterministic, train.py:57).
+// Two kernels share that operand scheme:
+//   wgrad_pipe_kernel  chunk-channel-major operands (the whole MLP): ONE software-pipelined workgroup per CU,
+//                      192-row tiles, LDS-DMA ring, operand prefetch -- see its header below;
+//   wgrad_kernel       everything else (the upsampler's channels-first images): WN x WK waves of XN x XK MFMA tiles,
+//                      i.e. a (32 XN WN) x (32 XK WK) workgroup tile chosen per shape by padded work
+//                          128 x 128  (2x2 waves of 2x2)      192 x 64 / 64 x 192  (2x2 waves of 3x1 / 1x3)
+//                           96 x  96  (3x1 waves of 1x3)
+//                      (one 128 x 128 tiling for everything spent 9 % of the MLP's weight-gradient MFMAs on padding),
+//                      chunks double-buffered through LDS (the next chunk's global loads are in flight during the
+//                      current chunk's MFMAs), two workgroups per CU.
+// The sample range is split (per image) over workgroups; the tiles of one split are placed on one XCD back-to-back so
+// the operand rows they share hit that XCD's L2.  Per-split partial tiles are summed in a fixed order by
+// wgrad_reduce_kernel (deterministic; the reference trains with cudnn.deterministic, train.py:57).
 //
-// Riding along, computed from the staging registers (outside the MFMA stream: every VALU instruction
-// between two fp32 MFMAs costs ~15-25 matrix-pipe cycles), only in the workgroups that own them:
-//   * column sums of dY (bias gradients, per image)            -- workgroups with tile-k == 0
-//   * vec^T X for a per-sample vector (density-head gradient)  -- workgroups with tile-n == 0
+// Riding along: column sums of dY (bias gradients, per image) and vec^T X for a per-sample vector (density-head
+// gradient).  wgrad_kernel takes them from the operand registers between the MFMAs, in every workgroup (GNR_WG_RIDERS
+// below: with two workgroups per CU that is free, and a single round of workgroups ends with its slowest member);
+// wgrad_pipe_kernel shares them between the waves that hold the same rows.
 #include <type_traits>
 
 #include "gnr_chain3.h"
