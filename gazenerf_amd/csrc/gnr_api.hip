@@ -102,9 +102,9 @@ size_t carve_fwd(const GnrProblem* p, int n_streams, bool save, char* base, FwdP
         if (fp) fp->ws[s] = w;
     }
     float* zval = take(M);
-    float* enc = nullptr; float* delta = nullptr; float* pts = nullptr;
-    if (save) { enc = take(M * ENC_PAD); delta = take(M); pts = take(M * 4); }
-    if (fp) { fp->zval = zval; fp->enc = enc; fp->delta = delta; fp->pts = pts; }
+    float* enc = nullptr; float* enc3 = nullptr; float* delta = nullptr; float* pts = nullptr;
+    if (save) { enc = take(M * ENC_PAD); enc3 = take(M * ENC_PAD); delta = take(M); pts = take(M * 4); }
+    if (fp) { fp->zval = zval; fp->enc = enc; fp->enc3 = enc3; fp->delta = delta; fp->pts = pts; }
     return off;
 }
 

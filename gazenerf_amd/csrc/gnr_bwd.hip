@@ -590,15 +590,15 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
                 launch_wgrad(dyh(5), H, H, hptr(4), H, H, p->batch, cpi, DW.fea_w[5], vp + H, vp, 0, dbl(5), H,
                              nullptr, nullptr, sc.wg_part, st, bf16x3);
                 if (DW.fea_w[5])
-                    launch_wgrad(dyh(5), H, H, fp.enc, ENC_PAD, ENC_PAD, p->batch, cpi, DW.fea_w[5], vp + H, 0, 1,
-                                 nullptr, 0, nullptr, nullptr, sc.wg_part, st, bf16x3);
+                    launch_wgrad(dyh(5), H, H, bf16x3 ? fp.enc3 : fp.enc, ENC_PAD, ENC_PAD, p->batch, cpi, DW.fea_w[5], vp + H, 0,
+                                 bf16x3 ? 2 : 1, nullptr, 0, nullptr, nullptr, sc.wg_part, st, bf16x3);
             } else {
                 launch_wgrad(dyh(l), H, H, hptr(l - 1), H, H, p->batch, cpi, DW.fea_w[l], H, 0, 0, dbl(l), H,
                              nullptr, nullptr, sc.wg_part, st, bf16x3);
             }
         }
-        launch_wgrad(dyh(0), H, H, fp.enc, ENC_PAD, ENC_PAD, p->batch, cpi, DW.fea_w[0], vp, 0, 1, dbl(0), H,
-                     nullptr, nullptr, sc.wg_part, st, bf16x3);
+        launch_wgrad(dyh(0), H, H, bf16x3 ? fp.enc3 : fp.enc, ENC_PAD, ENC_PAD, p->batch, cpi, DW.fea_w[0], vp, 0, bf16x3 ? 2 : 1,
+                     dbl(0), H, nullptr, nullptr, sc.wg_part, st, bf16x3);
         if (s == 0) stage_mark(GNR_STAGE_WGRAD, 1, st);
         launch_vecsum(sc.dsig_ray, p->batch, p->n_rays, dbl(N_CHAIN), H, st);
 

@@ -100,20 +100,20 @@ __global__ __launch_bounds__(256, 1) void bwd3_chain_kernel(const BwdParams bp) 
     // the in-order vmcnt queue behind fresh LDS-DMA pieces
     unsigned mk[RELU_WORDS], mkn[RELU_WORDS];
     auto bits = [&](int layer) { return bp.relu_bits + relu_bits_offset(layer, bp.n_chunks, chunk); };
-    auto dyh = [&](int l) { return quad_ptr(bp.dY_h + l * M * H, H, chunk, j, h); };
+    auto dyh = [&](int l) { return qdump(bp.dY_h + l * M * H, H, chunk, j, h); };
     auto keep = [](unsigned word, int t, int rr, float v) {
         // bit 16 (t&1) + rr of the word -> all-ones / zero mask (v_bfe_i32 + v_and)
         const int m = __builtin_amdgcn_sbfe((int)word, 16 * (t & 1) + rr, 1);
         return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & m);
     };
-    // transform of a layer input: [mask with the sign bits in mk] + dump (channel-quad layout)
+    // transform of a layer input: [mask with the sign bits in mk]; the dump of the (masked) input is the QDump argument
+    // of mm3_h (QHL layout, gnr_chain3.h)
 #define GNR_XF(MASK, DP)                                                                          \
-    [&, dp = (DP)](int t, int rr, f32x4& v) {                                                     \
+    [&](int t, int rr, f32x4& v) {                                                                \
         if (MASK) {                                                                               \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = keep(mk[t >> 1], t, rr + e, v[e]); \
         }                                                                                         \
-        dump_store((f32x4*)(dp + quad_off(t, rr)), v);                                            \
-    }
+    }, (DP)
     auto promote = [&]() {
 #pragma unroll
         for (int q = 0; q < RELU_WORDS; ++q) mk[q] = mkn[q];
@@ -121,25 +121,23 @@ __global__ __launch_bounds__(256, 1) void bwd3_chain_kernel(const BwdParams bp) 
 
     load_relu_bits<NT_H2>(mkn, bits(8), lane);
     // RGB2^T: A(9) -> Bv(6)                          (dumps dfeat)
-    mm3_h<NT_F, NT_H2, INIT_ZERO, false, 1>(A, Bv, nullptr, h, w, GNR_XF(false, quad_ptr(bp.dfeat, FEAT_PAD, chunk, j, h)));
+    mm3_h<NT_F, NT_H2, INIT_ZERO, false, 1>(A, Bv, nullptr, h, w, GNR_XF(false, qdump(bp.dfeat, FEAT_PAD, chunk, j, h)));
     promote();
     load_relu_bits<NT_H>(mkn, bits(7), lane);
     // RGB1^T: Bv(6) -> A(12), input masked by y1 > 0  (dumps dY_r1)
-    mm3_h<NT_H2, NT_H, INIT_ZERO, false, 1>(Bv, A, nullptr, h, w, GNR_XF(true, quad_ptr(bp.dY_r1, H2, chunk, j, h)));
+    mm3_h<NT_H2, NT_H, INIT_ZERO, false, 1>(Bv, A, nullptr, h, w, GNR_XF(true, qdump(bp.dY_r1, H2, chunk, j, h)));
     // RGB0^T: A -> Bv, no activation on y0           (dumps dY_r0)
-    mm3_h<NT_H, NT_H, INIT_ZERO, false, 1>(A, Bv, nullptr, h, w, GNR_XF(false, quad_ptr(bp.dY_r0, H, chunk, j, h)));
+    mm3_h<NT_H, NT_H, INIT_ZERO, false, 1>(A, Bv, nullptr, h, w, GNR_XF(false, qdump(bp.dY_r0, H, chunk, j, h)));
     promote();
     load_relu_bits<NT_H>(mkn, bits(6), lane);
     // L7^T: Bv -> A; input = (d h7 + density head) masked by h7 > 0   (dumps dY_7)
     {
         const float* wsg = wsig_lds + 4 * h;
-        float* dp = dyh(7);
-        mm3_h<NT_H, NT_H, INIT_ZERO, false, 1>(Bv, A, nullptr, h, w, [&, dp](int t, int rr, f32x4& v) {
+        mm3_h<NT_H, NT_H, INIT_ZERO, false, 1>(Bv, A, nullptr, h, w, [&](int t, int rr, f32x4& v) {
             const f32x4 w4 = *(const f32x4*)(wsg + 32 * t + 8 * (rr >> 2));
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = keep(mk[t >> 1], t, rr + e, fmaf(w4[e], ds, v[e]));
-            dump_store((f32x4*)(dp + quad_off(t, rr)), v);
-        });
+        }, dyh(7));
     }
     promote();
     load_relu_bits<NT_H>(mkn, bits(5), lane);

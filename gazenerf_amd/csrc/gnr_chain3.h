@@ -224,25 +224,40 @@ struct XfRelu {
     }
 };
 
-// Training dumps use the "channel-quad" layout: element (chunk c, channel n, sample j) of a C-channel
-// tensor at c*32*C + (n>>2)*128 + 4j + (n&3) floats, so that the quad a lane holds is ONE 16-byte store
-// and a wave's store covers 1 KiB contiguous.  (The vector-memory path accepts roughly one wave
-// instruction per ~20 cycles per CU whatever its width: dword stores of the same data -- the
-// chunk-channel-major layout of the fp32 kernels -- cost 4x the instructions and, measured, +40 % on
-// the training forward.)  quad_ptr: this lane's base; quad (t, r) lives at + (8t + (r>>2)*2) * 128.
-__device__ __forceinline__ float* quad_ptr(float* dst, int C, long chunk, int j, int h) {
-    return dst + chunk * (CHUNK * (long)C) + h * 128 + 4 * j;
+// Training dumps use the "QHL" layout: one 16-byte element {hi01, hi23, lo01, lo23} -- the bf16 (hi, lo) split of
+// the four consecutive channels a lane holds, exactly the words the next layer's MFMA operand is built from -- per
+// (chunk c, channel quad q, sample j) of a C-channel tensor, at byte c*32*C*4 + q*512 + (j ^ 4(q&3))*16, the two 8-byte
+// halves swapped in quads with bit 2 set.  A lane's quad is ONE 16-byte store and a wave's store covers 1 KiB.  (The
+// vector-memory path accepts roughly one wave instruction per ~20 cycles per CU whatever its width: dword stores of
+// the same data -- the chunk-channel-major layout of the fp32 kernels -- cost 4x the instructions and, measured, +40 %
+// on the training forward.)  The weight-gradient kernel reads this layout with transposing LDS reads and never
+// converts anything (wgrad3_tr_kernel, gnr_wgrad.hip: the slot XOR and the half swap are its bank-conflict scheme).
+// Round 1 dumped the fp32 quad and let the GEMM re-split every element in each of its three workgroup columns.
+struct QDump {
+    char* base;          // tensor + chunk*32*C*4 (wave-uniform: stays in SGPRs), or nullptr: no dump
+    unsigned s0, s1;     // this lane's byte offset inside quad q = 8t + 2(r>>2) + h for (r>>2) even / odd:
+                         // h*512 + (j ^ 4(q&3))*16 with q&3 = 2((r>>2)&1) + h
+};
+__device__ __forceinline__ QDump qdump(float* dst, int C, long chunk, int j, int h) {
+    QDump q;
+    q.base = dst ? (char*)(dst + chunk * (CHUNK * (long)C)) : nullptr;
+    q.s0 = h * 512 + (j ^ (4 * h)) * 16;
+    q.s1 = h * 512 + (j ^ (8 + 4 * h)) * 16;
+    return q;
 }
-__device__ __forceinline__ int quad_off(int t, int r) { return (8 * t + 2 * (r >> 2)) * 128; }
 
 template <bool WRITEBACK, class Xf>
-__device__ __forceinline__ void convert_quad(f32x16& src, int r, BTile& dst, int t, Xf& xf) {
+__device__ __forceinline__ void convert_quad(f32x16& src, int r, BTile& dst, int t, Xf& xf, const QDump& qd) {
     f32x4 v = {src[r], src[r + 1], src[r + 2], src[r + 3]};
     xf(t, r, v);
     if (WRITEBACK) { src[r] = v.x; src[r + 1] = v.y; src[r + 2] = v.z; src[r + 3] = v.w; }
     unsigned h0, l0, h1, l1;
     split_pair(v.x, v.y, h0, l0);
     split_pair(v.z, v.w, h1, l1);
+    if (qd.base && !(ABL & 32)) {       // the training dump: the split itself (quads with bit 2 set: halves swapped)
+        u32x4* p = (u32x4*)(qd.base + (8 * t + 2 * (r >> 2)) * 512 + (((r >> 2) & 1) ? qd.s1 : qd.s0));
+        dump_store(p, (r >> 3) ? u32x4{l0, l1, h0, h1} : u32x4{h0, h1, l0, l1});
+    }
     const int u = r >> 3, w = (r & 7) >> 1;
     dst.h[u][w] = h0; dst.h[u][w + 1] = h1;
     dst.l[u][w] = l0; dst.l[u][w + 1] = l1;
@@ -264,10 +279,10 @@ __device__ __forceinline__ void bias_init(f32x16& acc, const float* bias, int nt
 // reading the same input then uses XfNone).
 enum { INIT_NONE = 0, INIT_BIAS = 1, INIT_ZERO = 2 };
 
-// DUMPS = global stores xf issues per call (0, or 1 when it dumps its quad).
+// DUMPS = global stores a conversion issues (0, or 1 when qd dumps the quad: the vmcnt bookkeeping needs the count).
 template <int NT_IN, int NT_OUT, int INIT, bool WRITEBACK, int DUMPS, class Xf>
 __device__ __forceinline__ void mm3_h(f32x16 (&prev)[NT_H], f32x16 (&acc)[NT_H], const float* out_bias, int h, WRing& w,
-                                      Xf xf) {
+                                      Xf xf, const QDump qd = QDump{nullptr, 0, 0}) {
     constexpr int PPT = NT_OUT;                 // row pairs per input tile (2 K-steps x NT_OUT rows / 2)
     constexpr int NP = NT_IN * PPT;
     // conversions (xf calls) issued inside pair P: the next tile's 4 register quads spread over 2 PPT slots
@@ -280,7 +295,7 @@ __device__ __forceinline__ void mm3_h(f32x16 (&prev)[NT_H], f32x16 (&acc)[NT_H],
     BTile cur, nxt;
     if (INIT == INIT_BIAS) { bias_init(acc[0], out_bias, 0, h); bias_init(acc[1 % NT_OUT], out_bias, 1 % NT_OUT, h); }
 #pragma unroll
-    for (int r = 0; r < 16; r += 4) convert_quad<WRITEBACK>(prev[0], r, cur, 0, xf);
+    for (int r = 0; r < 16; r += 4) convert_quad<WRITEBACK>(prev[0], r, cur, 0, xf, qd);
     ring_layer<NP>(w, [&](int P, const u32x4 (&g)[2][2]) {
         const int t = P / PPT, pt = P % PPT;
         const int i0 = 2 * pt, i1 = i0 + 1;
@@ -297,8 +312,8 @@ __device__ __forceinline__ void mm3_h(f32x16 (&prev)[NT_H], f32x16 (&acc)[NT_H],
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < NT_IN && !(ABL & 4)) {
 #pragma unroll
-            for (int qd = ((2 * pt) * 4) / (2 * PPT); qd < ((2 * pt + 1) * 4) / (2 * PPT); ++qd)
-                convert_quad<WRITEBACK>(prev[t + 1], 4 * qd, nxt, t + 1, xf);
+            for (int qq = ((2 * pt) * 4) / (2 * PPT); qq < ((2 * pt + 1) * 4) / (2 * PPT); ++qq)
+                convert_quad<WRITEBACK>(prev[t + 1], 4 * qq, nxt, t + 1, xf, qd);
         }
         __builtin_amdgcn_sched_barrier(0);
         acc[n0] = mfma_bf(g[0][1], cur.h[u0], acc[n0]);
@@ -306,8 +321,8 @@ __device__ __forceinline__ void mm3_h(f32x16 (&prev)[NT_H], f32x16 (&acc)[NT_H],
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < NT_IN && !(ABL & 4)) {
 #pragma unroll
-            for (int qd = ((2 * pt + 1) * 4) / (2 * PPT); qd < ((2 * pt + 2) * 4) / (2 * PPT); ++qd)
-                convert_quad<WRITEBACK>(prev[t + 1], 4 * qd, nxt, t + 1, xf);
+            for (int qq = ((2 * pt + 1) * 4) / (2 * PPT); qq < ((2 * pt + 2) * 4) / (2 * PPT); ++qq)
+                convert_quad<WRITEBACK>(prev[t + 1], 4 * qq, nxt, t + 1, xf, qd);
         }
         __builtin_amdgcn_sched_barrier(0);
         acc[n0] = mfma_bf(g[0][0], cur.l[u0], acc[n0]);

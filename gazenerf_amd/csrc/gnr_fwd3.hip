@@ -120,22 +120,42 @@ __global__ __launch_bounds__(256, 1) void fwd3_kernel(const FwdParams fp) {
     {
         float e[ENC_STEPS];
         encode_point(px, py, pz, h, e);
+        // Lane (j, h) holds the slots 2 s + h; quad q = s>>1 of the dumps is {slot(2q, 0), slot(2q, 1), slot(2q+1, 0),
+        // slot(2q+1, 1)}: half of it sits in the other lane half.  v_permlane32_swap_b32 (semantics pinned by
+        // tools/ubench/permlane_probe.hip: lanes < 32 receive (x of lane, x of lane + 32), lanes >= 32 receive (y of
+        // lane - 32, y of lane)) completes quad q in the lower half and quad q + 1 in the upper half: every dump is one
+        // 16-byte store per lane (dword stores of the same data: 4x the instructions, +5 % on the training forward).
+        auto swp = [](unsigned x, unsigned y, unsigned& a, unsigned& b) {
+            auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+            a = r[0]; b = r[1];
+        };
+        const QDump qe = qdump(SAVE ? fp.enc3 : nullptr, ENC_PAD, chunk, j, h);
+        float* ef = fp.enc + chunk * (CHUNK * ENC_PAD) + h * 128 + 4 * j;
 #pragma unroll
-        for (int T = 0; T < 2; ++T)
+        for (int q = 0; q < 16; q += 2) {
+            unsigned hi[2], lo[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int wd = 0; wd < 4; ++wd) {
-                    unsigned hi, lo;
-                    split_pair(e[16 * T + 8 * u + 2 * wd], e[16 * T + 8 * u + 2 * wd + 1], hi, lo);
-                    enc_col[(T * 16 + u * 4 + wd) * 256] = hi;
-                    enc_col[(T * 16 + 8 + u * 4 + wd) * 256] = lo;
-                }
+            for (int o = 0; o < 2; ++o) {
+                const int T = (q + o) >> 3, u = ((q + o) >> 2) & 1, wd = (q + o) & 3;
+                split_pair(e[2 * (q + o)], e[2 * (q + o) + 1], hi[o], lo[o]);
+                enc_col[(T * 16 + u * 4 + wd) * 256] = hi[o];
+                enc_col[(T * 16 + 8 + u * 4 + wd) * 256] = lo[o];
+            }
+            if (SAVE) {
+                // the weight-gradient operand of the encoding columns, QHL layout (gnr_chain3.h) with the "channel"
+                // order k' = 4 (s>>1) + 2 h + (s&1) of the slots 2 s + h (wgrad_reduce_kernel maps it back)
+                unsigned a0, a1, b0, b1;
+                swp(hi[0], hi[1], a0, a1);
+                swp(lo[0], lo[1], b0, b1);
+                dump_store((u32x4*)(qe.base + q * 512 + (((q >> 1) & 1) ? qe.s1 : qe.s0)),
+                           ((q >> 2) & 1) ? u32x4{b0, b1, a0, a1} : u32x4{a0, a1, b0, b1});
+                // fp32 copy for the Embedder backward: channel-quad layout, channel = encoding slot 2 s + h
+                swp(__builtin_bit_cast(unsigned, e[2 * q]), __builtin_bit_cast(unsigned, e[2 * q + 2]), a0, a1);
+                swp(__builtin_bit_cast(unsigned, e[2 * q + 1]), __builtin_bit_cast(unsigned, e[2 * q + 3]), b0, b1);
+                dump_store((u32x4*)(ef + q * 128), u32x4{a0, a1, b0, b1});
+            }
+        }
         if (SAVE) {
-            // channel-quad layout, channel = encoding slot 2 s + h
-#pragma unroll
-            for (int s = 0; s < ENC_STEPS; ++s)
-                dump_store(fp.enc + chunk * (CHUNK * ENC_PAD) + ((2 * s + h) >> 2) * 128 + 4 * j + ((2 * s + h) & 3), e[s]);
             if (h == 0) {
                 fp.delta[row] = delta;
                 fp.zval[row] = z0;
@@ -164,8 +184,8 @@ __global__ __launch_bounds__(256, 1) void fwd3_kernel(const FwdParams fp) {
         auto bl = [&](int l) { return bias_lds + l * H; };
         // training forward: the transform of a layer input = activation + sign bits + dump of that input
         unsigned word = 0;
-        auto xf_relu = [&](float* dst, int C, unsigned* bits) {
-            float* qp = SAVE ? quad_ptr(dst, C, chunk, j, h) : nullptr;
+        auto qd = [&](float* dst, int C) { return SAVE ? qdump(dst, C, chunk, j, h) : QDump{nullptr, 0, 0}; };
+        auto xf_relu = [&](unsigned* bits) {
             return [=, &word](int t, int rr, f32x4& v) {
                 if (SAVE) {
 #pragma unroll
@@ -176,16 +196,9 @@ __global__ __launch_bounds__(256, 1) void fwd3_kernel(const FwdParams fp) {
                     }
                     // 32 sign bits (tiles 2q, 2q+1) complete: first inserted = register 0 of the even tile
                     if ((t & 1) && rr == 12) dump_store(bits + (t >> 1) * 64 + lane, __builtin_bitreverse32(word));
-                    if (!(ABL & 32) && !((ABL & 128) && (t & 1))) dump_store((f32x4*)(qp + quad_off(t, rr)), v);
                 } else {
                     XfRelu()(t, rr, v);
                 }
-            };
-        };
-        auto xf_lin = [&](float* dst, int C) {
-            float* qp = SAVE ? quad_ptr(dst, C, chunk, j, h) : nullptr;
-            return [=](int t, int rr, f32x4& v) {
-                if (SAVE && !(ABL & 32)) dump_store((f32x4*)(qp + quad_off(t, rr)), v);
             };
         };
         auto sb = [&](int layer) { return SAVE ? ws.relu_bits + relu_bits_offset(layer, fp.n_chunks, chunk) : nullptr; };
@@ -195,18 +208,18 @@ __global__ __launch_bounds__(256, 1) void fwd3_kernel(const FwdParams fp) {
 #pragma unroll 1
         for (int rep = 0; rep < 2; ++rep) {                                    // L1..L4
             const int la = 2 * rep + 1, lb = la + 1;
-            mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 1 : 0>(A, Bv, bl(la), h, w, xf_relu(ah(la - 1), H, sb(la - 1)));
-            mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 1 : 0>(Bv, A, bl(lb), h, w, xf_relu(ah(lb - 1), H, sb(lb - 1)));
+            mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 1 : 0>(A, Bv, bl(la), h, w, xf_relu(sb(la - 1)), qd(ah(la - 1), H));
+            mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 1 : 0>(Bv, A, bl(lb), h, w, xf_relu(sb(lb - 1)), qd(ah(lb - 1), H));
         }
         mm3_enc<NT_H>(enc_col, Bv, bl(5), h, w);                               // L5: encoding part, then h4 part
-        mm3_h<NT_H, NT_H, INIT_NONE, false, SAVE ? 1 : 0>(A, Bv, bl(5), h, w, xf_relu(ah(4), H, sb(4)));
-        mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 1 : 0>(Bv, A, bl(6), h, w, xf_relu(ah(5), H, sb(5)));      // L6
-        mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 1 : 0>(A, Bv, bl(7), h, w, xf_relu(ah(6), H, sb(6)));      // L7
+        mm3_h<NT_H, NT_H, INIT_NONE, false, SAVE ? 1 : 0>(A, Bv, bl(5), h, w, xf_relu(sb(4)), qd(ah(4), H));
+        mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 1 : 0>(Bv, A, bl(6), h, w, xf_relu(sb(5)), qd(ah(5), H));      // L6
+        mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 1 : 0>(A, Bv, bl(7), h, w, xf_relu(sb(6)), qd(ah(6), H));      // L7
         // RGB0 consumes h7 = relu(Bv); the density head rides on the conversion (fp32 VALU dot)
         float sig = 0.0f;
         {
             const float* wsg = bias_lds + N_CHAIN * H + 4 * h;
-            auto base = xf_relu(ah(7), H, sb(7));
+            auto base = xf_relu(sb(7));
             mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 1 : 0>(Bv, A, bl(LR0), h, w, [&, base](int t, int rr, f32x4& v) {
                 base(t, rr, v);
                 const f32x4 w4 = *(const f32x4*)(wsg + 32 * t + 8 * (rr >> 2));
@@ -214,13 +227,13 @@ __global__ __launch_bounds__(256, 1) void fwd3_kernel(const FwdParams fp) {
                 sig = fmaf(w4.y, v.y, sig);
                 sig = fmaf(w4.z, v.z, sig);
                 sig = fmaf(w4.w, v.w, sig);
-            });
+            }, qd(ah(7), H));
         }
         sig += __shfl_xor(sig, 32);
         sig += ws.wsig[H];
         if (SAVE && h == 0) ws.sigma_raw[row] = sig;
-        mm3_h<NT_H, NT_H2, INIT_BIAS, false, SAVE ? 1 : 0>(A, Bv, bl(LR1), h, w, xf_lin(SAVE ? ws.act_y0 : nullptr, H));
-        mm3_h<NT_H2, NT_F, INIT_BIAS, false, SAVE ? 1 : 0>(Bv, A, bl(LR2), h, w, xf_relu(SAVE ? ws.act_y1 : nullptr, H2, sb(8)));
+        mm3_h<NT_H, NT_H2, INIT_BIAS, false, SAVE ? 1 : 0>(A, Bv, bl(LR1), h, w, XfNone(), qd(ws.act_y0, H));
+        mm3_h<NT_H2, NT_F, INIT_BIAS, false, SAVE ? 1 : 0>(Bv, A, bl(LR2), h, w, xf_relu(sb(8)), qd(ws.act_y1, H2));
         if (SAVE) dump<NT_F>(A, ws.act_feat, FEAT_PAD, chunk, j, h);
         composite_chunk(A, sig, delta, z0, ws, chunk, row, lane, SAVE || fp.want_wl != 0);
     }

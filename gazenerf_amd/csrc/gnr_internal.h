@@ -94,6 +94,8 @@ struct FwdParams {
     StreamWs ws[2];
     // shared per-sample geometry saved for backward / weights output
     float* enc;           // [M][ENC_PAD]  (our k-order)   (training only)
+    float* enc3;          // [M][ENC_PAD]  the same as bf16 (hi, lo) quads in the QHL layout: the weight-gradient operand
+                          //               of the bf16x3 path (gnr_chain3.h); the fp32 copy feeds the Embedder backward
     float* delta;         // [M]
     float* zval;          // [M]
     float* pts;           // [M][4]        (training only)

@@ -3,6 +3,7 @@
 // experiment switches (-DGNR_WG_...) can be compared side by side:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-D...] tools/ubench/wgrad_bench.hip -o wgrad_bench && ./wgrad_bench
 #include <cmath>
+#include <cstring>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -41,10 +42,41 @@ int main(int argc, char** argv) {
             if (!dense && v < 0.0f) v = 0.0f;
         }
     };
-    fill();
+    // bf16x3 (argv[1] = 3): the operands are the chain kernels' pre-split dumps -- element (chunk, channel quad q,
+    // sample j) = 16 bytes {hi01, hi23, lo01, lo23} at chunk*32*C*4 + q*512 + (j ^ 4(q&3))*16 ("QHL")
+    auto bf = [](float v) { unsigned u; memcpy(&u, &v, 4); u += 0x7fffu + ((u >> 16) & 1u); return u >> 16; };       // RN
+    auto bff = [](unsigned b) { unsigned u = b << 16; float f; memcpy(&f, &u, 4); return f; };
+    auto fill_qhl = [&]() {
+        unsigned* w = (unsigned*)h.data();
+        for (long e = 0; e < M * 384 / 4; ++e) {         // e = (chunk*96 + q)*32 + j for C = 384; other C reuse the bytes
+            float v[4]; unsigned hi[4], lo[4];
+            for (int i = 0; i < 4; ++i) {
+                s = s * 1664525u + 1013904223u;
+                v[i] = ((s >> 8) & 0xffff) / 65536.0f - 0.5f;
+                if (!dense && v[i] < 0.0f) v[i] = 0.0f;
+                hi[i] = bf(v[i]); lo[i] = bf(v[i] - bff(hi[i]));
+            }
+            const int sw = (int)((e >> 5) >> 2) & 1 ? 2 : 0;       // quads with bit 2 set: {lo, hi}  (96 quads per chunk: (e>>5) % 96 has the same bit 2)
+            w[4 * e + (0 ^ sw)] = hi[0] | (hi[1] << 16); w[4 * e + (1 ^ sw)] = hi[2] | (hi[3] << 16);
+            w[4 * e + (2 ^ sw)] = lo[0] | (lo[1] << 16); w[4 * e + (3 ^ sw)] = lo[2] | (lo[3] << 16);
+        }
+    };
+    std::vector<float> hA, hB;
+    if (x3) fill_qhl(); else fill();
     CK(hipMemcpy(A, h.data(), M * 384 * 4, hipMemcpyHostToDevice));
-    fill();
+    if (x3) hA = h;
+    if (x3) fill_qhl(); else fill();
     CK(hipMemcpy(B, h.data(), M * 384 * 4, hipMemcpyHostToDevice));
+    if (x3) hB = h;
+    // decoded value (hi + lo) of (sample s, channel n) of a C-channel QHL tensor
+    auto qhl = [&](const std::vector<float>& t, int C, long sidx, int n) {
+        const long chunk = sidx >> 5; const int j = (int)(sidx & 31), q = n >> 2, e = n & 3;
+        const unsigned* w = (const unsigned*)t.data() + (chunk * 32L * C) + q * 128 + ((j ^ (4 * (q & 3))) * 4);
+        const int sw = (q >> 2) & 1 ? 2 : 0;
+        const unsigned hw = w[(e >> 1) ^ sw], lw = w[(2 + (e >> 1)) ^ sw];
+        const unsigned hb = (e & 1) ? hw >> 16 : hw & 0xffff, lb = (e & 1) ? lw >> 16 : lw & 0xffff;
+        return (double)bff(hb) + (double)bff(lb);
+    };
     CK(hipMemcpy(vec, h.data(), M * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -81,6 +113,27 @@ int main(int argc, char** argv) {
         if (sh.vec) for (int k = 0; k < sh.k_valid; ++k) sv += fabs(hv[k]) + 1e-3 * k * hv[k];
         printf("%-14s %8.3f ms  %7.1f TF (useful)  x%d   wg0 %.0f kcycles   chk %.6e %.6e %.6e %.6e\n", sh.name, ms, flop / ms / 1e9,
                sh.count, cyc / 1e3, sw, swp, sc, sv);
+        if (x3) {       // spot check against the decoded operands (fp64 on the host)
+            double worst = 0;
+            const int ns[4] = {0, 37, sh.n_valid / 2 + 3, sh.n_valid - 1}, ks[3] = {1, sh.k_valid / 2, sh.k_valid - 1};
+            for (int a = 0; a < 4; ++a)
+                for (int bq = 0; bq < 3; ++bq) {
+                    double ref = 0, mag = 0;
+                    for (long sidx = 0; sidx < M; ++sidx) {
+                        const double p = qhl(hA, sh.lda, sidx, ns[a]) * qhl(hB, sh.ldb, sidx, ks[bq]);
+                        ref += p; mag += fabs(p);
+                    }
+                    const double err = fabs(hw[ns[a] * 640 + ks[bq]] - ref) / (mag + 1e-30);
+                    if (err > worst) worst = err;
+                }
+            double cref = 0, cmag = 0;
+            for (long sidx = 0; sidx < M; ++sidx) { const double p = qhl(hA, sh.lda, sidx, 5); cref += p; cmag += fabs(p); }
+            double vref = 0, vmag = 0;
+            if (sh.vec) for (long sidx = 0; sidx < M; ++sidx) { const double p = h[sidx] * 0 + qhl(hB, sh.ldb, sidx, 9); (void)p; }
+            printf("               spot check vs fp64 of the decoded operands: dW rel err (of sum|.|) %.2e, colsum[5] %.2e\n", worst,
+                   fabs(hc[5] - cref) / (cmag + 1e-30));
+            (void)vref; (void)vmag;
+        }
         total_ms += ms * sh.count; total_flop += flop * sh.count;
     }
     printf("stream total   %8.3f ms  %7.1f TF = %.3f of 157.3\n", total_ms, total_flop / total_ms / 1e9, total_flop / total_ms / 1e9 / 157.3);
