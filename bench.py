@@ -44,9 +44,10 @@ PEAK_FP32_MFMA_TFLOPS = 157.3                 # MI355X_MICROARCH.md chip-level p
 # bf16x3: three bf16 MFMAs per fp32-equivalent product -> a third of the 16x fp32 rate (dense bf16 peak / 3)
 PEAK_BF16X3_TFLOPS = 16.0 * PEAK_FP32_MFMA_TFLOPS / 3.0
 HBM_PEAK_GBS = 8000.0
+PEAK_CLOCK_MHZ = 2400.0                       # the clock both MFMA peaks are quoted at
 # the weight-gradient stage: its main kernel instance first (the 384^2 layers), then what else runs inside the bracket
 WGRAD_KERNEL = {False: "gnr::wgrad_pipe_kernel<3, 3, false, 1> + its other instances + gnr::wgrad_reduce_kernel",
-                True: "gnr::wgrad3_kernel<false> + gnr::wgrad3_kernel<true> + gnr::wgrad_reduce_kernel"}
+                True: "gnr::wgrad3_tr_kernel<3, false> + its other instances + gnr::wgrad_reduce_kernel"}
 
 
 def parse():
@@ -302,7 +303,7 @@ def dist_info(ctx, reducer, clock):
 def run_cfg2b(ctx):
     args, rank, world, dev, dist, torch = (ctx[k] for k in ("args", "rank", "world", "dev", "dist", "torch"))
     from gazenerf_amd import render, synth
-    from gazenerf_amd.hiptime import StageTimer
+    from gazenerf_amd.hiptime import ClockProbe, StageTimer
     from gazenerf_amd.parallel import GradAllReducer
 
     side, n_p = args.side, args.samples
@@ -351,16 +352,23 @@ def run_cfg2b(ctx):
     def leg(precision):
         dt = timed_loop(ctx, lambda: step(precision), reset)
         stage_ms = {k: t.collect() for k, t in timers.items()}
-        return dt, stage_ms, dist_info(ctx, reducer, clock) if fwdbwd else None
+        info = dist_info(ctx, reducer, clock) if fwdbwd else None
+        # one more, untimed, step with the shader-clock probe armed: the clock the power management sustains under
+        # each stage's kernels (the MFMA peaks are quoted at 2.4 GHz)
+        reset(False)
+        with ClockProbe(dev) as probe:
+            step(precision)
+            torch.cuda.synchronize()
+        return dt, stage_ms, info, probe.mhz()
 
-    dt, stage_ms, ar = leg(args.precision)
+    dt, stage_ms, ar, clocks = leg(args.precision)
     alt = None
     if args.precision == "fp32" and not args.no_alt:
         alt = leg("bf16x3")            # second, separately timed leg on the bf16x3 kernels (never the headline)
     if rank != 0:
         return None
 
-    def describe(precision, dt, stage_ms):
+    def describe(precision, dt, stage_ms, clocks):
         x3 = precision == "bf16x3"
         peak = PEAK_BF16X3_TFLOPS if x3 else PEAK_FP32_MFMA_TFLOPS
         ms = dt / args.steps * 1e3
@@ -386,6 +394,10 @@ def run_cfg2b(ctx):
                            "unit": "TFLOP/s", "frac": ach / peak, "avg_ms": a, "launches_timed": len(stage_ms.get(key, [])),
                            "flop_per_launch": flop,
                            "share_of_step": a * per_step_mult * launches_per_step / ms if ms > 0 else 0.0})
+            if clocks.get(key):
+                # in-kernel s_memtime / s_memrealtime of workgroup 0 (gnr_set_clock_probe), separate untimed step
+                stages[-1]["clock_mhz"] = clocks[key]
+                stages[-1]["frac_at_clock"] = ach / (peak * clocks[key] / PEAK_CLOCK_MHZ)
         if fwdbwd and stage_ms.get("comp_bwd"):
             # HBM-bound compositing pass (CalcRayColor backward): algorithmic bytes per sample = 288 saved features +
             # sigma_raw + delta read, w_i + dL/dsigma written; per ray 288 upstream + 3 scalars
@@ -402,7 +414,7 @@ def run_cfg2b(ctx):
         step_ach = step_flop / (ms * 1e-3) / 1e12
         return ms, stages, step_ach, rays_per_launch
 
-    ms, stages, step_ach, rays_per_launch = describe(args.precision, dt, stage_ms)
+    ms, stages, step_ach, rays_per_launch = describe(args.precision, dt, stage_ms, clocks)
     x3 = args.precision == "bf16x3"
     peak = PEAK_BF16X3_TFLOPS if x3 else PEAK_FP32_MFMA_TFLOPS
     # the dominant stage = the largest share of the step among the MFMA-bound stages
@@ -426,6 +438,7 @@ def run_cfg2b(ctx):
                      "peak_basis": ("dense bf16 MFMA peak (16 x 157.3) / 3 terms; achieved counts the fp32-equivalent "
                                     "algorithmic FLOPs") if x3 else "fp32 MFMA peak",
                      "frac": dom["frac"], "frac_of_fp32_mfma_peak": dom["achieved"] / PEAK_FP32_MFMA_TFLOPS,
+                     "clock_mhz": dom.get("clock_mhz"), "frac_at_clock": dom.get("frac_at_clock"),
                      "traffic": traffic, "traffic_source": traffic_src,
                      "flop_per_launch": dom["flop_per_launch"], "avg_launch_ms": dom["avg_ms"],
                      "launches_timed": dom["launches_timed"], "share_of_step": dom["share_of_step"],
@@ -441,8 +454,8 @@ def run_cfg2b(ctx):
     if ar:
         res["allreduce"] = ar
     if alt is not None:
-        adt, ams, _ = alt
-        a_ms, a_stages, a_step, _ = describe("bf16x3", adt, ams)
+        adt, ams, _, aclk = alt
+        a_ms, a_stages, a_step, _ = describe("bf16x3", adt, ams, aclk)
         a_dom = max((s for s in a_stages if s["bound"] == "mfma"), key=lambda s: s["share_of_step"])
         res["bf16x3"] = {
             "note": "same workload, same timing protocol, dense layers (forward, dgrad chain, weight-gradient "

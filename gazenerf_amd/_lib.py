@@ -14,6 +14,7 @@ N_TRUNK = 8
 N_RGB = 3
 WS_FWD, WS_FWD_SAVE, WS_BWD = 0, 1, 2
 STAGE_FWD_MLP, STAGE_DGRAD, STAGE_COMP_BWD, STAGE_WGRAD = 0, 1, 2, 3
+N_STAGES = 4
 ABI_VERSION = 2
 
 _p = C.c_void_p
@@ -75,7 +76,7 @@ class GnrInputGrads(C.Structure):
 
 
 EXPORTS = ("gnr_abi_version", "gnr_sizeof", "gnr_workspace_bytes", "gnr_fwd", "gnr_fwd_bf16x3", "gnr_bwd", "gnr_bwd_bf16x3", "gnr_resample",
-           "gnr_sample_zvals", "gnr_set_kernel_timing", "gnr_set_aux_timing", "gnr_set_stage_timing", "gnr_merge_scratch_bytes",
+           "gnr_sample_zvals", "gnr_set_kernel_timing", "gnr_set_aux_timing", "gnr_set_stage_timing", "gnr_set_clock_probe", "gnr_merge_scratch_bytes",
            "gnr_merge_fwd", "gnr_merge_bwd", "gnr_upsample_workspace_bytes", "gnr_upsample_fwd", "gnr_upsample_bwd",
            "gnr_last_error")
 
@@ -137,6 +138,8 @@ def load():
     lib.gnr_merge_bwd.argtypes = [C.POINTER(GnrMergeProblem)] + [_p] * 10 + [C.c_size_t, _p]
     lib.gnr_set_stage_timing.restype = C.c_int
     lib.gnr_set_stage_timing.argtypes = [C.c_int, _p, _p]
+    lib.gnr_set_clock_probe.restype = C.c_int
+    lib.gnr_set_clock_probe.argtypes = [_p]
     lib.gnr_set_aux_timing.restype = C.c_int
     lib.gnr_set_aux_timing.argtypes = [_p, _p]
     if lib.gnr_abi_version() != ABI_VERSION:

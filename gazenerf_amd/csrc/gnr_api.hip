@@ -24,6 +24,12 @@ void stage_mark(int stage, int which, hipStream_t st) {
     if (hipEvent_t e = g_stage_ev[stage][which].load()) (void)hipEventRecord(e, st);
 }
 
+std::atomic<unsigned long long*> g_clk_probe{nullptr};
+unsigned long long* clock_probe_slot(int stage) {
+    unsigned long long* p = g_clk_probe.load();
+    return p ? p + 2 * stage : nullptr;
+}
+
 int fail(const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -139,6 +145,11 @@ int gnr_set_stage_timing(int stage, void* ev_start, void* ev_stop) {
     return 0;
 }
 
+int gnr_set_clock_probe(void* dev_counters) {
+    g_clk_probe = (unsigned long long*)dev_counters;
+    return 0;
+}
+
 int gnr_set_aux_timing(void* ev_start, void* ev_stop) { return gnr_set_stage_timing(GNR_STAGE_COMP_BWD, ev_start, ev_stop); }
 
 int gnr_set_kernel_timing(void* ev_start, void* ev_stop) {
@@ -174,6 +185,7 @@ static int fwd_impl(const GnrProblem* p, const GnrWeights* face, const GnrWeight
     FwdParams fp{};
     carve_fwd(p, n_streams, save, (char*)workspace, &fp);
     fp.want_wl = (out->weights[0] || (n_streams > 1 && out->weights[1])) ? 1 : 0;
+    fp.clk = clock_probe_slot(GNR_STAGE_FWD_MLP);
     const GnrWeights* ws_in[2] = {face, eyes};
     launch_prep(*p, n_streams, ws_in, fp.ws, st, !bf16x3);
     if (bf16x3) launch_prep3(*p, n_streams, ws_in, fp.ws, st);

@@ -216,6 +216,7 @@ __global__ __launch_bounds__(256, 1) void bwd_chain_kernel(const BwdParams bp) {
     const int j = lane & 31, h = lane >> 5;
     const long chunk = (long)blockIdx.x * WAVES_PER_WG + wave;
     if (chunk >= bp.n_chunks) return;
+    const ClkProbe clk0 = clk_begin();
     const long ray_g = chunk / bp.chunks_per_ray;
     const long row = chunk * CHUNK + j;
     const long M = bp.M;
@@ -300,6 +301,7 @@ __global__ __launch_bounds__(256, 1) void bwd_chain_kernel(const BwdParams bp) {
             gc[0] = sx; gc[1] = sy; gc[2] = sz; gc[3] = zx; gc[4] = zy; gc[5] = zz; gc[6] = 0.0f; gc[7] = 0.0f;
         }
     }
+    clk_end(clk0, bp.clk);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -563,6 +565,7 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         bp.relu_bits = ws.relu_bits; bp.enc = fp.enc; bp.zval = fp.zval;
         bp.dY_h = sc.dY_h; bp.dY_r0 = sc.dY_r0; bp.dY_r1 = sc.dY_r1; bp.dfeat = sc.dfeat;
         bp.geo_chunk = sc.geo_chunk; bp.accumulate_geo = s > 0;
+        bp.clk = clock_probe_slot(GNR_STAGE_DGRAD);
         if (s == 0) stage_mark(GNR_STAGE_DGRAD, 0, st);
         if (bf16x3)
             launch_bwd3_chain(bp, st);

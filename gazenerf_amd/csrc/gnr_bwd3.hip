@@ -62,6 +62,7 @@ constexpr size_t BWD3_LDS_BYTES = RING_BYTES + (size_t)H * sizeof(float);
 __global__ __launch_bounds__(256, 1) void bwd3_chain_kernel(const BwdParams bp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* ring = (char*)smem;
+    const ClkProbe clk0 = clk_begin();
     float* wsig_lds = smem + RING_BYTES / 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(256, 1) void bwd3_chain_kernel(const BwdParams bp) 
         }
     }
     wait_vm<0>();       // no LDS-DMA may outlive the wave
+    clk_end(clk0, bp.clk);
 }
 
 void launch_packT3(const PackTParams& pt, hipStream_t stream) {

@@ -49,6 +49,7 @@ struct BwdParams {
     float* dfeat;             // [M][288]
     float* geo_chunk;         // [n_chunks][8]: sum dpts (3), sum z*dpts (3)
     int accumulate_geo;
+    unsigned long long* clk;  // shader-clock probe or nullptr
 };
 
 // d(encoding) held as a 2-tile C/D register file (lane-half h owns the slots it encoded) -> d(pts).

@@ -25,6 +25,7 @@ template <bool SAVE>
 __global__ __launch_bounds__(256, 1) void fwd_kernel(const FwdParams fp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* enc_lds = smem;                              // [step][thread]: each thread owns a column
+    const ClkProbe clk0 = clk_begin();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel(const FwdParams fp) {
         // ---- A5: chunk-local compositing (utils/model_utils.py:498-534) ----
         composite_chunk(A, sig, delta, z0, ws, chunk, row, lane, SAVE || fp.want_wl);
     }
+    clk_end(clk0, fp.clk);
 }
 
 void launch_fwd(const FwdParams& fp, hipStream_t stream) {

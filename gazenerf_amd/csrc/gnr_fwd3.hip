@@ -82,6 +82,7 @@ template <bool SAVE>
 __global__ __launch_bounds__(256, 1) void fwd3_kernel(const FwdParams fp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* ring = (char*)smem;
+    const ClkProbe clk0 = clk_begin();
     unsigned* enc_lds = (unsigned*)(smem + RING_BYTES / 4);          // [32 words][256 threads]
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(256, 1) void fwd3_kernel(const FwdParams fp) {
         composite_chunk(A, sig, delta, z0, ws, chunk, row, lane, SAVE || fp.want_wl != 0);
     }
     wait_vm<0>();       // no LDS-DMA may outlive the wave
+    clk_end(clk0, fp.clk);
 }
 
 void launch_prep3(const GnrProblem& p, int n_streams, const GnrWeights* const* wts, StreamWs* ws, hipStream_t stream) {

@@ -101,7 +101,22 @@ struct FwdParams {
     float* pts;           // [M][4]        (training only)
     int save;
     int want_wl;
+    unsigned long long* clk;   // shader-clock probe or nullptr
 };
+
+// Shader-clock probe (gnr_set_clock_probe): two scalar counter reads at kernel entry, two at exit, two atomics by
+// one thread of workgroup 0.
+struct ClkProbe {
+    unsigned long long c, r;
+};
+__device__ __forceinline__ ClkProbe clk_begin() { return ClkProbe{__builtin_readcyclecounter(), __builtin_amdgcn_s_memrealtime()}; }
+__device__ __forceinline__ void clk_end(const ClkProbe& s, unsigned long long* clk) {
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(clk, __builtin_readcyclecounter() - s.c);
+        atomicAdd(clk + 1, __builtin_amdgcn_s_memrealtime() - s.r);
+    }
+}
+unsigned long long* clock_probe_slot(int stage);     // gnr_api.hip; nullptr when the probe is off
 
 struct CombineParams {
     GnrProblem prob;

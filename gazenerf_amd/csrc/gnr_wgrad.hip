@@ -47,7 +47,6 @@ namespace gnr {
 //                  2.99 ms for modes 3 / 1 / 2 / 0)
 //   GNR_WG_NOPIPE  route chunk-channel-major operands to wgrad_kernel too (instead of wgrad_pipe_kernel)
 //   GNR_PIPE_ABL   timing experiments on wgrad_pipe_kernel, see there
-//   GNR_WG_CLOCK   store workgroup 0's cycle count (s_memtime) for the effective-clock estimate of the bench
 #ifndef GNR_WG_RIDERS
 #define GNR_WG_RIDERS 3
 #endif
@@ -72,6 +71,7 @@ struct WgradParams {
     //   b*img + lc*chunk + n*row + j.  CCM dumps: row = 32, chunk = 32*ld, img = chunks_per_image*32*ld;
     //   channels-first images [B][C][P]: row = P, chunk = 32, img = C*P.
     long a_row, a_chunk, a_img, b_row, b_chunk, b_img;
+    unsigned long long* clk;      // shader-clock probe (gnr_internal.h) or nullptr
 };
 
 template <int N>
@@ -98,9 +98,7 @@ __global__ __launch_bounds__(64 * WN * WK, 2) void wgrad_kernel(const WgradParam
     const int tile = slot % tiles;
     if (split >= wp.batch * wp.spi) return;
     const int tn = tile / wp.tiles_k, tk = tile - tn * wp.tiles_k;
-#ifdef GNR_WG_CLOCK
-    const unsigned long long clk0 = __builtin_readcyclecounter();
-#endif
+    const ClkProbe clk0 = clk_begin();
 
     // Two workgroups share each SIMD's matrix pipe.  With equal priority they advance in lock-step
     // and reach their per-chunk barrier together, idling the pipe; a static priority for the wave
@@ -247,9 +245,7 @@ __global__ __launch_bounds__(64 * WN * WK, 2) void wgrad_kernel(const WgradParam
     if (RM == 3 || (RM == 2 && (do_cs || do_vs))) loop(std::true_type{});
     else loop(std::false_type{});
 
-#ifdef GNR_WG_CLOCK
-    if (id == 0 && tid == 0) *(unsigned long long*)(wp.vec_part + 1024 * 192 - 2) = __builtin_readcyclecounter() - clk0;
-#endif
+    clk_end(clk0, wp.clk);
     float* pt = wp.partial + (((long)split * wp.tiles_n + tn) * wp.tiles_k + tk) * (long)(TN * TK);
 #pragma unroll
     for (int x = 0; x < XN; ++x)
@@ -337,9 +333,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradParams wp
     const int tile = slot % tiles;
     if (split >= wp.batch * wp.spi) return;
     const int tn = tile / wp.tiles_k, tk = tile - tn * wp.tiles_k;
-#ifdef GNR_WG_CLOCK
-    const unsigned long long clk0 = __builtin_readcyclecounter();
-#endif
+    const ClkProbe clk0 = clk_begin();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave >> 1, wk = wave & 1;
@@ -506,9 +500,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradParams wp
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the zero-filled tail requests
 
-#ifdef GNR_WG_CLOCK
-    if (id == 0 && tid == 0) *(unsigned long long*)(wp.vec_part + 1024 * 192 - 2) = __builtin_readcyclecounter() - clk0;
-#endif
+    clk_end(clk0, wp.clk);
     float* pt = wp.partial + (((long)split * wp.tiles_n + tn) * wp.tiles_k + tk) * (long)(TN * TK);
 #pragma unroll
     for (int x = 0; x < XN; ++x)
@@ -589,9 +581,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr_kernel(const WgradParams wp)
     const int tile = slot % tiles;
     if (split >= wp.batch * wp.spi) return;
     const int tn = tile / wp.tiles_k, tk = tile - tn * wp.tiles_k;
-#ifdef GNR_WG_CLOCK
-    const unsigned long long clk0 = __builtin_readcyclecounter();
-#endif
+    const ClkProbe clk0 = clk_begin();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = split / wp.spi, sp = split - b * wp.spi;
@@ -815,9 +805,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr_kernel(const WgradParams wp)
         spread();
         buf = nbuf;
     }
-#ifdef GNR_WG_CLOCK
-    if (id == 0 && tid == 0) *(unsigned long long*)(wp.vec_part + 1024 * 192 - 2) = __builtin_readcyclecounter() - clk0;
-#endif
+    clk_end(clk0, wp.clk);
     float* pt = wp.partial + (((long)split * wp.tiles_n + tn) * wp.tiles_k + tk) * (long)(TN * TK);
 #pragma unroll
     for (int x = 0; x < XN; ++x)
@@ -964,6 +952,7 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
         wp.a_row = CHUNK; wp.a_chunk = (long)CHUNK * lda; wp.a_img = chunks_per_image * wp.a_chunk;
         wp.b_row = CHUNK; wp.b_chunk = (long)CHUNK * ldb; wp.b_img = chunks_per_image * wp.b_chunk;
     }
+    wp.clk = clock_probe_slot(GNR_STAGE_WGRAD);
     const bool with_vec = vec_out != nullptr;
     // chunk-channel-major fp32 operands of the MLP's shapes go to the pipelined one-workgroup-per-CU kernel
     // (192-row tiles; K = 64 for the encoding columns); everything else to the two-workgroups-per-CU kernel

@@ -61,6 +61,33 @@ class StageTimer:
         return out
 
 
+class ClockProbe:
+    """Shader clock sustained under each MFMA-bound stage (gnr_set_clock_probe): workgroup 0 of the stage's kernels adds
+    {shader cycles, 100 MHz reference ticks} to a device buffer; ``mhz()`` = 100 * cycles / ticks per stage.
+
+        with ClockProbe(device) as probe:
+            ... forward / backward calls ...
+        torch.cuda.synchronize(); probe.mhz() -> {"fwd_mlp": 2093.0, "dgrad": ..., "wgrad": ...}"""
+
+    def __init__(self, device):
+        import torch
+        self.buf = torch.zeros(_lib.N_STAGES, 2, dtype=torch.int64, device=device)
+        self.lib = _lib.load()
+
+    def __enter__(self):
+        self.buf.zero_()
+        self.lib.gnr_set_clock_probe(C.c_void_p(self.buf.data_ptr()))
+        return self
+
+    def __exit__(self, *exc):
+        self.lib.gnr_set_clock_probe(None)
+        return False
+
+    def mhz(self):
+        v = self.buf.cpu().tolist()
+        return {name: 100.0 * v[i][0] / v[i][1] for name, i in STAGES.items() if v[i][1] > 0}
+
+
 class KernelTimer:
     """One event pair, synchronous read-out (tests and small tools).  aux=False: the fused MLP kernel of gnr_fwd /
     the dgrad chain of gnr_bwd (gnr_set_kernel_timing); aux=True: the compositing backward (gnr_set_aux_timing)."""

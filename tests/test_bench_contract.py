@@ -46,6 +46,8 @@ def test_single_gpu_line(mode):
     for s in stages.values():
         assert s["launches_timed"] == 2 and s["avg_ms"] > 0 and 0.0 < s["frac"] < 1.0
         assert abs(s["frac"] - s["achieved"] / s["peak"]) < 1e-9
+        if s["stage"] != "comp_bwd":      # shader clock under the stage's kernels (in-kernel probe): a plausible gfx950 clock
+            assert 500.0 < s["clock_mhz"] <= 2600.0 and abs(s["frac_at_clock"] - s["frac"] * 2400.0 / s["clock_mhz"]) < 1e-9
     assert 0.5 < sum(s["share_of_step"] for s in stages.values()) <= 1.0 + 1e-6
     if mode == "fwd":
         cb = d["cpu_baseline"]

@@ -88,6 +88,98 @@ __global__ __launch_bounds__(256, 1) void k(const u32x4* __restrict__ W, unsigne
     out[blockIdx.x * 256 + tid] = s;
 }
 
+
+// Software-pipelined variant (what the real kernels do: ring reads run one phase ahead, under the MFMAs).
+// FEED 0: none   1: 2 x dwordx4 LDS-DMA right after the barrier   2: the same two pieces after MFMA 1 and MFMA 7
+//      3: 8 x buffer_load_dword ... lds (256 B each), one after each of the first 8 MFMAs
+//      4: 2 x dwordx4 after the barrier, ring reads NOT interleaved (all 8 after the MFMAs' issue)
+template <int FEED>
+__global__ __launch_bounds__(256, 1) void kp(const u32x4* __restrict__ W, unsigned bytes, float* out, int phases) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 ring[];       // 6 slots x 8 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 6 * 512; i += 256) ring[i] = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+    __syncthreads();
+    f32x16 acc[12];
+    for (int i = 0; i < 12; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const u32x4 b0 = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    i32x4 rs;
+    const unsigned long long a = (unsigned long long)W;
+    rs.x = (int)(unsigned)a; rs.y = (int)(unsigned)(a >> 32); rs.z = (int)bytes; rs.w = 0x00020000;
+    const unsigned voff = lane * 16u + wave * 2048u;
+    const unsigned voff4 = lane * 4u + wave * 2048u;
+    unsigned soff = (blockIdx.x * 8192u * 13u) % (bytes - 65536u);
+    unsigned wr = wave * 2048u, rd = 0;
+    u32x4 g[2][8];
+    {
+        const char* src = (const char*)ring + lane * 16;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g[0][i] = *(const u32x4*)(src + i * 1024);
+        rd = 8192u;
+    }
+    auto dma16 = [&](unsigned off) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff + off), "s"(rs), "s"(soff), "s"(wr + off) : "memory");
+    };
+    auto dma4 = [&](unsigned off) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                     "buffer_load_dword %1, %2, %3 offen lds\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff4 + off), "s"(rs), "s"(soff), "s"(wr + off) : "memory");
+    };
+    for (int ph = 0; ph < phases; ph += 2) {
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            if (FEED) { if (FEED == 3) wait_vm<24>(); else wait_vm<6>(); }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (FEED == 1 || FEED == 4) { dma16(0); dma16(1024); }
+            const char* src = (const char*)ring + rd + lane * 16;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                acc[i] = mf(g[par][(2 * (i / 3) + (i % 3 == 1)) & 7], b0, acc[i]);
+                if (FEED == 2 && i == 1) dma16(0);
+                if (FEED == 2 && i == 7) dma16(1024);
+                if (FEED == 3 && i < 8) dma4(256u * i);
+                if (FEED != 4 && i >= 2 && i < 10) g[par ^ 1][i - 2] = *(const u32x4*)(src + (i - 2) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (FEED == 4) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) g[par ^ 1][i] = *(const u32x4*)(src + i * 1024);
+            }
+            if (FEED) {
+                soff += 8192u; if (soff > bytes - 65536u) soff = 0;
+                wr += 8192u; if (wr >= 6 * 8192u) wr -= 6 * 8192u;
+            }
+            rd += 8192u; if (rd >= 6 * 8192u) rd = 0;
+        }
+    }
+    if (FEED) wait_vm<0>();
+    float s = 0.f;
+    for (int i = 0; i < 12; ++i) s += acc[i][0];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
+template <int FEED> void runp(const char* name, const u32x4* W, unsigned bytes, float* out) {
+    const int phases = 20000, blocks = 256;
+    hipFuncSetAttribute((const void*)kp<FEED>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 8192);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kp<FEED>, dim3(blocks), dim3(256), 6 * 8192, 0, W, bytes, out, phases);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+    }
+    const double cyc = ms * 1e-3 * 2.4e9 / phases;
+    printf("%-64s %8.3f ms  %6.0f cycles per phase  MFMA %.0f %%\n", name, ms, cyc, 384.0 / cyc * 100);
+}
+
 template <int MODE> void run(const char* name, const u32x4* W, unsigned bytes, float* out) {
     const int phases = 20000, blocks = 256;
     hipFuncSetAttribute((const void*)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 8192);
@@ -112,6 +204,11 @@ int main() {
     run<0>("no feed (barrier + 8 ds_read_b128 + 12 MFMA)", W, bytes, out);
     run<1>("+ LDS-DMA: 2 x buffer_load_dwordx4 ... lds", W, bytes, out);
     run<2>("+ registers: 2 x buffer_load_dwordx4, 2 x ds_write_b128", W, bytes, out);
+    runp<0>("pipelined reads, no feed", W, bytes, out);
+    runp<1>("pipelined reads + 2 x dwordx4 DMA after the barrier", W, bytes, out);
+    runp<2>("pipelined reads + 2 x dwordx4 DMA after MFMA 1 / 7", W, bytes, out);
+    runp<3>("pipelined reads + 8 x dword DMA, one per MFMA", W, bytes, out);
+    runp<4>("2 x dwordx4 DMA after the barrier, reads after the MFMAs", W, bytes, out);
     printf("%s\n", hipGetErrorString(hipDeviceSynchronize()));
     return 0;
 }

@@ -16,6 +16,10 @@ int fail(const char*, ...) { return 1; }
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
+// the library's shader-clock probe (gnr_api.hip), here a plain device buffer: slot layout [stage][2]
+static unsigned long long* g_clk = nullptr;
+namespace gnr { unsigned long long* clock_probe_slot(int) { return g_clk; } }
+
 int main(int argc, char** argv) {
     const long M = 16384L * 64;                 // one bench micro-batch: 16 384 rays x 64 samples
     const long chunks = M / 32;
@@ -30,6 +34,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&A, M * 384 * 4)); CK(hipMalloc(&B, M * 384 * 4)); CK(hipMalloc(&dW, 384 * 640 * 4));
     CK(hipMalloc(&cs, 4096 * 4)); CK(hipMalloc(&vec, M * 4)); CK(hipMalloc(&vout, 4096 * 4));
     CK(hipMalloc(&scratch, gnr::wgrad_scratch_floats() * 4));
+    CK(hipMalloc(&g_clk, 16)); CK(hipMemset(g_clk, 0, 16));
     // data like the real operands: post-ReLU activations and masked gradients are ~half zeros (the chip clocks to
     // its power budget: dense random operands run the same kernel at a lower clock).  argv[2] = 1: dense instead.
     const bool dense = argc > 2 && atoi(argv[2]) == 1;
@@ -98,9 +103,11 @@ int main(int argc, char** argv) {
         ms /= reps;
         const double flop = 2.0 * M * sh.n_valid * sh.k_valid;
         unsigned long long cyc = 0;
-#ifdef GNR_WG_CLOCK
-        CK(hipMemcpy(&cyc, scratch + (size_t)1024 * 16384 + (size_t)1024 * 192 + (size_t)1024 * 192 - 2, 8, hipMemcpyDeviceToHost));
-#endif
+        unsigned long long hclk[2];
+        CK(hipMemcpy(hclk, g_clk, 16, hipMemcpyDeviceToHost));
+        cyc = hclk[0];
+        const double mhz = hclk[1] ? 100.0 * hclk[0] / hclk[1] : 0.0;
+        CK(hipMemset(g_clk, 0, 16));
         // checksums, to compare builds: sum |dW|, sum |colsum|, sum |vec_out|, and a position-weighted sum of dW
         std::vector<float> hw(384 * 640), hc(384), hv(384);
         CK(hipMemcpy(hw.data(), dW, hw.size() * 4, hipMemcpyDeviceToHost));
@@ -111,8 +118,8 @@ int main(int argc, char** argv) {
             for (int k = 0; k < sh.k_valid; ++k) { const double v = hw[n * 640 + k]; sw += fabs(v); swp += v * ((n * 131 + k * 7) % 97); }
         for (int n = 0; n < sh.n_valid; ++n) sc += fabs(hc[n]) + 1e-3 * n * hc[n];
         if (sh.vec) for (int k = 0; k < sh.k_valid; ++k) sv += fabs(hv[k]) + 1e-3 * k * hv[k];
-        printf("%-14s %8.3f ms  %7.1f TF (useful)  x%d   wg0 %.0f kcycles   chk %.6e %.6e %.6e %.6e\n", sh.name, ms, flop / ms / 1e9,
-               sh.count, cyc / 1e3, sw, swp, sc, sv);
+        printf("%-14s %8.3f ms  %7.1f TF (useful)  x%d   wg0 %.0f kcycles @ %.0f MHz   chk %.6e %.6e %.6e %.6e\n", sh.name, ms, flop / ms / 1e9,
+               sh.count, cyc / 1e3 / (reps + 2), mhz, sw, swp, sc, sv);
         if (x3) {       // spot check against the decoded operands (fp64 on the host)
             double worst = 0;
             const int ns[4] = {0, 37, sh.n_valid / 2 + 3, sh.n_valid - 1}, ks[3] = {1, sh.k_valid / 2, sh.k_valid - 1};
