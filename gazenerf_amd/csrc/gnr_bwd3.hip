@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256, 1) void bwd3_chain_kernel(const BwdParams bp) 
 
     load_relu_bits<NT_H2>(mkn, bits(8), lane);
     // RGB2^T: A(9) -> Bv(6)                          (dumps dfeat)
-    mm3_h<NT_F, NT_H2, INIT_ZERO, false, 1>(A, Bv, nullptr, h, w, GNR_XF(false, qdump(bp.dfeat, FEAT_PAD, chunk, j, h)));
+    mm3_h<NT_F, NT_H2, INIT_ZERO, false, 1, 3>(A, Bv, nullptr, h, w, GNR_XF(false, qdump(bp.dfeat, FEAT_PAD, chunk, j, h)));    // 27 + 3 phases
     promote();
     load_relu_bits<NT_H>(mkn, bits(7), lane);
     // RGB1^T: Bv(6) -> A(12), input masked by y1 > 0  (dumps dY_r1)

@@ -30,11 +30,18 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // split a pair of fp32 values into packed {hi(a), hi(b)} and {lo(a), lo(b)}: v_cvt_pk_bf16_f32 (RNE),
 // shift/mask back to fp32, one packed subtract, v_cvt_pk_bf16_f32 -- 5 VALU instructions per pair
-__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+__device__ __forceinline__ unsigned hi_pair(float a, float b) {                 // 1 VALU
     const f32x2 v = {a, b};
-    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ unsigned lo_pair(float a, float b, unsigned hi) {    // 4 VALU
+    const f32x2 v = {a, b};
     const f32x2 hf = {__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
-    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, bf16x2));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, bf16x2));
+}
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+    hi = hi_pair(a, b);
+    lo = lo_pair(a, b, hi);
 }
 
 // k-order of a K=16 bf16 step s = 2t + u over an activation tile held in the C/D layout: lane-half h
@@ -81,56 +88,40 @@ constexpr unsigned BATCH_BYTES = RB_ROWS * 2048u;      // 8 KiB
 constexpr unsigned RING_BYTES = NSLOT * BATCH_BYTES;   // 48 KiB at LDS offset 0
 static_assert(RB_ROWS == WAVES_PER_WG, "one row of each batch per wave");
 
+// Every layer starts on ring slot 0 (its phase count is a multiple of NSLOT; the one that is not -- RGB2 with 27
+// phases -- appends three empty phases, ring_layer<.., SKIP>), so after unrolling every LDS offset below is an
+// immediate and the only ring arithmetic left is one scalar add of the stream offset per phase.  (Round 1 carried
+// rd / wr / wrap tests in SGPRs: ~10 scalar instructions per 12 MFMAs of a wave that can issue one instruction per
+// four cycles -- see the issue budget at ring_layer.)
 struct WRing {
     i32x4 rs;                // buffer descriptor of the packed stream (num_records = exact bytes)
     unsigned voff;           // lane*16 + wave*2048
     unsigned soff;           // stream offset of the next batch to request
-    unsigned wr;             // LDS address (M0) of this wave's row in the slot to fill next
-    unsigned wr_end;         // wr wraps here
-    unsigned rd;             // ring offset of the batch being consumed
+    unsigned m0v[NSLOT];     // LDS address (M0) of this wave's row in slot s
     const char* lane_base;   // ring + lane*16
     u32x4 g[2][2][2];        // [pair][row][hi/lo]: rows 0,1 and rows 2,3 of the current batch
 };
 
-struct RingTicket {
-    unsigned soff, wr;
-};
-
-// Measured (tools/ablate_fwd3.sh): a piece blocks the issuing wave for ~94 cycles, and that is not
-// contention between the four waves -- spreading their requests over the phase (one wave per MFMA group)
-// made the kernel 12 % slower, because the barrier then waits for whichever wave is stalled.
-__device__ __forceinline__ void ring_issue(const WRing& w, const RingTicket& t) {
+// One 1 KiB piece (PIECE = 0 / 1) of the wave's row of the batch at stream offset soff -> ring slot `slot`.
+// M0 is a reserved register: hipcc never keeps a value in it across instructions (it re-materialises M0 right before
+// each of its own uses), so the asm overwrites it without saving (the generated code is checked for foreign M0 uses by
+// tools/resource_usage.sh).  Measured (tools/ablate_fwd3.sh, tools/ubench/feed_cost.hip): a piece blocks the issuing
+// wave for 40-90 cycles, more than the 32-cycle shadow of one MFMA.
+template <int PIECE>
+__device__ __forceinline__ void ring_issue_piece(const WRing& w, int slot, unsigned soff) {
     if (ABL & 1) return;
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %4\n\t"
-        "s_nop 0\n\t"
-        "buffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
-        "buffer_load_dwordx4 %1, %2, %3 offen offset:1024 lds\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(w.voff), "s"(w.rs), "s"(t.soff), "s"(t.wr)
-        : "memory");
+    if (PIECE == 0)
+        asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                     :: "v"(w.voff), "s"(w.rs), "s"(soff), "s"(w.m0v[slot]) : "memory");
+    else
+        asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen offset:1024 lds"
+                     :: "v"(w.voff), "s"(w.rs), "s"(soff), "s"(w.m0v[slot]) : "memory");
 }
 
-__device__ __forceinline__ RingTicket ring_advance(WRing& w) {
-    const RingTicket t = {w.soff, w.wr};
-    w.soff += BATCH_BYTES;
-    w.wr += BATCH_BYTES;
-    if (w.wr == w.wr_end) w.wr -= RING_BYTES;
-    return t;
-}
-
-__device__ __forceinline__ void ring_request(WRing& w) { ring_issue(w, ring_advance(w)); }
-
-__device__ __forceinline__ void ring_read_pair(const WRing& w, unsigned slot_off, int pair, u32x4 (&g)[2][2]) {
+// quarter i (0..3) of a pair of rows: row i>>1, hi / lo half i&1
+__device__ __forceinline__ void ring_read_quarter(const WRing& w, int slot, int pair, int i, u32x4 (&g)[2][2]) {
     if (ABL & 8) return;
-    const char* p = w.lane_base + slot_off + pair * 4096;
-    g[0][0] = *(const u32x4*)(p);
-    g[0][1] = *(const u32x4*)(p + 1024);
-    g[1][0] = *(const u32x4*)(p + 2048);
-    g[1][1] = *(const u32x4*)(p + 3072);
+    g[i >> 1][i & 1] = *(const u32x4*)(w.lane_base + slot * (int)BATCH_BYTES + pair * 4096 + i * 1024);
 }
 
 __device__ __forceinline__ void ring_init(WRing& w, const float* packed, unsigned stream_bytes, char* ring, int lane,
@@ -142,17 +133,19 @@ __device__ __forceinline__ void ring_init(WRing& w, const float* packed, unsigne
     w.rs.w = 0x00020000;
     w.voff = (unsigned)lane * 16u + wave * 2048u;
     w.soff = 0;
-    w.wr = (unsigned)(size_t)ring + wave * 2048u;
-    w.wr_end = w.wr + RING_BYTES;
-    w.rd = 0;
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; ++sl) w.m0v[sl] = (unsigned)(size_t)ring + wave * 2048u + sl * BATCH_BYTES;
     w.lane_base = ring + lane * 16;
     if (ABL & 8) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) w.g[q >> 2][(q >> 1) & 1][q & 1] = u32x4{(unsigned)lane, 1u, 2u, 3u};
     }
-    if (ABL & 4) {}
 #pragma unroll
-    for (int k = 0; k <= DEPTH; ++k) ring_request(w);
+    for (int k = 0; k <= DEPTH; ++k) {
+        ring_issue_piece<0>(w, k, w.soff);
+        ring_issue_piece<1>(w, k, w.soff);
+        w.soff += BATCH_BYTES;
+    }
 }
 
 // first rows into registers: call after ring_init, with no other barrier in between
@@ -166,7 +159,8 @@ __device__ __forceinline__ void ring_barrier() {
 __device__ __forceinline__ void ring_start(WRing& w) {
     wait_vm<2 * DEPTH>();
     ring_barrier();
-    ring_read_pair(w, 0, 0, w.g[0]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ring_read_quarter(w, 0, 0, i, w.g[0]);
 }
 
 // s_waitcnt vmcnt(n) for an n that is a constant after unrolling
@@ -180,28 +174,52 @@ __device__ __forceinline__ void wait_vm_n(int n) {
     }
 }
 
-// NP pairs of rows (NP even): pair(P, g) issues the six MFMAs of rows 2P, 2P+1 from g[row][hi/lo].
+// NP pairs of rows (NP even): pair(P, g, mid) issues the six MFMAs of rows 2P, 2P+1 from g[row][hi/lo] and calls
+// mid(i) right after its i-th MFMA (i = 0..3).
+// Issue budget: with one wave per SIMD a wave issues ONE instruction per four cycles, whatever its kind, so the 32
+// matrix-pipe cycles of a v_mfma_f32_32x32x16_bf16 cover seven more instructions and nothing else: the phase is
+// scheduled by hand.  mid(i) = one ring read of the NEXT pair's rows (a phase ahead of its use) and, behind the second
+// MFMA of each pair, one LDS-DMA piece; the activation conversion of mm3_h is cut into stages of <= 5 VALU behind
+// other MFMAs.  Round 1 issued both pieces and four reads back to back after the barrier and a whole conversion
+// (19 VALU) in one gap: 7.0 instructions per MFMA, matrix pipe 59 % busy (PMC: profiles/r2_x3_pmc_fwd.txt).
 // stores(ph) = global stores the pair functions of phase ph issue (training dumps), 0 outside [0, NP/2):
 // they sit in the same in-order vmcnt queue as the LDS-DMA pieces, so the wait for "everything but the
 // last DEPTH-1 batches" must allow them too -- counting fewer than were issued only makes the wait
 // stricter, never unsafe.
-template <int NP, class PairFn, class StoresFn>
+// SKIP empty phases (barrier + DMA, no MFMA) follow when NP/2 is not a multiple of NSLOT: the three requests that would
+// target the skipped slots re-request the batch at the unchanged stream offset (the vmcnt bookkeeping counts two
+// pieces per phase), and the next layer / weight set starts on slot 0 again.
+template <int NP, int SKIP, class PairFn, class StoresFn>
 __device__ __forceinline__ void ring_layer(WRing& w, PairFn pair, StoresFn stores) {
     static_assert(NP % 2 == 0, "layers start and end on batch boundaries");
+    constexpr int NPH = NP / 2;
+    static_assert((NPH + SKIP) % NSLOT == 0 && NPH > DEPTH, "every layer starts on ring slot 0");
 #pragma clang loop unroll(full)
-    for (int ph = 0; ph < NP / 2; ++ph) {
+    for (int ph = 0; ph < NPH + SKIP; ++ph) {
         int allow = 2 * (DEPTH - 1);
 #pragma unroll
-        for (int d = 1; d < DEPTH; ++d) allow += (ph - d >= 0 && !(ABL & 64)) ? stores(ph - d) : 0;
+        for (int d = 1; d < DEPTH; ++d) allow += (ph - d >= 0 && ph - d < NPH && !(ABL & 64)) ? stores(ph - d) : 0;
         if (!(ABL & 16)) wait_vm_n(allow);
         if (!(ABL & 2)) ring_barrier();
-        ring_request(w);
-        ring_read_pair(w, w.rd, 1, w.g[1]);
-        pair(2 * ph, w.g[0]);
-        const unsigned nrd = (w.rd + BATCH_BYTES == RING_BYTES) ? 0u : w.rd + BATCH_BYTES;
-        ring_read_pair(w, nrd, 0, w.g[0]);
-        pair(2 * ph + 1, w.g[1]);
-        w.rd = nrd;
+        const int rd = ph % NSLOT, nrd = (ph + 1) % NSLOT, wr = (ph + DEPTH + 1) % NSLOT;
+        const bool dummy = ph >= NPH - (DEPTH + 1) && ph < NPH - (DEPTH + 1) + SKIP;
+        const unsigned soff = w.soff;
+        if (!dummy) w.soff += BATCH_BYTES;
+        if (ph < NPH) {
+            pair(2 * ph, w.g[0], [&](int i) {
+                ring_read_quarter(w, rd, 1, i, w.g[1]);
+                if (i == 1) ring_issue_piece<0>(w, wr, soff);
+            });
+            pair(2 * ph + 1, w.g[1], [&](int i) {
+                ring_read_quarter(w, nrd, 0, i, w.g[0]);
+                if (i == 1) ring_issue_piece<1>(w, wr, soff);
+            });
+        } else {
+            ring_issue_piece<0>(w, wr, soff);
+            ring_issue_piece<1>(w, wr, soff);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ring_read_quarter(w, nrd, 0, i, w.g[0]);
+        }
     }
 }
 
@@ -218,9 +236,14 @@ struct XfNone {
 };
 struct XfRelu {
     __device__ __forceinline__ void operator()(int, int, f32x4& v) const {
-        // one v_med3_f32 each (fmaxf would add a canonicalising v_max in IEEE mode)
+        // one v_max_i32 on the bit pattern each (negative floats are negative integers; fmaxf and fmed3 both compile
+        // to a canonicalising v_max plus the v_max in IEEE mode)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], 0.0f, __builtin_inff());
+        for (int e = 0; e < 4; ++e) {
+            const float x = v[e];       // (a copy: __builtin_bit_cast of an ext-vector ELEMENT reads element 0 with this hipcc)
+            const int b = __builtin_bit_cast(int, x);
+            v[e] = __builtin_bit_cast(float, b > 0 ? b : 0);
+        }
     }
 };
 
@@ -263,6 +286,37 @@ __device__ __forceinline__ void convert_quad(f32x16& src, int r, BTile& dst, int
     dst.l[u][w] = l0; dst.l[u][w + 1] = l1;
 }
 
+// The same conversion in four stages of <= 5 VALU (inference), one behind each of four MFMAs (ring_layer's issue
+// budget): fetch (v_accvgpr_read when the source tile lives in AGPRs) | transform + hi(0,1) | lo(0,1) + hi(2,3) |
+// lo(2,3) + dump + operand words.
+struct ConvQuad {
+    f32x4 v;
+    unsigned h0, h1, l0;
+};
+__device__ __forceinline__ void conv_fetch(const f32x16& src, int r, ConvQuad& c) {
+    c.v = f32x4{src[r], src[r + 1], src[r + 2], src[r + 3]};
+}
+template <bool WRITEBACK, class Xf>
+__device__ __forceinline__ void conv_xf(f32x16& src, int r, int t, Xf& xf, ConvQuad& c) {
+    xf(t, r, c.v);
+    if (WRITEBACK) { src[r] = c.v.x; src[r + 1] = c.v.y; src[r + 2] = c.v.z; src[r + 3] = c.v.w; }
+    c.h0 = hi_pair(c.v.x, c.v.y);
+}
+__device__ __forceinline__ void conv_mid(ConvQuad& c) {
+    c.l0 = lo_pair(c.v.x, c.v.y, c.h0);
+    c.h1 = hi_pair(c.v.z, c.v.w);
+}
+__device__ __forceinline__ void conv_finish(const ConvQuad& c, int r, BTile& dst, int t, const QDump& qd) {
+    const unsigned l1 = lo_pair(c.v.z, c.v.w, c.h1);
+    if (qd.base && !(ABL & 32)) {
+        u32x4* p = (u32x4*)(qd.base + (8 * t + 2 * (r >> 2)) * 512 + (((r >> 2) & 1) ? qd.s1 : qd.s0));
+        dump_store(p, (r >> 3) ? u32x4{c.l0, l1, c.h0, c.h1} : u32x4{c.h0, c.h1, c.l0, l1});
+    }
+    const int u = r >> 3, w = (r & 7) >> 1;
+    dst.h[u][w] = c.h0; dst.h[u][w + 1] = c.h1;
+    dst.l[u][w] = c.l0; dst.l[u][w + 1] = l1;
+}
+
 // accumulator tile nt starts from its bias: lane (j, h) register r <-> channel 32nt + (r&3) + 8(r>>2) + 4h
 __device__ __forceinline__ void bias_init(f32x16& acc, const float* bias, int nt, int h) {
 #pragma unroll
@@ -280,15 +334,19 @@ __device__ __forceinline__ void bias_init(f32x16& acc, const float* bias, int nt
 enum { INIT_NONE = 0, INIT_BIAS = 1, INIT_ZERO = 2 };
 
 // DUMPS = global stores a conversion issues (0, or 1 when qd dumps the quad: the vmcnt bookkeeping needs the count).
-template <int NT_IN, int NT_OUT, int INIT, bool WRITEBACK, int DUMPS, class Xf>
+// SKIP: see ring_layer.
+template <int NT_IN, int NT_OUT, int INIT, bool WRITEBACK, int DUMPS, int SKIP = 0, class Xf>
 __device__ __forceinline__ void mm3_h(f32x16 (&prev)[NT_H], f32x16 (&acc)[NT_H], const float* out_bias, int h, WRing& w,
                                       Xf xf, const QDump qd = QDump{nullptr, 0, 0}) {
     constexpr int PPT = NT_OUT;                 // row pairs per input tile (2 K-steps x NT_OUT rows / 2)
     constexpr int NP = NT_IN * PPT;
-    // conversions (xf calls) issued inside pair P: the next tile's 4 register quads spread over 2 PPT slots
-    auto conv_in_pair = [](int P) {
+    static_assert(PPT >= 2, "at most two conversions per pair");
+    // quads of the next input tile converted before pair pt of the current one: its 4 register quads spread over the
+    // PPT pairs; q_lo(pt + 1) - q_lo(pt) = the conversions (xf calls) issued inside pair pt: 0, 1 or (PPT = 2) 2
+    auto q_lo = [](int pt) { return (4 * pt) / PPT; };
+    auto conv_in_pair = [&](int P) {
         const int t = P / PPT, pt = P % PPT;
-        return t + 1 < NT_IN ? ((2 * pt + 2) * 4) / (2 * PPT) - ((2 * pt) * 4) / (2 * PPT) : 0;
+        return t + 1 < NT_IN ? q_lo(pt + 1) - q_lo(pt) : 0;
     };
     auto stores = [&](int ph) { return DUMPS * (conv_in_pair(2 * ph) + conv_in_pair(2 * ph + 1)); };
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -296,37 +354,47 @@ __device__ __forceinline__ void mm3_h(f32x16 (&prev)[NT_H], f32x16 (&acc)[NT_H],
     if (INIT == INIT_BIAS) { bias_init(acc[0], out_bias, 0, h); bias_init(acc[1 % NT_OUT], out_bias, 1 % NT_OUT, h); }
 #pragma unroll
     for (int r = 0; r < 16; r += 4) convert_quad<WRITEBACK>(prev[0], r, cur, 0, xf, qd);
-    ring_layer<NP>(w, [&](int P, const u32x4 (&g)[2][2]) {
+    ring_layer<NP, SKIP>(w, [&](int P, const u32x4 (&g)[2][2], auto mid) {
         const int t = P / PPT, pt = P % PPT;
         const int i0 = 2 * pt, i1 = i0 + 1;
         const int u0 = i0 / NT_OUT, n0 = i0 % NT_OUT, u1 = i1 / NT_OUT, n1 = i1 % NT_OUT;
+        const int qa = q_lo(pt), nq = (t + 1 < NT_IN && !(ABL & 4)) ? q_lo(pt + 1) - qa : 0;
+        const int tn = t + 1 < NT_IN ? t + 1 : t;       // (index kept in range where nq == 0)
+        ConvQuad cq;
+        const bool z0 = INIT == INIT_ZERO && t == 0 && u0 == 0, z1 = INIT == INIT_ZERO && t == 0 && u1 == 0;
+        acc[n0] = mfma_bf(g[0][0], cur.h[u0], z0 ? zero : acc[n0]);
+        mid(0);
+        if (nq == 1) conv_fetch(prev[tn], 4 * qa, cq);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[n1] = mfma_bf(g[1][0], cur.h[u1], z1 ? zero : acc[n1]);
+        mid(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (nq == 2) {
+            convert_quad<WRITEBACK>(prev[tn], 4 * qa, nxt, tn, xf, qd);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        acc[n0] = mfma_bf(g[0][1], cur.h[u0], acc[n0]);
+        mid(2);
+        if (nq == 1) conv_xf<WRITEBACK>(prev[tn], 4 * qa, tn, xf, cq);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[n1] = mfma_bf(g[1][1], cur.h[u1], acc[n1]);
+        mid(3);
+        if (nq == 1) conv_mid(cq);
+        __builtin_amdgcn_sched_barrier(0);
+        if (nq == 2) {
+            convert_quad<WRITEBACK>(prev[tn], 4 * (qa + 1), nxt, tn, xf, qd);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        acc[n0] = mfma_bf(g[0][0], cur.l[u0], acc[n0]);
+        if (nq == 1) conv_finish(cq, 4 * qa, nxt, tn, qd);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[n1] = mfma_bf(g[1][0], cur.l[u1], acc[n1]);
         // biases of the tiles the NEXT pair opens
         if (INIT == INIT_BIAS && t == 0) {
 #pragma unroll
             for (int i = i0 + 2; i < i0 + 4; ++i)
                 if (i >= 2 && i < NT_OUT) bias_init(acc[i], out_bias, i, h);
         }
-        const bool z0 = INIT == INIT_ZERO && t == 0 && u0 == 0, z1 = INIT == INIT_ZERO && t == 0 && u1 == 0;
-        acc[n0] = mfma_bf(g[0][0], cur.h[u0], z0 ? zero : acc[n0]);
-        acc[n1] = mfma_bf(g[1][0], cur.h[u1], z1 ? zero : acc[n1]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < NT_IN && !(ABL & 4)) {
-#pragma unroll
-            for (int qq = ((2 * pt) * 4) / (2 * PPT); qq < ((2 * pt + 1) * 4) / (2 * PPT); ++qq)
-                convert_quad<WRITEBACK>(prev[t + 1], 4 * qq, nxt, t + 1, xf, qd);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        acc[n0] = mfma_bf(g[0][1], cur.h[u0], acc[n0]);
-        acc[n1] = mfma_bf(g[1][1], cur.h[u1], acc[n1]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < NT_IN && !(ABL & 4)) {
-#pragma unroll
-            for (int qq = ((2 * pt + 1) * 4) / (2 * PPT); qq < ((2 * pt + 2) * 4) / (2 * PPT); ++qq)
-                convert_quad<WRITEBACK>(prev[t + 1], 4 * qq, nxt, t + 1, xf, qd);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        acc[n0] = mfma_bf(g[0][0], cur.l[u0], acc[n0]);
-        acc[n1] = mfma_bf(g[1][0], cur.l[u1], acc[n1]);
         __builtin_amdgcn_sched_barrier(0);
         if (pt == PPT - 1 && t + 1 < NT_IN) cur = nxt;
     }, stores);
@@ -349,16 +417,24 @@ __device__ __forceinline__ void mm3_enc(const unsigned* enc_col, f32x16 (&acc)[N
         }
     bias_init(acc[0], out_bias, 0, h);
     bias_init(acc[1], out_bias, 1, h);
-    ring_layer<NP>(w, [&](int P, const u32x4 (&g)[2][2]) {
+    ring_layer<NP, 0>(w, [&](int P, const u32x4 (&g)[2][2], auto mid) {
         const int i0 = 2 * P, s = i0 / NT_OUT, n0 = i0 % NT_OUT, n1 = n0 + 1;
         if (s == 0 && n0 + 3 < NT_OUT) {
             bias_init(acc[n0 + 2], out_bias, n0 + 2, h);
             bias_init(acc[n0 + 3], out_bias, n0 + 3, h);
         }
         acc[n0] = mfma_bf(g[0][0], bh[s], acc[n0]);
+        mid(0);
+        __builtin_amdgcn_sched_barrier(0);
         acc[n1] = mfma_bf(g[1][0], bh[s], acc[n1]);
+        mid(1);
+        __builtin_amdgcn_sched_barrier(0);
         acc[n0] = mfma_bf(g[0][1], bh[s], acc[n0]);
+        mid(2);
+        __builtin_amdgcn_sched_barrier(0);
         acc[n1] = mfma_bf(g[1][1], bh[s], acc[n1]);
+        mid(3);
+        __builtin_amdgcn_sched_barrier(0);
         acc[n0] = mfma_bf(g[0][0], bl[s], acc[n0]);
         acc[n1] = mfma_bf(g[1][0], bl[s], acc[n1]);
         __builtin_amdgcn_sched_barrier(0);

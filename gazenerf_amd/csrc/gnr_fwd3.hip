@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256, 1) void fwd3_kernel(const FwdParams fp) {
         sig += ws.wsig[H];
         if (SAVE && h == 0) ws.sigma_raw[row] = sig;
         mm3_h<NT_H, NT_H2, INIT_BIAS, false, SAVE ? 1 : 0>(A, Bv, bl(LR1), h, w, XfNone(), qd(ws.act_y0, H));
-        mm3_h<NT_H2, NT_F, INIT_BIAS, false, SAVE ? 1 : 0>(Bv, A, bl(LR2), h, w, xf_relu(sb(8)), qd(ws.act_y1, H2));
+        mm3_h<NT_H2, NT_F, INIT_BIAS, false, SAVE ? 1 : 0, 3>(Bv, A, bl(LR2), h, w, xf_relu(sb(8)), qd(ws.act_y1, H2));   // 27 + 3 phases
         if (SAVE) dump<NT_F>(A, ws.act_feat, FEAT_PAD, chunk, j, h);
         composite_chunk(A, sig, delta, z0, ws, chunk, row, lane, SAVE || fp.want_wl != 0);
     }

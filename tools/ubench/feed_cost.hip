@@ -93,8 +93,13 @@ __global__ __launch_bounds__(256, 1) void k(const u32x4* __restrict__ W, unsigne
 // FEED 0: none   1: 2 x dwordx4 LDS-DMA right after the barrier   2: the same two pieces after MFMA 1 and MFMA 7
 //      3: 8 x buffer_load_dword ... lds (256 B each), one after each of the first 8 MFMAs
 //      4: 2 x dwordx4 after the barrier, ring reads NOT interleaved (all 8 after the MFMAs' issue)
-template <int FEED>
+// DEP 0: every MFMA of a phase has its own accumulator   1: the real kernels' pattern: a pair of accumulators takes three
+// MFMAs each, alternating (n0 n1 n0 n1 n0 n1): every dependent MFMA issues one MFMA after its producer
+// 2: four accumulators in rotation (n0 n1 n2 n3 n0 ...): dependent MFMAs three apart
+__device__ unsigned long long g_clk[2];
+template <int FEED, int DEP>
 __global__ __launch_bounds__(256, 1) void kp(const u32x4* __restrict__ W, unsigned bytes, float* out, int phases) {
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
     extern __shared__ __attribute__((aligned(16))) u32x4 ring[];       // 6 slots x 8 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -141,7 +146,8 @@ __global__ __launch_bounds__(256, 1) void kp(const u32x4* __restrict__ W, unsign
             const char* src = (const char*)ring + rd + lane * 16;
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
-                acc[i] = mf(g[par][(2 * (i / 3) + (i % 3 == 1)) & 7], b0, acc[i]);
+                const int ai = DEP == 0 ? i : DEP == 1 ? 2 * (i / 6) + (i & 1) : (i & 3);
+                acc[ai] = mf(g[par][(2 * (i / 3) + (i % 3 == 1)) & 7], b0, acc[ai]);
                 if (FEED == 2 && i == 1) dma16(0);
                 if (FEED == 2 && i == 7) dma16(1024);
                 if (FEED == 3 && i < 8) dma4(256u * i);
@@ -163,21 +169,25 @@ __global__ __launch_bounds__(256, 1) void kp(const u32x4* __restrict__ W, unsign
     float s = 0.f;
     for (int i = 0; i < 12; ++i) s += acc[i][0];
     out[blockIdx.x * 256 + tid] = s;
+    if (blockIdx.x == 0 && tid == 0) { g_clk[0] = __builtin_readcyclecounter() - c0; g_clk[1] = __builtin_amdgcn_s_memrealtime() - r0; }
 }
 
-template <int FEED> void runp(const char* name, const u32x4* W, unsigned bytes, float* out) {
+template <int FEED, int DEP = 0> void runp(const char* name, const u32x4* W, unsigned bytes, float* out) {
     const int phases = 20000, blocks = 256;
-    hipFuncSetAttribute((const void*)kp<FEED>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 8192);
+    hipFuncSetAttribute((const void*)kp<FEED, DEP>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 8192);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float ms = 0;
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL(kp<FEED>, dim3(blocks), dim3(256), 6 * 8192, 0, W, bytes, out, phases);
+        hipLaunchKernelGGL((kp<FEED, DEP>), dim3(blocks), dim3(256), 6 * 8192, 0, W, bytes, out, phases);
         hipEventRecord(e1); hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
     }
-    const double cyc = ms * 1e-3 * 2.4e9 / phases;
-    printf("%-64s %8.3f ms  %6.0f cycles per phase  MFMA %.0f %%\n", name, ms, cyc, 384.0 / cyc * 100);
+    unsigned long long hc[2];
+    hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_clk), 16);
+    const double mhz = 100.0 * hc[0] / hc[1];
+    const double cyc = ms * 1e-3 * mhz * 1e6 / phases;          // true shader cycles (in-kernel s_memtime / s_memrealtime)
+    printf("%-64s %8.3f ms @ %4.0f MHz  %6.0f cycles per phase  MFMA %.0f %%\n", name, ms, mhz, cyc, 384.0 / cyc * 100);
 }
 
 template <int MODE> void run(const char* name, const u32x4* W, unsigned bytes, float* out) {
@@ -209,6 +219,10 @@ int main() {
     runp<2>("pipelined reads + 2 x dwordx4 DMA after MFMA 1 / 7", W, bytes, out);
     runp<3>("pipelined reads + 8 x dword DMA, one per MFMA", W, bytes, out);
     runp<4>("2 x dwordx4 DMA after the barrier, reads after the MFMAs", W, bytes, out);
+    runp<0, 1>("no feed, accumulators n0 n1 n0 n1 n0 n1 (the real pattern)", W, bytes, out);
+    runp<2, 1>("DMA after MFMA 1 / 7, accumulators n0 n1 n0 n1 n0 n1", W, bytes, out);
+    runp<0, 2>("no feed, four accumulators in rotation", W, bytes, out);
+    runp<2, 2>("DMA after MFMA 1 / 7, four accumulators in rotation", W, bytes, out);
     printf("%s\n", hipGetErrorString(hipDeviceSynchronize()));
     return 0;
 }
