@@ -269,15 +269,31 @@ __device__ __forceinline__ QDump qdump(float* dst, int C, long chunk, int j, int
     return q;
 }
 
-template <bool WRITEBACK, class Xf>
-__device__ __forceinline__ void convert_quad(f32x16& src, int r, BTile& dst, int t, Xf& xf, const QDump& qd) {
+// GNR_DUMP_BRANCH (per translation unit): test qd.base at run time as well.  The branch splits the unrolled layer code
+// into basic blocks, which pins the hand-made instruction order better than sched_barrier does (pure MFMAs still move
+// across those before machine scheduling): measured on bwd3_chain_kernel 6.5 ms with the branch, 6.9 ms without; on
+// fwd3_kernel<true> the same branch cost 190 spilled registers and 1.3 ms.  Compiler behaviour, re-measure on upgrades.
+#ifndef GNR_DUMP_BRANCH
+#define GNR_DUMP_BRANCH 0
+#endif
+
+struct XfLateNone {
+    __device__ __forceinline__ void operator()(int, int, const f32x4&) const {}
+};
+
+// DUMP is a template parameter on purpose: a run-time test of qd.base puts a branch into the unrolled layer code and
+// each of those costs the register allocator ~200 spills.  late(t, r, v): side effects on the transformed values
+// (sign-bit collection of the training forward), kept apart so that the staged version can issue it later.
+template <bool WRITEBACK, bool DUMP, class Xf, class Late>
+__device__ __forceinline__ void convert_quad(f32x16& src, int r, BTile& dst, int t, Xf& xf, Late& late, const QDump& qd) {
     f32x4 v = {src[r], src[r + 1], src[r + 2], src[r + 3]};
     xf(t, r, v);
+    late(t, r, v);
     if (WRITEBACK) { src[r] = v.x; src[r + 1] = v.y; src[r + 2] = v.z; src[r + 3] = v.w; }
     unsigned h0, l0, h1, l1;
     split_pair(v.x, v.y, h0, l0);
     split_pair(v.z, v.w, h1, l1);
-    if (qd.base && !(ABL & 32)) {       // the training dump: the split itself (quads with bit 2 set: halves swapped)
+    if (DUMP && !(ABL & 32) && (!GNR_DUMP_BRANCH || qd.base)) {     // the training dump: the split itself (quads with bit 2 set: halves swapped)
         u32x4* p = (u32x4*)(qd.base + (8 * t + 2 * (r >> 2)) * 512 + (((r >> 2) & 1) ? qd.s1 : qd.s0));
         dump_store(p, (r >> 3) ? u32x4{l0, l1, h0, h1} : u32x4{h0, h1, l0, l1});
     }
@@ -286,9 +302,9 @@ __device__ __forceinline__ void convert_quad(f32x16& src, int r, BTile& dst, int
     dst.l[u][w] = l0; dst.l[u][w + 1] = l1;
 }
 
-// The same conversion in four stages of <= 5 VALU (inference), one behind each of four MFMAs (ring_layer's issue
-// budget): fetch (v_accvgpr_read when the source tile lives in AGPRs) | transform + hi(0,1) | lo(0,1) + hi(2,3) |
-// lo(2,3) + dump + operand words.
+// The same conversion in stages of <= 5 VALU (inference), each behind another MFMA (ring_layer's issue budget):
+// fetch (v_accvgpr_read when the source tile lives in AGPRs) | transform + hi(0,1) | lo(0,1) + hi(2,3) |
+// lo(2,3) + dump + operand words | late(): the training forward's sign bits.
 struct ConvQuad {
     f32x4 v;
     unsigned h0, h1, l0;
@@ -306,9 +322,10 @@ __device__ __forceinline__ void conv_mid(ConvQuad& c) {
     c.l0 = lo_pair(c.v.x, c.v.y, c.h0);
     c.h1 = hi_pair(c.v.z, c.v.w);
 }
+template <bool DUMP>
 __device__ __forceinline__ void conv_finish(const ConvQuad& c, int r, BTile& dst, int t, const QDump& qd) {
     const unsigned l1 = lo_pair(c.v.z, c.v.w, c.h1);
-    if (qd.base && !(ABL & 32)) {
+    if (DUMP && !(ABL & 32) && (!GNR_DUMP_BRANCH || qd.base)) {
         u32x4* p = (u32x4*)(qd.base + (8 * t + 2 * (r >> 2)) * 512 + (((r >> 2) & 1) ? qd.s1 : qd.s0));
         dump_store(p, (r >> 3) ? u32x4{c.l0, l1, c.h0, c.h1} : u32x4{c.h0, c.h1, c.l0, l1});
     }
@@ -335,9 +352,10 @@ enum { INIT_NONE = 0, INIT_BIAS = 1, INIT_ZERO = 2 };
 
 // DUMPS = global stores a conversion issues (0, or 1 when qd dumps the quad: the vmcnt bookkeeping needs the count).
 // SKIP: see ring_layer.
-template <int NT_IN, int NT_OUT, int INIT, bool WRITEBACK, int DUMPS, int SKIP = 0, class Xf>
+template <int NT_IN, int NT_OUT, int INIT, bool WRITEBACK, int DUMPS, int SKIP = 0, class Xf, class Late = XfLateNone>
 __device__ __forceinline__ void mm3_h(f32x16 (&prev)[NT_H], f32x16 (&acc)[NT_H], const float* out_bias, int h, WRing& w,
-                                      Xf xf, const QDump qd = QDump{nullptr, 0, 0}) {
+                                      Xf xf, const QDump qd = QDump{nullptr, 0, 0}, Late late = Late()) {
+    constexpr bool DUMP = DUMPS != 0;
     constexpr int PPT = NT_OUT;                 // row pairs per input tile (2 K-steps x NT_OUT rows / 2)
     constexpr int NP = NT_IN * PPT;
     static_assert(PPT >= 2, "at most two conversions per pair");
@@ -353,7 +371,7 @@ __device__ __forceinline__ void mm3_h(f32x16 (&prev)[NT_H], f32x16 (&acc)[NT_H],
     BTile cur, nxt;
     if (INIT == INIT_BIAS) { bias_init(acc[0], out_bias, 0, h); bias_init(acc[1 % NT_OUT], out_bias, 1 % NT_OUT, h); }
 #pragma unroll
-    for (int r = 0; r < 16; r += 4) convert_quad<WRITEBACK>(prev[0], r, cur, 0, xf, qd);
+    for (int r = 0; r < 16; r += 4) convert_quad<WRITEBACK, DUMP>(prev[0], r, cur, 0, xf, late, qd);
     ring_layer<NP, SKIP>(w, [&](int P, const u32x4 (&g)[2][2], auto mid) {
         const int t = P / PPT, pt = P % PPT;
         const int i0 = 2 * pt, i1 = i0 + 1;
@@ -370,7 +388,7 @@ __device__ __forceinline__ void mm3_h(f32x16 (&prev)[NT_H], f32x16 (&acc)[NT_H],
         mid(1);
         __builtin_amdgcn_sched_barrier(0);
         if (nq == 2) {
-            convert_quad<WRITEBACK>(prev[tn], 4 * qa, nxt, tn, xf, qd);
+            convert_quad<WRITEBACK, DUMP>(prev[tn], 4 * qa, nxt, tn, xf, late, qd);
             __builtin_amdgcn_sched_barrier(0);
         }
         acc[n0] = mfma_bf(g[0][1], cur.h[u0], acc[n0]);
@@ -382,13 +400,14 @@ __device__ __forceinline__ void mm3_h(f32x16 (&prev)[NT_H], f32x16 (&acc)[NT_H],
         if (nq == 1) conv_mid(cq);
         __builtin_amdgcn_sched_barrier(0);
         if (nq == 2) {
-            convert_quad<WRITEBACK>(prev[tn], 4 * (qa + 1), nxt, tn, xf, qd);
+            convert_quad<WRITEBACK, DUMP>(prev[tn], 4 * (qa + 1), nxt, tn, xf, late, qd);
             __builtin_amdgcn_sched_barrier(0);
         }
         acc[n0] = mfma_bf(g[0][0], cur.l[u0], acc[n0]);
-        if (nq == 1) conv_finish(cq, 4 * qa, nxt, tn, qd);
+        if (nq == 1) conv_finish<DUMP>(cq, 4 * qa, nxt, tn, qd);
         __builtin_amdgcn_sched_barrier(0);
         acc[n1] = mfma_bf(g[1][0], cur.l[u1], acc[n1]);
+        if (nq == 1) late(tn, 4 * qa, cq.v);
         // biases of the tiles the NEXT pair opens
         if (INIT == INIT_BIAS && t == 0) {
 #pragma unroll

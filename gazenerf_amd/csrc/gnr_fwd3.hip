@@ -186,21 +186,24 @@ __global__ __launch_bounds__(256, 1) void fwd3_kernel(const FwdParams fp) {
         // training forward: the transform of a layer input = activation + sign bits + dump of that input
         unsigned word = 0;
         auto qd = [&](float* dst, int C) { return SAVE ? qdump(dst, C, chunk, j, h) : QDump{nullptr, 0, 0}; };
-        auto xf_relu = [&](unsigned* bits) {
-            return [=, &word](int t, int rr, f32x4& v) {
-                if (SAVE) {
+        // ReLU in the transform (XfRelu: one v_max_i32 per value); the sign bits ride two MFMAs later (`late` of mm3_h):
+        // bit = min(bits of relu(v), 1), word = (word << 1) | bit -- v_min_u32 + v_lshl_or_b32 per value
+        auto xf_relu = [&](unsigned*) { return XfRelu(); };
+        auto late_bits = [&](unsigned* bits) {
+            return [=, &word](int t, int rr, const f32x4& v) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const bool pos = v[e] > 0.0f;
-                        v[e] = pos ? v[e] : 0.0f;
-                        word = (word << 1) | (pos ? 1u : 0u);
-                    }
-                    // 32 sign bits (tiles 2q, 2q+1) complete: first inserted = register 0 of the even tile
-                    if ((t & 1) && rr == 12) dump_store(bits + (t >> 1) * 64 + lane, __builtin_bitreverse32(word));
-                } else {
-                    XfRelu()(t, rr, v);
+                for (int e = 0; e < 4; ++e) {
+                    const float x = v[e];
+                    const unsigned b = __builtin_bit_cast(unsigned, x);
+                    word = (word << 1) | (b < 1u ? b : 1u);
                 }
+                // 32 sign bits (tiles 2q, 2q+1) complete: first inserted = register 0 of the even tile
+                if ((t & 1) && rr == 12) dump_store(bits + (t >> 1) * 64 + lane, __builtin_bitreverse32(word));
             };
+        };
+        auto lbits = [&](unsigned* bits) {
+            if constexpr (SAVE) return late_bits(bits);
+            else return XfLateNone();
         };
         auto sb = [&](int layer) { return SAVE ? ws.relu_bits + relu_bits_offset(layer, fp.n_chunks, chunk) : nullptr; };
         auto ah = [&](int l) { return SAVE ? ws.act_h + (long)l * fp.M * H : nullptr; };
@@ -209,18 +212,19 @@ __global__ __launch_bounds__(256, 1) void fwd3_kernel(const FwdParams fp) {
 #pragma unroll 1
         for (int rep = 0; rep < 2; ++rep) {                                    // L1..L4
             const int la = 2 * rep + 1, lb = la + 1;
-            mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 1 : 0>(A, Bv, bl(la), h, w, xf_relu(sb(la - 1)), qd(ah(la - 1), H));
-            mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 1 : 0>(Bv, A, bl(lb), h, w, xf_relu(sb(lb - 1)), qd(ah(lb - 1), H));
+            mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 1 : 0>(A, Bv, bl(la), h, w, xf_relu(sb(la - 1)), qd(ah(la - 1), H), lbits(sb(la - 1)));
+            mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 1 : 0>(Bv, A, bl(lb), h, w, xf_relu(sb(lb - 1)), qd(ah(lb - 1), H), lbits(sb(lb - 1)));
         }
         mm3_enc<NT_H>(enc_col, Bv, bl(5), h, w);                               // L5: encoding part, then h4 part
-        mm3_h<NT_H, NT_H, INIT_NONE, false, SAVE ? 1 : 0>(A, Bv, bl(5), h, w, xf_relu(sb(4)), qd(ah(4), H));
-        mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 1 : 0>(Bv, A, bl(6), h, w, xf_relu(sb(5)), qd(ah(5), H));      // L6
-        mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 1 : 0>(A, Bv, bl(7), h, w, xf_relu(sb(6)), qd(ah(6), H));      // L7
+        mm3_h<NT_H, NT_H, INIT_NONE, false, SAVE ? 1 : 0>(A, Bv, bl(5), h, w, xf_relu(sb(4)), qd(ah(4), H), lbits(sb(4)));
+        mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 1 : 0>(Bv, A, bl(6), h, w, xf_relu(sb(5)), qd(ah(5), H), lbits(sb(5)));      // L6
+        mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 1 : 0>(A, Bv, bl(7), h, w, xf_relu(sb(6)), qd(ah(6), H), lbits(sb(6)));      // L7
         // RGB0 consumes h7 = relu(Bv); the density head rides on the conversion (fp32 VALU dot)
         float sig = 0.0f;
         {
             const float* wsg = bias_lds + N_CHAIN * H + 4 * h;
             auto base = xf_relu(sb(7));
+            auto late7 = lbits(sb(7));
             mm3_h<NT_H, NT_H, INIT_BIAS, false, SAVE ? 1 : 0>(Bv, A, bl(LR0), h, w, [&, base](int t, int rr, f32x4& v) {
                 base(t, rr, v);
                 const f32x4 w4 = *(const f32x4*)(wsg + 32 * t + 8 * (rr >> 2));
@@ -228,13 +232,13 @@ __global__ __launch_bounds__(256, 1) void fwd3_kernel(const FwdParams fp) {
                 sig = fmaf(w4.y, v.y, sig);
                 sig = fmaf(w4.z, v.z, sig);
                 sig = fmaf(w4.w, v.w, sig);
-            }, qd(ah(7), H));
+            }, qd(ah(7), H), late7);
         }
         sig += __shfl_xor(sig, 32);
         sig += ws.wsig[H];
         if (SAVE && h == 0) ws.sigma_raw[row] = sig;
         mm3_h<NT_H, NT_H2, INIT_BIAS, false, SAVE ? 1 : 0>(A, Bv, bl(LR1), h, w, XfNone(), qd(ws.act_y0, H));
-        mm3_h<NT_H2, NT_F, INIT_BIAS, false, SAVE ? 1 : 0, 3>(Bv, A, bl(LR2), h, w, xf_relu(sb(8)), qd(ws.act_y1, H2));   // 27 + 3 phases
+        mm3_h<NT_H2, NT_F, INIT_BIAS, false, SAVE ? 1 : 0, 3>(Bv, A, bl(LR2), h, w, xf_relu(sb(8)), qd(ws.act_y1, H2), lbits(sb(8)));   // 27 + 3 phases
         if (SAVE) dump<NT_F>(A, ws.act_feat, FEAT_PAD, chunk, j, h);
         composite_chunk(A, sig, delta, z0, ws, chunk, row, lane, SAVE || fp.want_wl != 0);
     }
