@@ -63,8 +63,9 @@ __host__ __device__ inline int dlayout3_channel(int step16, int h, int q) {
 //   s_waitcnt vmcnt(2 (DEPTH-1))   its own share of batch k+1 has landed
 //   s_barrier                      -> batch k+1 is complete and visible; every wave has issued (hence
 //                                     fetched the operands of) all MFMAs of batch k-1
-//   request batch k+DEPTH+1        into the slot batch k-1 occupied            (NSLOT = DEPTH + 2)
-//   ds_read rows 2,3 of batch k;  MFMAs of rows 0,1;  ds_read rows 0,1 of batch k+1;  MFMAs of rows 2,3
+//   MFMAs of rows 0,1 of batch k, one ds_read of rows 2,3 behind each of the first four, the first piece of batch
+//       k+DEPTH+1 (into the slot batch k-1 occupied, NSLOT = DEPTH + 2) behind the second;
+//   MFMAs of rows 2,3, with the reads of rows 0,1 of batch k+1 and the second piece      (ring_layer: issue budget)
 // The DMA is inline asm (hipcc would otherwise put a vmcnt(0) in front of every LDS read that might
 // alias it); hipcc's own vmcnt bookkeeping stays correct because extra outstanding operations only make
 // its counted waits stricter, and ours count only operations issued after the ones we wait for.

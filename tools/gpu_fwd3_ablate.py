@@ -3,6 +3,7 @@ import glob, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
 import sys, os
+os.environ["GNR_BINDING"] = "ctypes"       # the C++ extension is linked against the in-tree libgnr.so, not the variant
 sys.path.insert(0, %r)
 import torch
 from gazenerf_amd import _lib
