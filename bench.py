@@ -395,7 +395,7 @@ def run_cfg2b(ctx):
                            "flop_per_launch": flop,
                            "share_of_step": a * per_step_mult * launches_per_step / ms if ms > 0 else 0.0})
             if clocks.get(key):
-                # in-kernel s_memtime / s_memrealtime of workgroup 0 (gnr_set_clock_probe), separate untimed step
+                # in-kernel s_memtime / s_memrealtime of every 64th workgroup (gnr_set_clock_probe), separate untimed step
                 stages[-1]["clock_mhz"] = clocks[key]
                 stages[-1]["frac_at_clock"] = ach / (peak * clocks[key] / PEAK_CLOCK_MHZ)
         if fwdbwd and stage_ms.get("comp_bwd"):

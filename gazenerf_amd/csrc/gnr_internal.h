@@ -105,13 +105,14 @@ struct FwdParams {
 };
 
 // Shader-clock probe (gnr_set_clock_probe): two scalar counter reads at kernel entry, two at exit, two atomics by
-// one thread of workgroup 0.
+// one thread of every 64th workgroup (workgroups of the chain kernels live ~0.5 ms: sampling only workgroup 0 would
+// report the clock at the start of the launch, not the one sustained over it).
 struct ClkProbe {
     unsigned long long c, r;
 };
 __device__ __forceinline__ ClkProbe clk_begin() { return ClkProbe{__builtin_readcyclecounter(), __builtin_amdgcn_s_memrealtime()}; }
 __device__ __forceinline__ void clk_end(const ClkProbe& s, unsigned long long* clk) {
-    if (clk && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (clk && (blockIdx.x & 63) == 0 && threadIdx.x == 0) {
         atomicAdd(clk, __builtin_readcyclecounter() - s.c);
         atomicAdd(clk + 1, __builtin_amdgcn_s_memrealtime() - s.r);
     }

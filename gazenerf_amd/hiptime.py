@@ -62,7 +62,7 @@ class StageTimer:
 
 
 class ClockProbe:
-    """Shader clock sustained under each MFMA-bound stage (gnr_set_clock_probe): workgroup 0 of the stage's kernels adds
+    """Shader clock sustained under each MFMA-bound stage (gnr_set_clock_probe): every 64th workgroup of the stage's kernels adds
     {shader cycles, 100 MHz reference ticks} to a device buffer; ``mhz()`` = 100 * cycles / ticks per stage.
 
         with ClockProbe(device) as probe:

@@ -203,7 +203,7 @@ enum { GNR_STAGE_FWD_MLP = 0, GNR_STAGE_DGRAD = 1, GNR_STAGE_COMP_BWD = 2, GNR_S
 int gnr_set_stage_timing(int stage, void* ev_start, void* ev_stop);
 
 /* Shader-clock probe (measurement hook like the ones above; NULL = off, the default).  dev_counters = device memory,
- * uint64_t [GNR_N_STAGES][2], zeroed by the caller: workgroup 0 of every MFMA-bound kernel of a stage (the fused
+ * uint64_t [GNR_N_STAGES][2], zeroed by the caller: every 64th workgroup of every MFMA-bound kernel of a stage (the fused
  * forward kernel; the dgrad chain; each weight-gradient GEMM) adds {shader cycles (s_memtime), 100 MHz reference
  * ticks (s_memrealtime)} it lived through.  cycles / ticks x 100 MHz = the clock the power management sustained under
  * THAT kernel's load -- the MFMA peaks in DESIGN.md are quoted at 2.4 GHz.  COMP_BWD is not probed (HBM-bound). */
