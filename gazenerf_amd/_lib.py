@@ -27,7 +27,7 @@ class GnrProblem(C.Structure):
                 ("world_z1", C.c_float), ("world_z2", C.c_float),
                 ("xy", _p), ("R", _p), ("T", _p), ("Kinv", _p),
                 ("shape_code", _p), ("gaze", _p), ("appea_code", _p),
-                ("t_rand", _p), ("z_edges", _p), ("edges_follow_T", C.c_int32)]
+                ("t_rand", _p), ("z_edges", _p), ("edges_follow_T", C.c_int32), ("weights_packed", C.c_int32)]
 
 
 class GnrWeights(C.Structure):

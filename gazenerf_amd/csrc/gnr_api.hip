@@ -187,8 +187,10 @@ static int fwd_impl(const GnrProblem* p, const GnrWeights* face, const GnrWeight
     fp.want_wl = (out->weights[0] || (n_streams > 1 && out->weights[1])) ? 1 : 0;
     fp.clk = clock_probe_slot(GNR_STAGE_FWD_MLP);
     const GnrWeights* ws_in[2] = {face, eyes};
-    launch_prep(*p, n_streams, ws_in, fp.ws, st, !bf16x3);
-    if (bf16x3) launch_prep3(*p, n_streams, ws_in, fp.ws, st);
+    // weights_packed: the caller vouches that the packed streams in this workspace are current (inference only)
+    const bool reuse = p->weights_packed != 0 && !save;
+    launch_prep(*p, n_streams, ws_in, fp.ws, st, !bf16x3 && !reuse);       // (the code-folded biases are always rebuilt)
+    if (bf16x3 && !reuse) launch_prep3(*p, n_streams, ws_in, fp.ws, st);
     stage_mark(GNR_STAGE_FWD_MLP, 0, st);
     if (bf16x3) launch_fwd3(fp, st);
     else launch_fwd(fp, st);

@@ -120,18 +120,25 @@ std::vector<Tensor> render_fwd(const Tensor& xy, const Tensor& R, const Tensor& 
                                const Tensor& gaze, const Tensor& appea_code, const OptTensor& t_rand, const OptTensor& z_edges,
                                const std::vector<Tensor>& face, const std::vector<Tensor>& eyes, int64_t n_samples, double world_z1,
                                double world_z2, int64_t hidden, int64_t feat_nc, bool save, bool want_depth, bool want_weights,
-                               bool bf16x3, bool edges_follow_T) {
+                               bool bf16x3, bool edges_follow_T, const OptTensor& ws_in, bool weights_packed) {
     Problem p = make_problem(xy, R, T, Kinv, shape_code, gaze, appea_code, t_rand, z_edges, n_samples, world_z1, world_z2, hidden,
                              feat_nc, edges_follow_T);
     const c10::DeviceGuard guard(p.dev);
     const int n_streams = eyes.empty() ? 1 : 2;
     const size_t nbytes = gnr_workspace_bytes(&p.c, n_streams, save ? GNR_WS_FWD_SAVE : GNR_WS_FWD);
+    // a caller-owned workspace (render.PackedWeightCache) whose packed weights may still be current
+    TORCH_CHECK(!weights_packed || (ws_in && !save), "weights_packed needs the caller's workspace and an inference call");
+    if (ws_in) {
+        TORCH_CHECK(ws_in->is_cuda() && ws_in->device() == p.dev && ws_in->scalar_type() == at::kByte && ws_in->is_contiguous() &&
+                    (size_t)ws_in->numel() >= nbytes, "workspace must be a contiguous uint8 tensor of >= ", nbytes, " bytes on ", p.dev);
+    }
+    p.c.weights_packed = weights_packed ? 1 : 0;
     TORCH_CHECK(nbytes != 0, gnr_last_error());
     std::vector<Tensor> keep;
     GnrWeights w[2]{};
     fill_weights(face, p, hidden, feat_nc, "stream0", keep, &w[0]);
     if (n_streams > 1) fill_weights(eyes, p, hidden, feat_nc, "stream1", keep, &w[1]);
-    Tensor ws = alloc_ws(nbytes, p.dev);
+    Tensor ws = ws_in ? *ws_in : alloc_ws(nbytes, p.dev);
     const auto opt = at::TensorOptions().dtype(at::kFloat).device(p.dev);
     GnrOutputs out{};
     std::vector<Tensor> res;

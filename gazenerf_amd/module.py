@@ -71,6 +71,8 @@ class HotPathRenderer(nn.Module):
                  ws_budget_bytes: Optional[int] = None):
         super().__init__()
         self.ws_budget_bytes = ws_budget_bytes      # None == render.DEFAULT_WS_BUDGET; see render_two_stream
+        # inference calls keep their workspace and skip the weight re-layout while the parameters are unchanged
+        self._wcache, self._wcache_fine = R_.PackedWeightCache(), R_.PackedWeightCache()
         if precision not in ("fp32", "bf16x3"):
             raise ValueError("precision must be 'fp32' or 'bf16x3'")
         self.precision = precision
@@ -97,7 +99,7 @@ class HotPathRenderer(nn.Module):
             self.fg_CD_predictor_face.param_list(), self.fg_CD_predictor_eyes.param_list(),
             n_samples=n_p, world_z1=self.world_z1, world_z2=self.world_z2, t_rand=t_rand,
             return_weights=want_w, hidden=self.hidden, feat_nc=self.featmap_nc, precision=self.precision,
-            ws_budget_bytes=self.ws_budget_bytes)
+            ws_budget_bytes=self.ws_budget_bytes, weight_cache=self._wcache)
         if self.hier_sampling:
             zv = R_.sample_zvals(batch_xy, batch_Rmats.detach(), batch_Tvecs.detach(), batch_inv_inmats,
                                  n_samples=n_p, world_z1=self.world_z1, world_z2=self.world_z2, t_rand=t_rand)
@@ -110,7 +112,7 @@ class HotPathRenderer(nn.Module):
                 n_samples=n_p + self.num_sample_fine, world_z1=self.world_z1, world_z2=self.world_z2,
                 z_edges=edges, edges_follow_T=True,       # FineSample detaches only the weights (model_utils.py:418)
                 hidden=self.hidden, feat_nc=self.featmap_nc, precision=self.precision,
-                ws_budget_bytes=self.ws_budget_bytes)
+                ws_budget_bytes=self.ws_budget_bytes, weight_cache=self._wcache_fine)
             out["feat_fine"], out["bg_alpha_fine"] = fine["feat_face"], fine["bg_alpha_face"]
             out["fine_edges"] = edges
         return out

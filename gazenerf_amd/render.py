@@ -152,14 +152,68 @@ def _ext_call(fn, *args):
         raise _lib.GnrError(str(e).split("\n")[0]) from None
 
 
-def _run_forward(prob: _Problem, streams, save: bool, want_depth: bool, want_weights: bool, bf16x3: bool = False):
+class PackedWeightCache:
+    """Caller-owned inference workspace whose re-laid-out weights survive from call to call (GnrProblem.weights_packed).
+
+    Every gnr_fwd re-packs 2 x 5.4 MB of weights into its workspace (12-54 us per weight set: 1-3 % of a 64 x 64-ray
+    inference).  With a cache the op runs inference calls in the cache's workspace and skips the re-layout when
+    nothing changed: same precision, same problem dimensions, and every parameter is the SAME tensor object at the
+    SAME ``_version`` (torch bumps it on every in-place write, e.g. an optimizer step or ``load_state_dict``).  The
+    cache holds references to the parameter tensors, so a freed-and-reallocated address cannot alias a key.
+    Training calls (anything that needs gradients) never use it.  One cache per module and HIP stream: concurrent
+    calls on two streams would share the workspace."""
+
+    def __init__(self):
+        self.ws = None
+        self.shape_key = None
+        self.params = None
+        self.versions = None
+        self.hits = 0
+        self.misses = 0
+
+    def lookup(self, nbytes: int, shape_key, params):
+        """(workspace, packed weights still valid)."""
+        same_shape = self.ws is not None and self.shape_key == shape_key and self.ws.numel() >= nbytes
+        hit = (same_shape and self.params is not None and len(self.params) == len(params) and
+               all(a is b and b._version == v for a, b, v in zip(self.params, params, self.versions)))
+        if not same_shape:
+            self.ws = _alloc_ws(max(int(nbytes), 256), shape_key[-1])
+        self.hits += int(hit)
+        self.misses += int(not hit)
+        return self.ws, hit
+
+    def store(self, shape_key, params):
+        self.shape_key = shape_key
+        self.params = list(params)
+        self.versions = [p._version for p in params]
+
+    def clear(self):
+        self.__init__()
+
+
+def _run_forward(prob: _Problem, streams, save: bool, want_depth: bool, want_weights: bool, bf16x3: bool = False,
+                 cache: Optional[PackedWeightCache] = None, cache_params=None):
     ext = _torch_ext.active()
+    cws, packed, shape_key = None, False, None
+    if cache is not None and not save:
+        c = prob.c
+        nb = _lib.load().gnr_workspace_bytes(C.byref(c), len(streams), _lib.WS_FWD)
+        if nb == 0:
+            _lib.check(1, _lib.load())
+        shape_key = (bool(bf16x3), len(streams), c.batch, c.n_rays, c.n_samples, c.hidden, c.feat_nc, c.shape_dims,
+                     c.gaze_dims, c.appea_dims, int(nb), prob.device)
+        cws, packed = cache.lookup(nb, shape_key, cache_params)
+        # the parameters the kernels read must be the cached tensors themselves, not contiguous copies of them
+        packed = packed and all(a.data_ptr() == b.data_ptr() for a, b in zip(cache_params, [t for st in streams for t in st]))
+    prob.c.weights_packed = 1 if packed else 0
     if ext is not None:                # C++ binding: device guard, current stream, allocation and checks in C++
         t = prob.tensors
         flat = _ext_call(ext.render_fwd, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], streams[0],
                               streams[1] if len(streams) > 1 else [], prob.n_p, prob.c.world_z1, prob.c.world_z2,
                               prob.c.hidden, prob.c.feat_nc, bool(save), bool(want_depth), bool(want_weights), bool(bf16x3),
-                              bool(prob.c.edges_follow_T))
+                              bool(prob.c.edges_follow_T), cws, bool(packed))
+        if cws is not None:
+            cache.store(shape_key, cache_params)
         per = 2 + int(want_depth) + int(want_weights)
         res = []
         for s in range(len(streams)):
@@ -175,7 +229,7 @@ def _run_forward(prob: _Problem, streams, save: bool, want_depth: bool, want_wei
         nbytes = lib.gnr_workspace_bytes(C.byref(prob.c), n_streams, kind)
         if nbytes == 0:
             _lib.check(1, lib)
-        ws = _alloc_ws(nbytes, dev)
+        ws = cws if cws is not None else _alloc_ws(nbytes, dev)
         outs = _lib.GnrOutputs()
         res = []
         for s in range(n_streams):
@@ -194,6 +248,8 @@ def _run_forward(prob: _Problem, streams, save: bool, want_depth: bool, want_wei
         rc = fwd(C.byref(prob.c), C.byref(w0), C.byref(w1) if w1 is not None else None,
                  C.byref(outs), 1 if save else 0, C.c_void_p(ws.data_ptr()), ws.numel(), _stream_ptr(dev))
         _lib.check(rc, lib)
+        if cws is not None:
+            cache.store(shape_key, cache_params)
     return res, ws
 
 
@@ -286,8 +342,9 @@ class _RenderFn(torch.autograd.Function):
         bf16x3 = cfg.get("precision", "fp32") == "bf16x3"
         tile = plan_ray_tiles(prob, n_streams, cfg.get("ws_budget_bytes"), cfg.get("ray_tile")) if need_grad else None
         save = need_grad and tile is None
-        res, ws = _run_forward(prob, streams, save, cfg["want_depth"], cfg["want_weights"], bf16x3)
-        ctx.cfg = {k: v for k, v in cfg.items() if not torch.is_tensor(v)}
+        res, ws = _run_forward(prob, streams, save, cfg["want_depth"], cfg["want_weights"], bf16x3,
+                               cache=None if need_grad else cfg.get("weight_cache"), cache_params=flat_params)
+        ctx.cfg = {k: v for k, v in cfg.items() if not torch.is_tensor(v) and k != "weight_cache"}
         ctx.tile, ctx.need_grad = tile, need_grad
         ctx.param_shapes = [tuple(t.shape) for t in flat_params]
         if need_grad:
@@ -368,7 +425,7 @@ def render_two_stream(batch_xy, R, T, Kinv, shape_code, gaze, appea_code, face_p
                       return_depth: bool = False, return_weights: bool = False,
                       hidden: int = 384, feat_nc: int = 258, precision: str = "fp32",
                       edges_follow_T: bool = False, ray_tile: Optional[int] = None,
-                      ws_budget_bytes: Optional[int] = None):
+                      ws_budget_bytes: Optional[int] = None, weight_cache: Optional["PackedWeightCache"] = None):
     """Run the hot path.  Returns a dict with feat_face [B,feat_nc,N_r], bg_alpha_face [B,1,N_r]
     (and *_eyes when ``eyes_params`` is given; depth_* / w_* [B,1,N_r,N_p] on request).
 
@@ -387,6 +444,9 @@ def render_two_stream(batch_xy, R, T, Kinv, shape_code, gaze, appea_code, face_p
     recomputes forward-with-save per tile and accumulates the gradients in a fixed order.  ``ray_tile`` forces a
     tile size.  The reference makes one forward call for the whole image (models/gaze_nerf.py:211-320); so does
     the caller of this op.
+
+    ``weight_cache`` (a ``PackedWeightCache`` the caller keeps): inference calls run in its workspace and skip the
+    weight re-layout while the parameters are unchanged.
     """
     if precision not in ("fp32", "bf16x3"):
         raise ValueError("precision must be 'fp32' or 'bf16x3'")
@@ -396,7 +456,8 @@ def render_two_stream(batch_xy, R, T, Kinv, shape_code, gaze, appea_code, face_p
     cfg = dict(xy=batch_xy, Kinv=Kinv, n_samples=int(n_samples), world_z1=world_z1, world_z2=world_z2,
                t_rand=t_rand, z_edges=z_edges, hidden=hidden, feat_nc=feat_nc, n_streams=len(streams),
                want_depth=return_depth, want_weights=return_weights, precision=precision,
-               edges_follow_T=bool(edges_follow_T), ray_tile=ray_tile, ws_budget_bytes=ws_budget_bytes)
+               edges_follow_T=bool(edges_follow_T), ray_tile=ray_tile, ws_budget_bytes=ws_budget_bytes,
+               weight_cache=weight_cache)
     flat = [t for st in streams for t in st]
     outs = _RenderFn.apply(cfg, R, T, shape_code, gaze, appea_code, *flat)
     res: Dict[str, torch.Tensor] = {}

@@ -70,6 +70,13 @@ typedef struct GnrProblem {
                                  edges do -- it detaches only the weights, the coarse z it interpolates
                                  between are (T_z - world_z) terms (model_utils.py:418, 455-476, 339-357)
                                  -- so dT is that of the plane sweep.  ABI 2.                   */
+    int32_t weights_packed;   /* only read by gnr_fwd / gnr_fwd_bf16x3 with save_for_backward == 0.  Non-zero:
+                                 `workspace` still holds the re-laid-out weights a previous call of the SAME entry
+                                 point wrote for exactly these weight values, the same number of weight sets, the same
+                                 problem dimensions and the same workspace address; the call then skips its two
+                                 re-layout kernels (2 x 5.4 MB written per call: 1-3 % of a 64 x 64-ray inference).
+                                 The caller owns the invalidation (gazenerf_amd.render.PackedWeightCache keys it on
+                                 tensor identity + torch's version counter).  ABI 2.             */
 } GnrProblem;
 
 /* Parameters of one MLPforNeRF (models/mlp_nerf.py:13-93).  weight = Conv2d [out,in,1,1] memory

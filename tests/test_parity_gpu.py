@@ -835,3 +835,49 @@ def test_cfg5_full_size_hierarchical_properties():
         assert _maxabs(edges[:, sub, :-1], g["out_zvals"][:, 0]) <= 5e-4
         assert _maxabs(out["feat_face"][:, :, sub], g["out_feat_fine"]) <= 5 * TOL
         assert _maxabs(out["bg_alpha_face"][:, :, sub], g["out_bg_alpha_fine"]) <= 5 * TOL
+
+
+@pytest.mark.parametrize("binding", ["torch_ext", "ctypes"])
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_packed_weight_cache_skips_the_relayout_and_never_serves_stale_weights(precision, binding, monkeypatch):
+    """GnrProblem.weights_packed through PackedWeightCache: a second inference call with unchanged parameters hits (the
+    re-layout kernels are skipped) and is bit-identical; an in-place update (what an optimizer step or load_state_dict
+    does) or a replaced tensor misses and gives the uncached result; a training call never touches the cache."""
+    monkeypatch.setenv("GNR_BINDING", binding)
+    dev = _dev()
+    p = _to(synth.synth_problem(64, batch=1, seed=11, ray_subset=torch.arange(512) * 7 % 4096), dev)
+    face = _to(synth.hash_mlp_params("face", seed=2, density_scale=5.0), dev)
+    eyes = _to(synth.hash_mlp_params("eyes", seed=2, density_scale=5.0), dev)
+    cache = render.PackedWeightCache()
+
+    def run(c, f=None):
+        with torch.no_grad():
+            return render.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"], p["appea_code"],
+                                            f or face, eyes, n_samples=64, precision=precision, weight_cache=c)
+
+    ref = run(None)
+    a, b = run(cache), run(cache)
+    assert (cache.misses, cache.hits) == (1, 1)
+    for k in ref:
+        assert torch.equal(ref[k], a[k]) and torch.equal(ref[k], b[k]), k
+    face["FeaExt_module_3.weight"].mul_(1.25)               # in place: same tensor, new version
+    c, ref2 = run(cache), run(None)
+    assert (cache.misses, cache.hits) == (2, 1)
+    assert not torch.equal(ref["feat_face"], ref2["feat_face"])
+    for k in ref2:
+        assert torch.equal(ref2[k], c[k]), k
+    face2 = dict(face)
+    face2["RGB_layer_1.weight"] = face["RGB_layer_1.weight"] * 0.5      # another tensor object
+    d, ref3 = run(cache, face2), render.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"],
+                                                          p["appea_code"], face2, eyes, n_samples=64, precision=precision)
+    assert (cache.misses, cache.hits) == (3, 1)
+    for k in ref3:
+        assert torch.equal(ref3[k], d[k]), k
+    assert torch.equal(run(cache, face2)["feat_face"], ref3["feat_face"]) and cache.hits == 2
+    # a call that needs gradients ignores the cache
+    w = face2["density_module.weight"].clone().requires_grad_(True)
+    out = render.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"], p["appea_code"],
+                                   dict(face2, **{"density_module.weight": w}), eyes, n_samples=64, precision=precision,
+                                   weight_cache=cache)
+    out["feat_face"].sum().backward()
+    assert (cache.misses, cache.hits) == (3, 2) and w.grad is not None

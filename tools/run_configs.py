@@ -39,6 +39,12 @@ for prec in ("fp32", "bf16x3"):
             render.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"], p["appea_code"], face, eyes,
                                      n_samples=64, precision=prec)
     t = timed(cfg2a); rows.append(("cfg2a fwd 4096 rays", prec, t, 4096 / t))
+    wc = render.PackedWeightCache()
+    def cfg2a_cached():
+        with torch.no_grad():
+            render.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"], p["appea_code"], face, eyes,
+                                     n_samples=64, precision=prec, weight_cache=wc)
+    t = timed(cfg2a_cached); rows.append(("cfg2a fwd, packed weights cached", prec, t, 4096 / t))
     # cfg3
     p3 = to(synth.synth_problem(64, batch=2, camera="3", seed=7))
     tr = synth.synth_jitter(2, 4096, 64, seed=1).to(dev)
