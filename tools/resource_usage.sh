@@ -11,3 +11,9 @@ for f in "${files[@]}"; do
              /ScratchSize/ {sc="scratch " $NF} /SGPRs Spill/ {ss="sspill " $3} /VGPRs Spill/ {vs="vspill " $3} /LDS Size/ {l="lds " $NF}
              END {if (n) print n, v, a, sc, ss, vs, l}' | while read -r name rest; do echo "$(echo "$name" | c++filt | cut -c1-70) | $rest"; done
 done
+# M0 audit for the kernels whose inline asm overwrites M0 without saving it (gnr_chain3.h, ring_issue_piece): every line
+# mentioning m0 must be one of those writes.
+for f in gnr_fwd3.hip gnr_bwd3.hip; do
+    n=$(/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -S --cuda-device-only -o - "$f" 2>/dev/null | grep -w "m0" | grep -vcE "^\s*s_mov_b32 m0, (s[0-9]+|vcc_lo|vcc_hi|ttmp[0-9]+)\s*$")
+    echo "$f: foreign M0 uses: $n"
+done
