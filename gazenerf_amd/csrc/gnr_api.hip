@@ -45,7 +45,9 @@ static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 int check_problem(const GnrProblem* p, int n_streams) {
     if (!p) return fail("gnr: problem is NULL");
     if (n_streams < 1 || n_streams > 2) return fail("gnr: n_streams must be 1 or 2 (got %d)", n_streams);
-    if (p->hidden != H) return fail("gnr: this build supports hidden=%d only (got %d)", H, p->hidden);
+    // narrower networks run zero-padded in the 384-wide kernels: same results, 384-wide cost
+    if (p->hidden < 2 || p->hidden > H || (p->hidden & 1))
+        return fail("gnr: this build supports even hidden widths up to hidden=%d (got %d)", H, p->hidden);
     if (p->feat_nc < 1 || p->feat_nc > FEAT_PAD) return fail("gnr: feat_nc must be in [1,%d] (got %d)", FEAT_PAD, p->feat_nc);
     if (p->batch < 1 || p->n_rays < 1) return fail("gnr: empty problem (batch=%d n_rays=%d)", p->batch, p->n_rays);
     if (p->n_samples < 2) return fail("gnr: n_samples must be >= 2 (got %d)", p->n_samples);

@@ -21,7 +21,8 @@ size_t carve_fwd(const GnrProblem* p, int n_streams, bool save, char* base, FwdP
 size_t wgrad_scratch_floats();
 void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, int batch,
                   long chunks_per_image, float* dW, int ldw, int col_off, int enc_map, float* colsum_out,
-                  int colsum_ld, const float* vec, float* vec_out, float* scratch, hipStream_t stream, bool bf16x3);
+                  int colsum_ld, const float* vec, float* vec_out, float* scratch, hipStream_t stream, bool bf16x3,
+                  int n_crop = -1, int k_crop = -1);
 void launch_vecsum(const float* v, int batch, long per_image, float* out, int out_stride, hipStream_t stream);
 void stage_mark(int stage, int which, hipStream_t st);
 
@@ -392,14 +393,15 @@ __global__ void latent_codes_kernel(const LatentParams lp) {
     const GnrProblem& p = lp.prob;
     const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
     const int ext = p.shape_dims + p.gaze_dims, vp = ENC_CH + ext;
+    const int Hh = p.hidden, Hh2 = Hh / 2;                    // logical widths; dbias rows keep the stride H
     const float* db0 = lp.dbias + ((long)0 * p.batch + b) * H;
     const float* db5 = lp.dbias + ((long)5 * p.batch + b) * H;
     const float* dbr1 = lp.dbias + ((long)LR1 * p.batch + b) * H;
     if (c < ext) {
         float acc = 0.0f;
-        for (int n = 0; n < H; ++n) {
+        for (int n = 0; n < Hh; ++n) {
             acc = fmaf(lp.w.fea_w[0][(long)n * vp + ENC_CH + c], db0[n], acc);
-            acc = fmaf(lp.w.fea_w[5][(long)n * (vp + H) + ENC_CH + c], db5[n], acc);
+            acc = fmaf(lp.w.fea_w[5][(long)n * (vp + Hh) + ENC_CH + c], db5[n], acc);
         }
         float* dst = c < p.shape_dims ? (lp.dshape ? lp.dshape + b * p.shape_dims + c : nullptr)
                                       : (lp.dgaze ? lp.dgaze + b * p.gaze_dims + (c - p.shape_dims) : nullptr);
@@ -407,7 +409,7 @@ __global__ void latent_codes_kernel(const LatentParams lp) {
     }
     if (c < p.appea_dims && lp.dappea) {
         float acc = 0.0f;
-        for (int n = 0; n < H2; ++n) acc = fmaf(lp.w.rgb_w[1][(long)n * (H + p.appea_dims) + H + c], dbr1[n], acc);
+        for (int n = 0; n < Hh2; ++n) acc = fmaf(lp.w.rgb_w[1][(long)n * (Hh + p.appea_dims) + Hh + c], dbr1[n], acc);
         float* dst = lp.dappea + b * p.appea_dims + c;
         *dst = lp.accumulate ? *dst + acc : acc;
     }
@@ -418,10 +420,11 @@ __global__ void latent_weights_kernel(const LatentParams lp) {
     const GnrProblem& p = lp.prob;
     const int n = blockIdx.x, t = threadIdx.x;               // block per output row n < H
     const int ext = p.shape_dims + p.gaze_dims, vp = ENC_CH + ext;
+    const int Hh = p.hidden, Hh2 = Hh / 2;                    // rows beyond the network's width have no parameters
     auto code = [&](int b, int c) {
         return c < p.shape_dims ? p.shape_code[b * p.shape_dims + c] : p.gaze[b * p.gaze_dims + (c - p.shape_dims)];
     };
-    for (int c = t; c < ext; c += blockDim.x) {
+    for (int c = t; c < ext && n < Hh; c += blockDim.x) {
         float a0 = 0.0f, a5 = 0.0f;
         for (int b = 0; b < p.batch; ++b) {
             const float cv = code(b, c);
@@ -429,14 +432,14 @@ __global__ void latent_weights_kernel(const LatentParams lp) {
             a5 = fmaf(lp.dbias[((long)5 * p.batch + b) * H + n], cv, a5);
         }
         if (lp.dw.fea_w[0]) lp.dw.fea_w[0][(long)n * vp + ENC_CH + c] = a0;
-        if (lp.dw.fea_w[5]) lp.dw.fea_w[5][(long)n * (vp + H) + ENC_CH + c] = a5;
+        if (lp.dw.fea_w[5]) lp.dw.fea_w[5][(long)n * (vp + Hh) + ENC_CH + c] = a5;
     }
-    if (n < H2 && lp.dw.rgb_w[1])
+    if (n < Hh2 && lp.dw.rgb_w[1])
         for (int c = t; c < p.appea_dims; c += blockDim.x) {
             float a = 0.0f;
             for (int b = 0; b < p.batch; ++b)
                 a = fmaf(lp.dbias[((long)LR1 * p.batch + b) * H + n], p.appea_code[b * p.appea_dims + c], a);
-            lp.dw.rgb_w[1][(long)n * (H + p.appea_dims) + H + c] = a;
+            lp.dw.rgb_w[1][(long)n * (Hh + p.appea_dims) + Hh + c] = a;
         }
     if (t == 0) {
         auto bsum = [&](int l) {
@@ -445,9 +448,9 @@ __global__ void latent_weights_kernel(const LatentParams lp) {
             return a;
         };
         for (int l = 0; l < 8; ++l)
-            if (lp.dw.fea_b[l]) lp.dw.fea_b[l][n] = bsum(l);
-        if (lp.dw.rgb_b[0]) lp.dw.rgb_b[0][n] = bsum(LR0);
-        if (n < H2 && lp.dw.rgb_b[1]) lp.dw.rgb_b[1][n] = bsum(LR1);
+            if (n < Hh && lp.dw.fea_b[l]) lp.dw.fea_b[l][n] = bsum(l);
+        if (n < Hh && lp.dw.rgb_b[0]) lp.dw.rgb_b[0][n] = bsum(LR0);
+        if (n < Hh2 && lp.dw.rgb_b[1]) lp.dw.rgb_b[1][n] = bsum(LR1);
         if (n < p.feat_nc && lp.dw.rgb_b[2]) lp.dw.rgb_b[2][n] = bsum(LR2);
         if (n == 0 && lp.dw.density_b) lp.dw.density_b[0] = bsum(N_CHAIN);
     }
@@ -518,6 +521,7 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
     const long M = fp.M;
     const long rows_per_image = (long)p->n_rays * cpr * CHUNK;
     const int vp = ENC_CH + p->shape_dims + p->gaze_dims;
+    const int Hh = p->hidden, Hh2 = Hh / 2;
     GnrInputGrads dinz{};
     if (din) dinz = *din;
 
@@ -543,18 +547,19 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         auto setl = [&](int l, const float* wp, int ld, int n_valid, int col0, int k_valid, int enc) {
             pt.w[l] = wp; pt.ld[l] = ld; pt.n_valid[l] = n_valid; pt.col0[l] = col0; pt.k_valid[l] = k_valid; pt.enc[l] = enc;
         };
-        setl(0, W.rgb_w[2], H2, p->feat_nc, 0, H2, 0);
-        setl(1, W.rgb_w[1], H + p->appea_dims, H2, 0, H, 0);
-        setl(2, W.rgb_w[0], H, H, 0, H, 0);
-        setl(3, W.fea_w[7], H, H, 0, H, 0);
-        setl(4, W.fea_w[6], H, H, 0, H, 0);
-        setl(5, W.fea_w[5], vp + H, H, 0, ENC_PAD, 1);
-        setl(6, W.fea_w[5], vp + H, H, vp, H, 0);
-        setl(7, W.fea_w[4], H, H, 0, H, 0);
-        setl(8, W.fea_w[3], H, H, 0, H, 0);
-        setl(9, W.fea_w[2], H, H, 0, H, 0);
-        setl(10, W.fea_w[1], H, H, 0, H, 0);
-        setl(11, W.fea_w[0], vp, H, 0, ENC_PAD, 1);
+        // Hh = the network's own width (<= H): rows / columns beyond it are packed as zeros (as in launch_prep)
+        setl(0, W.rgb_w[2], Hh2, p->feat_nc, 0, Hh2, 0);
+        setl(1, W.rgb_w[1], Hh + p->appea_dims, Hh2, 0, Hh, 0);
+        setl(2, W.rgb_w[0], Hh, Hh, 0, Hh, 0);
+        setl(3, W.fea_w[7], Hh, Hh, 0, Hh, 0);
+        setl(4, W.fea_w[6], Hh, Hh, 0, Hh, 0);
+        setl(5, W.fea_w[5], vp + Hh, Hh, 0, ENC_PAD, 1);
+        setl(6, W.fea_w[5], vp + Hh, Hh, vp, Hh, 0);
+        setl(7, W.fea_w[4], Hh, Hh, 0, Hh, 0);
+        setl(8, W.fea_w[3], Hh, Hh, 0, Hh, 0);
+        setl(9, W.fea_w[2], Hh, Hh, 0, Hh, 0);
+        setl(10, W.fea_w[1], Hh, Hh, 0, Hh, 0);
+        setl(11, W.fea_w[0], vp, Hh, 0, ENC_PAD, 1);
         pt.packed = sc.packedT;
         if (bf16x3) launch_packT3(pt, st);
         else hipLaunchKernelGGL(packT_kernel, dim3(1024), dim3(256), 0, st, pt);
@@ -582,26 +587,27 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         auto dbl = [&](int l) { return sc.dbias + (size_t)l * p->batch * H; };
         const long cpi = (long)p->n_rays * cpr;                       // chunks per image
         if (s == 0) stage_mark(GNR_STAGE_WGRAD, 0, st);
-        launch_wgrad(sc.dfeat, FEAT_PAD, p->feat_nc, ws.act_y1, H2, H2, p->batch, cpi, DW.rgb_w[2], H2, 0, 0,
-                     dbl(LR2), H, nullptr, nullptr, sc.wg_part, st, bf16x3);
-        launch_wgrad(sc.dY_r1, H2, H2, ws.act_y0, H, H, p->batch, cpi, DW.rgb_w[1], H + p->appea_dims, 0, 0,
-                     dbl(LR1), H, nullptr, nullptr, sc.wg_part, st, bf16x3);
-        launch_wgrad(sc.dY_r0, H, H, hptr(7), H, H, p->batch, cpi, DW.rgb_w[0], H, 0, 0, dbl(LR0), H,
-                     sc.dsig, DW.density_w, sc.wg_part, st, bf16x3);
+        // GEMM shapes = the kernels' (H, H2); the last two arguments crop the written gradient to the network's width
+        launch_wgrad(sc.dfeat, FEAT_PAD, p->feat_nc, ws.act_y1, H2, H2, p->batch, cpi, DW.rgb_w[2], Hh2, 0, 0,
+                     dbl(LR2), H, nullptr, nullptr, sc.wg_part, st, bf16x3, p->feat_nc, Hh2);
+        launch_wgrad(sc.dY_r1, H2, H2, ws.act_y0, H, H, p->batch, cpi, DW.rgb_w[1], Hh + p->appea_dims, 0, 0,
+                     dbl(LR1), H, nullptr, nullptr, sc.wg_part, st, bf16x3, Hh2, Hh);
+        launch_wgrad(sc.dY_r0, H, H, hptr(7), H, H, p->batch, cpi, DW.rgb_w[0], Hh, 0, 0, dbl(LR0), H,
+                     sc.dsig, DW.density_w, sc.wg_part, st, bf16x3, Hh, Hh);
         for (int l = 7; l >= 1; --l) {
             if (l == 5) {
-                launch_wgrad(dyh(5), H, H, hptr(4), H, H, p->batch, cpi, DW.fea_w[5], vp + H, vp, 0, dbl(5), H,
-                             nullptr, nullptr, sc.wg_part, st, bf16x3);
+                launch_wgrad(dyh(5), H, H, hptr(4), H, H, p->batch, cpi, DW.fea_w[5], vp + Hh, vp, 0, dbl(5), H,
+                             nullptr, nullptr, sc.wg_part, st, bf16x3, Hh, Hh);
                 if (DW.fea_w[5])
-                    launch_wgrad(dyh(5), H, H, bf16x3 ? fp.enc3 : fp.enc, ENC_PAD, ENC_PAD, p->batch, cpi, DW.fea_w[5], vp + H, 0,
-                                 bf16x3 ? 2 : 1, nullptr, 0, nullptr, nullptr, sc.wg_part, st, bf16x3);
+                    launch_wgrad(dyh(5), H, H, bf16x3 ? fp.enc3 : fp.enc, ENC_PAD, ENC_PAD, p->batch, cpi, DW.fea_w[5], vp + Hh, 0,
+                                 bf16x3 ? 2 : 1, nullptr, 0, nullptr, nullptr, sc.wg_part, st, bf16x3, Hh, ENC_PAD);
             } else {
-                launch_wgrad(dyh(l), H, H, hptr(l - 1), H, H, p->batch, cpi, DW.fea_w[l], H, 0, 0, dbl(l), H,
-                             nullptr, nullptr, sc.wg_part, st, bf16x3);
+                launch_wgrad(dyh(l), H, H, hptr(l - 1), H, H, p->batch, cpi, DW.fea_w[l], Hh, 0, 0, dbl(l), H,
+                             nullptr, nullptr, sc.wg_part, st, bf16x3, Hh, Hh);
             }
         }
         launch_wgrad(dyh(0), H, H, bf16x3 ? fp.enc3 : fp.enc, ENC_PAD, ENC_PAD, p->batch, cpi, DW.fea_w[0], vp, 0, bf16x3 ? 2 : 1,
-                     dbl(0), H, nullptr, nullptr, sc.wg_part, st, bf16x3);
+                     dbl(0), H, nullptr, nullptr, sc.wg_part, st, bf16x3, Hh, ENC_PAD);
         if (s == 0) stage_mark(GNR_STAGE_WGRAD, 1, st);
         launch_vecsum(sc.dsig_ray, p->batch, p->n_rays, dbl(N_CHAIN), H, st);
 

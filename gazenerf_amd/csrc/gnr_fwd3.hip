@@ -248,19 +248,20 @@ __global__ __launch_bounds__(256, 1) void fwd3_kernel(const FwdParams fp) {
 
 void launch_prep3(const GnrProblem& p, int n_streams, const GnrWeights* const* wts, StreamWs* ws, hipStream_t stream) {
     const int vp = ENC_CH + p.shape_dims + p.gaze_dims;
+    const int Hh = p.hidden, Hh2 = Hh / 2;      // narrower networks: zero rows / columns beyond their width (launch_prep)
     for (int s = 0; s < n_streams; ++s) {
         Pack3Params pp;
         for (int l = 0; l < N_CHAIN; ++l) {
             if (l <= 7) {
                 pp.w[l] = wts[s]->fea_w[l];
-                pp.ld[l] = (l == 0) ? vp : (l == 5 ? vp + H : H);
-                pp.n_out[l] = H; pp.hcol[l] = (l == 5) ? vp : 0; pp.kh[l] = (l == 0) ? 0 : H;
+                pp.ld[l] = (l == 0) ? vp : (l == 5 ? vp + Hh : Hh);
+                pp.n_out[l] = Hh; pp.hcol[l] = (l == 5) ? vp : 0; pp.kh[l] = (l == 0) ? 0 : Hh;
             } else if (l == LR0) {
-                pp.w[l] = wts[s]->rgb_w[0]; pp.ld[l] = H; pp.n_out[l] = H; pp.hcol[l] = 0; pp.kh[l] = H;
+                pp.w[l] = wts[s]->rgb_w[0]; pp.ld[l] = Hh; pp.n_out[l] = Hh; pp.hcol[l] = 0; pp.kh[l] = Hh;
             } else if (l == LR1) {
-                pp.w[l] = wts[s]->rgb_w[1]; pp.ld[l] = H + p.appea_dims; pp.n_out[l] = H2; pp.hcol[l] = 0; pp.kh[l] = H;
+                pp.w[l] = wts[s]->rgb_w[1]; pp.ld[l] = Hh + p.appea_dims; pp.n_out[l] = Hh2; pp.hcol[l] = 0; pp.kh[l] = Hh;
             } else {
-                pp.w[l] = wts[s]->rgb_w[2]; pp.ld[l] = H2; pp.n_out[l] = p.feat_nc; pp.hcol[l] = 0; pp.kh[l] = H2;
+                pp.w[l] = wts[s]->rgb_w[2]; pp.ld[l] = Hh2; pp.n_out[l] = p.feat_nc; pp.hcol[l] = 0; pp.kh[l] = Hh2;
             }
         }
         pp.packed = (unsigned short*)ws[s].packed;

@@ -57,21 +57,24 @@ __global__ void bias_kernel(const BiasParams bp) {
     const GnrProblem& p = bp.prob;
     const int ext = p.shape_dims + p.gaze_dims;
     const int vp = ENC_CH + ext;
+    const int Hh = p.hidden, Hh2 = Hh / 2;      // channels beyond the network's width: bias 0 (their weights are packed as 0)
     float v = 0.0f;
     if (l <= 7) {
-        v = bp.w.fea_b[l][n];
-        if (l == 0 || l == 5) {
-            const int ld = (l == 0) ? vp : vp + H;
-            const float* wr = bp.w.fea_w[l] + (size_t)n * ld + ENC_CH;
-            for (int c = 0; c < p.shape_dims; ++c) v = fmaf(wr[c], p.shape_code[b * p.shape_dims + c], v);
-            for (int c = 0; c < p.gaze_dims; ++c) v = fmaf(wr[p.shape_dims + c], p.gaze[b * p.gaze_dims + c], v);
+        if (n < Hh) {
+            v = bp.w.fea_b[l][n];
+            if (l == 0 || l == 5) {
+                const int ld = (l == 0) ? vp : vp + Hh;
+                const float* wr = bp.w.fea_w[l] + (size_t)n * ld + ENC_CH;
+                for (int c = 0; c < p.shape_dims; ++c) v = fmaf(wr[c], p.shape_code[b * p.shape_dims + c], v);
+                for (int c = 0; c < p.gaze_dims; ++c) v = fmaf(wr[p.shape_dims + c], p.gaze[b * p.gaze_dims + c], v);
+            }
         }
     } else if (l == LR0) {
-        v = bp.w.rgb_b[0][n];
+        if (n < Hh) v = bp.w.rgb_b[0][n];
     } else if (l == LR1) {
-        if (n < H2) {
+        if (n < Hh2) {
             v = bp.w.rgb_b[1][n];
-            const float* wr = bp.w.rgb_w[1] + (size_t)n * (H + p.appea_dims) + H;
+            const float* wr = bp.w.rgb_w[1] + (size_t)n * (Hh + p.appea_dims) + Hh;
             for (int c = 0; c < p.appea_dims; ++c) v = fmaf(wr[c], p.appea_code[b * p.appea_dims + c], v);
         }
     } else {
@@ -79,7 +82,7 @@ __global__ void bias_kernel(const BiasParams bp) {
     }
     bp.bias[((size_t)l * p.batch + b) * H + n] = v;
     if (l == 0 && b == 0) {
-        bp.wsig[n] = bp.w.density_w[n];
+        bp.wsig[n] = n < Hh ? bp.w.density_w[n] : 0.0f;
         if (n == 0) bp.wsig[H] = bp.w.density_b[0];
     }
 }
@@ -87,21 +90,22 @@ __global__ void bias_kernel(const BiasParams bp) {
 void launch_prep(const GnrProblem& p, int n_streams, const GnrWeights* const* w, StreamWs* ws,
                  hipStream_t stream, bool pack_fp32) {
     const int vp = ENC_CH + p.shape_dims + p.gaze_dims;
+    const int Hh = p.hidden, Hh2 = Hh / 2;      // the network's own width; rows / columns beyond it are packed as zeros
     for (int s = 0; s < n_streams; ++s) {
         PackParams pp;
         for (int l = 0; l < N_CHAIN; ++l) {
             if (l <= 7) {
                 pp.w[l] = w[s]->fea_w[l];
-                pp.ld[l] = (l == 0) ? vp : (l == 5 ? vp + H : H);
-                pp.n_out[l] = H;
+                pp.ld[l] = (l == 0) ? vp : (l == 5 ? vp + Hh : Hh);
+                pp.n_out[l] = Hh;
                 pp.hcol[l] = (l == 5) ? vp : 0;
-                pp.kh[l] = (l == 0) ? 0 : H;
+                pp.kh[l] = (l == 0) ? 0 : Hh;
             } else if (l == LR0) {
-                pp.w[l] = w[s]->rgb_w[0]; pp.ld[l] = H; pp.n_out[l] = H; pp.hcol[l] = 0; pp.kh[l] = H;
+                pp.w[l] = w[s]->rgb_w[0]; pp.ld[l] = Hh; pp.n_out[l] = Hh; pp.hcol[l] = 0; pp.kh[l] = Hh;
             } else if (l == LR1) {
-                pp.w[l] = w[s]->rgb_w[1]; pp.ld[l] = H + p.appea_dims; pp.n_out[l] = H2; pp.hcol[l] = 0; pp.kh[l] = H;
+                pp.w[l] = w[s]->rgb_w[1]; pp.ld[l] = Hh + p.appea_dims; pp.n_out[l] = Hh2; pp.hcol[l] = 0; pp.kh[l] = Hh;
             } else {
-                pp.w[l] = w[s]->rgb_w[2]; pp.ld[l] = H2; pp.n_out[l] = p.feat_nc; pp.hcol[l] = 0; pp.kh[l] = H2;
+                pp.w[l] = w[s]->rgb_w[2]; pp.ld[l] = Hh2; pp.n_out[l] = p.feat_nc; pp.hcol[l] = 0; pp.kh[l] = Hh2;
             }
         }
         pp.packed = ws[s].packed;

@@ -939,10 +939,13 @@ static int choose_tile(int n_valid, int k_valid, bool vec) {
 
 // dW[n_valid x k_valid] (+ col_off, optional encoding-slot map) = A^T B over all chunks.
 // Optional: colsum_out[b][n] = per-image column sums of A; vec_out[k] = vec^T B.
+// n_crop x k_crop (<= n_valid x k_valid): the part of the product that is written out -- a network narrower than the
+// kernels' 384 channels has zero channels beyond its width in the dumps; the GEMM runs on the kernels' shapes, the
+// reduction writes the network's.
 static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, int batch,
                               long chunks_per_image, float* dW, int ldw, int col_off, int enc_map, float* colsum_out,
                               int colsum_ld, const float* vec, float* vec_out, float* scratch, hipStream_t stream,
-                              bool bf16x3, long pixels_per_image) {
+                              bool bf16x3, long pixels_per_image, int n_crop, int k_crop) {
     WgradParams wp{};
     wp.A = A; wp.B = B; wp.lda = lda; wp.ldb = ldb; wp.n_valid = n_valid; wp.k_valid = k_valid;
     if (pixels_per_image > 0) {       // channels-first images [B][C][P]
@@ -1022,10 +1025,10 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
     rp.partial = scratch; rp.splits = splits; rp.tiles_n = wp.tiles_n; rp.tiles_k = wp.tiles_k;
     rp.tn_rows = TN; rp.tk_cols = TK;
     rp.cs_q = pipe_xk ? 2 * wp.tiles_k : 1; rp.vs_q = pipe_xk ? 2 * wp.tiles_n : 1;
-    rp.n_valid = n_valid; rp.k_valid = k_valid; rp.dW = dW; rp.ldw = ldw; rp.col_off = col_off; rp.enc_map = enc_map;
+    rp.n_valid = n_crop; rp.k_valid = k_crop; rp.dW = dW; rp.ldw = ldw; rp.col_off = col_off; rp.enc_map = enc_map;
     rp.colsum_part = cs_part; rp.colsum_out = colsum_out; rp.colsum_ld = colsum_ld; rp.batch = batch; rp.spi = (int)spi;
     rp.vec_part = vec_part; rp.vec_out = vec_out ? vec_out : nullptr;
-    const long total = (long)n_valid * k_valid;
+    const long total = (long)n_crop * k_crop;
     const long per_block = total >= 16384 ? 64 : 16;            // elements per block, see reduce_dw
     long rblocks = (total + per_block - 1) / per_block;
     if (rblocks < 8) rblocks = 8;                               // the rider sums below run grid-stride too
@@ -1034,9 +1037,11 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
 
 void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, int batch,
                   long chunks_per_image, float* dW, int ldw, int col_off, int enc_map, float* colsum_out,
-                  int colsum_ld, const float* vec, float* vec_out, float* scratch, hipStream_t stream, bool bf16x3) {
+                  int colsum_ld, const float* vec, float* vec_out, float* scratch, hipStream_t stream, bool bf16x3,
+                  int n_crop = -1, int k_crop = -1) {
     launch_wgrad_impl(A, lda, n_valid, B, ldb, k_valid, batch, chunks_per_image, dW, ldw, col_off, enc_map, colsum_out,
-                      colsum_ld, vec, vec_out, scratch, stream, bf16x3, 0);
+                      colsum_ld, vec, vec_out, scratch, stream, bf16x3, 0, n_crop < 0 ? n_valid : n_crop,
+                      k_crop < 0 ? k_valid : k_crop);
 }
 
 // dW[n_valid x k_valid] = sum over images and pixels of A[b][n][p] * B[b][k][p] for channels-first fp32 images
@@ -1045,7 +1050,7 @@ void launch_wgrad_img(const float* A, int lda, int n_valid, const float* B, int 
                       long pixels_per_image, float* dW, int ldw, float* colsum_out, int colsum_ld, float* scratch,
                       hipStream_t stream) {
     launch_wgrad_impl(A, lda, n_valid, B, ldb, k_valid, batch, pixels_per_image / CHUNK, dW, ldw, 0, 0, colsum_out,
-                      colsum_ld, nullptr, nullptr, scratch, stream, false, pixels_per_image);
+                      colsum_ld, nullptr, nullptr, scratch, stream, false, pixels_per_image, n_valid, k_valid);
 }
 
 // per-image sum of a per-sample vector: out[b] = sum_{s in image b} v[s]   (density bias gradient)

@@ -47,7 +47,9 @@ typedef struct GnrProblem {
     int32_t batch;          /* B                                                              */
     int32_t n_rays;         /* N_r per image                                                  */
     int32_t n_samples;      /* N_p per ray  (opt.num_sample_coarse, or 192 for the fine pass) */
-    int32_t hidden;         /* opt.mlp_hidden_nchannels; this build supports 384              */
+    int32_t hidden;         /* opt.mlp_hidden_nchannels: 384 in the reference; any even width <= 384 is
+                               accepted and runs zero-padded in the 384-wide kernels (same results,
+                               384-wide cost; weight and gradient tensors keep their own shapes)       */
     int32_t feat_nc;        /* opt.featmap_nc; this build supports <= 288 (reference: 258)    */
     int32_t shape_dims;     /* 179 = iden + expr (configs/gazenerf_options.py:17)             */
     int32_t gaze_dims;      /* 2                                                              */

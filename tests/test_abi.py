@@ -42,7 +42,7 @@ def test_validation_errors_without_gpu(lib_built):
     from gazenerf_amd import _lib
     lib = _lib.load()
     p = _lib.GnrProblem()
-    p.batch, p.n_rays, p.n_samples, p.hidden, p.feat_nc = 1, 16, 64, 256, 258
+    p.batch, p.n_rays, p.n_samples, p.hidden, p.feat_nc = 1, 16, 64, 400, 258
     assert lib.gnr_workspace_bytes(ctypes.byref(p), 2, _lib.WS_FWD) == 0
     assert b"hidden=384" in lib.gnr_last_error()
     p.hidden = 384
@@ -78,7 +78,7 @@ def test_torch_extension_builds_and_loads(lib_built):
     assert ext.abi_version() == _lib.ABI_VERSION
     assert ext.saved_workspace_bytes(2, 4096, 64, 384, 258, 2) > 15e9          # cfg3: ~17 GB of saved activations
     with pytest.raises(RuntimeError, match="hidden=384"):
-        ext.saved_workspace_bytes(1, 16, 64, 256, 258, 2)
+        ext.saved_workspace_bytes(1, 16, 64, 385, 258, 2)
     x = torch.zeros(1, 2, 4)
     with pytest.raises(RuntimeError, match="no CPU path"):
         ext.render_fwd(x, x, x, x, x, x, x, None, None, [], [], 32, 2.5, -3.5, 384, 258, False, False, False, False, False, None, False)
