@@ -27,7 +27,8 @@ class GnrProblem(C.Structure):
                 ("world_z1", C.c_float), ("world_z2", C.c_float),
                 ("xy", _p), ("R", _p), ("T", _p), ("Kinv", _p),
                 ("shape_code", _p), ("gaze", _p), ("appea_code", _p),
-                ("t_rand", _p), ("z_edges", _p), ("edges_follow_T", C.c_int32), ("weights_packed", C.c_int32)]
+                ("t_rand", _p), ("z_edges", _p), ("edges_follow_T", C.c_int32), ("weights_packed", C.c_int32),
+                ("vd_dims", C.c_int32), ("ray_bias", _p * 2)]
 
 
 class GnrWeights(C.Structure):
@@ -72,7 +73,7 @@ GnrUpsampleWeightGrads = GnrUpsampleWeights      # identical layout (include/gnr
 
 
 class GnrInputGrads(C.Structure):
-    _fields_ = [("R", _p), ("T", _p), ("shape_code", _p), ("gaze", _p), ("appea_code", _p)]
+    _fields_ = [("R", _p), ("T", _p), ("shape_code", _p), ("gaze", _p), ("appea_code", _p), ("ray_bias", _p * 2)]
 
 
 EXPORTS = ("gnr_abi_version", "gnr_sizeof", "gnr_workspace_bytes", "gnr_fwd", "gnr_fwd_bf16x3", "gnr_bwd", "gnr_bwd_bf16x3", "gnr_resample",

@@ -52,7 +52,7 @@ int check_problem(const GnrProblem* p, int n_streams) {
     if (p->batch < 1 || p->n_rays < 1) return fail("gnr: empty problem (batch=%d n_rays=%d)", p->batch, p->n_rays);
     if (p->n_samples < 2) return fail("gnr: n_samples must be >= 2 (got %d)", p->n_samples);
     if ((p->n_samples + CHUNK - 1) / CHUNK > 16) return fail("gnr: n_samples must be <= 512 (got %d)", p->n_samples);
-    if (p->shape_dims < 0 || p->gaze_dims < 0 || p->appea_dims < 0) return fail("gnr: negative latent dims");
+    if (p->shape_dims < 0 || p->gaze_dims < 0 || p->appea_dims < 0 || p->vd_dims < 0) return fail("gnr: negative latent dims");
     if (!p->xy || !p->R || !p->T || !p->Kinv) return fail("gnr: xy/R/T/Kinv must be non-NULL");
     if ((p->shape_dims && !p->shape_code) || (p->gaze_dims && !p->gaze) || (p->appea_dims && !p->appea_code))
         return fail("gnr: latent code pointer is NULL");
@@ -188,6 +188,7 @@ static int fwd_impl(const GnrProblem* p, const GnrWeights* face, const GnrWeight
     carve_fwd(p, n_streams, save, (char*)workspace, &fp);
     fp.want_wl = (out->weights[0] || (n_streams > 1 && out->weights[1])) ? 1 : 0;
     fp.clk = clock_probe_slot(GNR_STAGE_FWD_MLP);
+    for (int s = 0; s < n_streams; ++s) fp.ws[s].ray_bias = p->ray_bias[s];
     const GnrWeights* ws_in[2] = {face, eyes};
     // weights_packed: the caller vouches that the packed streams in this workspace are current (inference only)
     const bool reuse = p->weights_packed != 0 && !save;

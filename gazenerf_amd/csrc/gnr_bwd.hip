@@ -409,7 +409,8 @@ __global__ void latent_codes_kernel(const LatentParams lp) {
     }
     if (c < p.appea_dims && lp.dappea) {
         float acc = 0.0f;
-        for (int n = 0; n < Hh2; ++n) acc = fmaf(lp.w.rgb_w[1][(long)n * (Hh + p.appea_dims) + Hh + c], dbr1[n], acc);
+        const int ld1 = Hh + p.vd_dims + p.appea_dims, a0 = Hh + p.vd_dims;      // appearance columns of RGB_layer_1
+        for (int n = 0; n < Hh2; ++n) acc = fmaf(lp.w.rgb_w[1][(long)n * ld1 + a0 + c], dbr1[n], acc);
         float* dst = lp.dappea + b * p.appea_dims + c;
         *dst = lp.accumulate ? *dst + acc : acc;
     }
@@ -439,8 +440,10 @@ __global__ void latent_weights_kernel(const LatentParams lp) {
             float a = 0.0f;
             for (int b = 0; b < p.batch; ++b)
                 a = fmaf(lp.dbias[((long)LR1 * p.batch + b) * H + n], p.appea_code[b * p.appea_dims + c], a);
-            lp.dw.rgb_w[1][(long)n * (Hh + p.appea_dims) + Hh + c] = a;
+            lp.dw.rgb_w[1][(long)n * (Hh + p.vd_dims + p.appea_dims) + Hh + p.vd_dims + c] = a;
         }
+    if (n < Hh2 && lp.dw.rgb_w[1])      // view-direction columns: their gradient flows through ray_bias to the caller's fold
+        for (int c = t; c < p.vd_dims; c += blockDim.x) lp.dw.rgb_w[1][(long)n * (Hh + p.vd_dims + p.appea_dims) + Hh + c] = 0.0f;
     if (t == 0) {
         auto bsum = [&](int l) {
             float a = 0.0f;
@@ -453,6 +456,48 @@ __global__ void latent_weights_kernel(const LatentParams lp) {
         if (n < Hh2 && lp.dw.rgb_b[1]) lp.dw.rgb_b[1][n] = bsum(LR1);
         if (n < p.feat_nc && lp.dw.rgb_b[2]) lp.dw.rgb_b[2][n] = bsum(LR2);
         if (n == 0 && lp.dw.density_b) lp.dw.density_b[0] = bsum(N_CHAIN);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// d loss / d ray_bias[ray][c] = sum over the ray's samples of dY of RGB_layer_1 (GnrProblem.ray_bias is added to that
+// layer's bias for every sample of the ray).  One wave per ray over the saved dY_r1 dump: chunk-channel-major fp32
+// (32 contiguous samples per channel), or the bf16x3 path's QHL quads (16 bytes {hi01, hi23, lo01, lo23} per sample; the
+// slot permutation and the half swap do not matter to a sum over all 32 slots except for which half is hi).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ray_bias_grad_kernel(const float* __restrict__ dY_r1, int chunks_per_ray, long n_rays_total,
+                                                            int n_out, int qhl, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long ray = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n_rays_total) return;
+    if (!qhl) {
+        for (int c = lane; c < n_out; c += 64) {
+            float acc = 0.0f;
+            for (int ch = 0; ch < chunks_per_ray; ++ch) {
+                const f32x4* src = (const f32x4*)(dY_r1 + (ray * chunks_per_ray + ch) * (long)(CHUNK * H2) + c * CHUNK);
+#pragma unroll
+                for (int q = 0; q < CHUNK / 4; ++q) { const f32x4 v = src[q]; acc += (v.x + v.y) + (v.z + v.w); }
+            }
+            out[ray * n_out + c] = acc;
+        }
+    } else {
+        for (int quad = lane; 4 * quad < n_out; quad += 64) {
+            float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            const bool swapped = (quad >> 2) & 1;
+            for (int ch = 0; ch < chunks_per_ray; ++ch) {
+                const uint4* src = (const uint4*)((const char*)dY_r1 + (ray * chunks_per_ray + ch) * (long)(CHUNK * H2 * 4) + quad * 512);
+                for (int j = 0; j < CHUNK; ++j) {
+                    const uint4 e = src[j];
+                    const unsigned h01 = swapped ? e.z : e.x, h23 = swapped ? e.w : e.y, l01 = swapped ? e.x : e.z, l23 = swapped ? e.y : e.w;
+                    a[0] += __uint_as_float(h01 << 16) + __uint_as_float(l01 << 16);
+                    a[1] += __uint_as_float(h01 & 0xffff0000u) + __uint_as_float(l01 & 0xffff0000u);
+                    a[2] += __uint_as_float(h23 << 16) + __uint_as_float(l23 << 16);
+                    a[3] += __uint_as_float(h23 & 0xffff0000u) + __uint_as_float(l23 & 0xffff0000u);
+                }
+            }
+            for (int e = 0; e < 4; ++e)
+                if (4 * quad + e < n_out) out[ray * n_out + 4 * quad + e] = a[e];
+        }
     }
 }
 
@@ -549,7 +594,7 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         };
         // Hh = the network's own width (<= H): rows / columns beyond it are packed as zeros (as in launch_prep)
         setl(0, W.rgb_w[2], Hh2, p->feat_nc, 0, Hh2, 0);
-        setl(1, W.rgb_w[1], Hh + p->appea_dims, Hh2, 0, Hh, 0);
+        setl(1, W.rgb_w[1], Hh + p->vd_dims + p->appea_dims, Hh2, 0, Hh, 0);
         setl(2, W.rgb_w[0], Hh, Hh, 0, Hh, 0);
         setl(3, W.fea_w[7], Hh, Hh, 0, Hh, 0);
         setl(4, W.fea_w[6], Hh, Hh, 0, Hh, 0);
@@ -590,7 +635,7 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         // GEMM shapes = the kernels' (H, H2); the last two arguments crop the written gradient to the network's width
         launch_wgrad(sc.dfeat, FEAT_PAD, p->feat_nc, ws.act_y1, H2, H2, p->batch, cpi, DW.rgb_w[2], Hh2, 0, 0,
                      dbl(LR2), H, nullptr, nullptr, sc.wg_part, st, bf16x3, p->feat_nc, Hh2);
-        launch_wgrad(sc.dY_r1, H2, H2, ws.act_y0, H, H, p->batch, cpi, DW.rgb_w[1], Hh + p->appea_dims, 0, 0,
+        launch_wgrad(sc.dY_r1, H2, H2, ws.act_y0, H, H, p->batch, cpi, DW.rgb_w[1], Hh + p->vd_dims + p->appea_dims, 0, 0,
                      dbl(LR1), H, nullptr, nullptr, sc.wg_part, st, bf16x3, Hh2, Hh);
         launch_wgrad(sc.dY_r0, H, H, hptr(7), H, H, p->batch, cpi, DW.rgb_w[0], Hh, 0, 0, dbl(LR0), H,
                      sc.dsig, DW.density_w, sc.wg_part, st, bf16x3, Hh, Hh);
@@ -610,6 +655,10 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
                      dbl(0), H, nullptr, nullptr, sc.wg_part, st, bf16x3, Hh, ENC_PAD);
         if (s == 0) stage_mark(GNR_STAGE_WGRAD, 1, st);
         launch_vecsum(sc.dsig_ray, p->batch, p->n_rays, dbl(N_CHAIN), H, st);
+
+        if (dinz.ray_bias[s])
+            hipLaunchKernelGGL(ray_bias_grad_kernel, dim3((unsigned)((n_rays_total + 3) / 4)), dim3(256), 0, st, sc.dY_r1, cpr,
+                               n_rays_total, Hh2, bf16x3 ? 1 : 0, dinz.ray_bias[s]);
 
         // 6. latent gradients from the per-image bias sums
         LatentParams lp{};

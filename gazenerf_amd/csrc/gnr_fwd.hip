@@ -94,6 +94,13 @@ __global__ __launch_bounds__(256, 1) void fwd_kernel(const FwdParams fp) {
                 const int l = q / (H / 4), c4 = q - l * (H / 4);
                 *(f32x4*)(bias_lds + l * BIAS_ROW + 4 * c4) = *(const f32x4*)(bsrc + l * bstride + 4 * c4);
             }
+            // per-ray bias of RGB_layer_1 (the caller's fold of the view-direction columns, include/gnr.h); LDS
+            // operations of one wave execute in order
+            if (ws.ray_bias) {
+                const int nrb = p.hidden / 2;
+                const float* rb = ws.ray_bias + ray_g * nrb;
+                for (int c = lane; c < nrb; c += 64) bias_lds[LR1 * BIAS_ROW + c] += rb[c];
+            }
         }
         auto bl = [&](int l) { return bias_lds + l * BIAS_ROW; };
         auto dp = [&](float* dst, int C) -> float* { return SAVE ? dump_ptr(dst, C, chunk, j, h) : nullptr; };

@@ -181,6 +181,11 @@ __global__ __launch_bounds__(256, 1) void fwd3_kernel(const FwdParams fp) {
             }
             for (int q = lane; q < H / 4; q += 64)
                 *(f32x4*)(bias_lds + N_CHAIN * H + 4 * q) = *(const f32x4*)(ws.wsig + 4 * q);
+            if (ws.ray_bias) {      // per-ray bias of RGB_layer_1 (view-direction columns folded by the caller, gnr.h)
+                const int nrb = p.hidden / 2;
+                const float* rb = ws.ray_bias + ray_g * nrb;
+                for (int c = lane; c < nrb; c += 64) bias_lds[LR1 * H + c] += rb[c];
+            }
         }
         auto bl = [&](int l) { return bias_lds + l * H; };
         // training forward: the transform of a layer input = activation + sign bits + dump of that input
@@ -259,7 +264,7 @@ void launch_prep3(const GnrProblem& p, int n_streams, const GnrWeights* const* w
             } else if (l == LR0) {
                 pp.w[l] = wts[s]->rgb_w[0]; pp.ld[l] = Hh; pp.n_out[l] = Hh; pp.hcol[l] = 0; pp.kh[l] = Hh;
             } else if (l == LR1) {
-                pp.w[l] = wts[s]->rgb_w[1]; pp.ld[l] = Hh + p.appea_dims; pp.n_out[l] = Hh2; pp.hcol[l] = 0; pp.kh[l] = Hh;
+                pp.w[l] = wts[s]->rgb_w[1]; pp.ld[l] = Hh + p.vd_dims + p.appea_dims; pp.n_out[l] = Hh2; pp.hcol[l] = 0; pp.kh[l] = Hh;
             } else {
                 pp.w[l] = wts[s]->rgb_w[2]; pp.ld[l] = Hh2; pp.n_out[l] = p.feat_nc; pp.hcol[l] = 0; pp.kh[l] = Hh2;
             }

@@ -83,6 +83,7 @@ struct StreamWs {
     float* act_feat;      // [M][FEAT_PAD]
     float* sigma_raw;     // [M]
     unsigned* relu_bits;  // [9][n_chunks][6][64]: sign bits of h0..h7, y1 in register order (lane-major)
+    const float* ray_bias;  // GnrProblem.ray_bias of this weight set ([B*N_r][hidden/2]) or nullptr
 };
 
 struct FwdParams {

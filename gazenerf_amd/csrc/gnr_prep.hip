@@ -74,7 +74,8 @@ __global__ void bias_kernel(const BiasParams bp) {
     } else if (l == LR1) {
         if (n < Hh2) {
             v = bp.w.rgb_b[1][n];
-            const float* wr = bp.w.rgb_w[1] + (size_t)n * (Hh + p.appea_dims) + Hh;
+            // columns [Hh, Hh + vd_dims) belong to the view-direction embedding: GnrProblem.ray_bias carries them
+            const float* wr = bp.w.rgb_w[1] + (size_t)n * (Hh + p.vd_dims + p.appea_dims) + Hh + p.vd_dims;
             for (int c = 0; c < p.appea_dims; ++c) v = fmaf(wr[c], p.appea_code[b * p.appea_dims + c], v);
         }
     } else {
@@ -103,7 +104,7 @@ void launch_prep(const GnrProblem& p, int n_streams, const GnrWeights* const* w,
             } else if (l == LR0) {
                 pp.w[l] = w[s]->rgb_w[0]; pp.ld[l] = Hh; pp.n_out[l] = Hh; pp.hcol[l] = 0; pp.kh[l] = Hh;
             } else if (l == LR1) {
-                pp.w[l] = w[s]->rgb_w[1]; pp.ld[l] = Hh + p.appea_dims; pp.n_out[l] = Hh2; pp.hcol[l] = 0; pp.kh[l] = Hh;
+                pp.w[l] = w[s]->rgb_w[1]; pp.ld[l] = Hh + p.vd_dims + p.appea_dims; pp.n_out[l] = Hh2; pp.hcol[l] = 0; pp.kh[l] = Hh;
             } else {
                 pp.w[l] = w[s]->rgb_w[2]; pp.ld[l] = Hh2; pp.n_out[l] = p.feat_nc; pp.hcol[l] = 0; pp.kh[l] = Hh2;
             }

@@ -52,6 +52,32 @@ class MLPParams(nn.Module):
         raise RuntimeError("MLPParams only holds parameters; evaluate it through HotPathRenderer")
 
 
+VD_FREQS = 4                       # GazeNeRFNet.vd_n_freqs (models/gaze_nerf.py:30)
+VD_DIMS = 3 + 6 * VD_FREQS         # 27 channels with include_input (gaze_nerf.py:31, 72-76)
+
+
+def view_direction_embedding(batch_xy, batch_Rmats, batch_inv_inmats):
+    """[B, 27, N_r]: the reference's ``vd_encoder(fg_dirs)`` (models/gaze_nerf.py:240-241) for one sample of each
+    ray -- ``dirs`` is the normalised ray direction expanded along the samples (utils/model_utils.py:366-369, 317),
+    so the embedding is constant along a ray.  Embedder order: x | sin(2^k x), cos(2^k x) for k = 0..3
+    (utils/model_utils.py:253-280).  Plain torch: differentiable w.r.t. the rotation."""
+    xyz = torch.nn.functional.pad(batch_xy, [0, 0, 0, 1, 0, 0], mode="constant", value=1.0)
+    d = batch_Rmats.bmm(batch_inv_inmats.bmm(xyz))
+    d = d / torch.norm(d, dim=1, keepdim=True)
+    parts = [d]
+    for k in range(VD_FREQS):
+        parts += [torch.sin(d * (2.0 ** k)), torch.cos(d * (2.0 ** k))]
+    return torch.cat(parts, dim=1)
+
+
+def view_direction_ray_bias(vd_embed, mlp: "MLPParams"):
+    """[B, N_r, H/2] = W[:, H:H+27] @ embedding: the view-direction columns of RGB_layer_1 folded into a per-ray bias
+    (render_two_stream(ray_bias_*=...)); autograd carries the gradient back into those columns and the rotation."""
+    h = mlp.h_channel
+    w = mlp.RGB_layer_1.weight[:, h:h + VD_DIMS, 0, 0]
+    return torch.einsum("ok,bkr->bro", w, vd_embed).contiguous()
+
+
 class HotPathRenderer(nn.Module):
     """GazeNeRF's two-stream volumetric renderer (the hot span of GazeNeRFNet._forward).
 
@@ -68,7 +94,7 @@ class HotPathRenderer(nn.Module):
                  world_z2: float = -3.5, hidden: int = 384, featmap_nc: int = 258,
                  shape_dims: int = synth.SHAPE_DIMS, gaze_dims: int = synth.GAZE_DIMS,
                  appea_dims: int = synth.APPEA_DIMS, hier_sampling: bool = False, precision: str = "fp32",
-                 ws_budget_bytes: Optional[int] = None):
+                 ws_budget_bytes: Optional[int] = None, include_vd: bool = False):
         super().__init__()
         self.ws_budget_bytes = ws_budget_bytes      # None == render.DEFAULT_WS_BUDGET; see render_two_stream
         # inference calls keep their workspace and skip the weight re-layout while the parameters are unchanged
@@ -80,11 +106,16 @@ class HotPathRenderer(nn.Module):
         self.world_z1, self.world_z2 = world_z1, world_z2
         self.hidden, self.featmap_nc = hidden, featmap_nc
         self.hier_sampling = hier_sampling
+        # include_vd (GazeNeRFNet's constructor argument, models/gaze_nerf.py:14, 70-80): RGB_layer_1 of every MLP also
+        # sees the 27-channel embedding of the view direction, in front of the appearance code
+        self.include_vd = include_vd
+        self.vd_dims = VD_DIMS if include_vd else 0
         vp = 63 + shape_dims + gaze_dims
-        self.fg_CD_predictor_eyes = MLPParams(vp, appea_dims, h_channel=hidden, res_nfeat=featmap_nc)
-        self.fg_CD_predictor_face = MLPParams(vp, appea_dims, h_channel=hidden, res_nfeat=featmap_nc)
+        vd_ch = appea_dims + self.vd_dims
+        self.fg_CD_predictor_eyes = MLPParams(vp, vd_ch, h_channel=hidden, res_nfeat=featmap_nc)
+        self.fg_CD_predictor_face = MLPParams(vp, vd_ch, h_channel=hidden, res_nfeat=featmap_nc)
         if hier_sampling:
-            self.fine_fg_CD_predictor = MLPParams(vp, appea_dims, h_channel=hidden, res_nfeat=featmap_nc)
+            self.fine_fg_CD_predictor = MLPParams(vp, vd_ch, h_channel=hidden, res_nfeat=featmap_nc)
 
     def forward(self, batch_xy, batch_Rmats, batch_Tvecs, batch_inv_inmats, shape_code, appea_code,
                 gaze_code, for_train: bool = False, t_rand: Optional[torch.Tensor] = None,
@@ -94,12 +125,20 @@ class HotPathRenderer(nn.Module):
         if for_train and t_rand is None:
             t_rand = torch.rand(B, n_r, n_p + 1, device=batch_xy.device)
         want_w = return_weights or self.hier_sampling
+        rb_face = rb_eyes = rb_fine = None
+        if self.include_vd:
+            vd = view_direction_embedding(batch_xy, batch_Rmats, batch_inv_inmats)
+            rb_face = view_direction_ray_bias(vd, self.fg_CD_predictor_face)
+            rb_eyes = view_direction_ray_bias(vd, self.fg_CD_predictor_eyes)
+            if self.hier_sampling:
+                rb_fine = view_direction_ray_bias(vd, self.fine_fg_CD_predictor)
         out = R_.render_two_stream(
             batch_xy, batch_Rmats, batch_Tvecs, batch_inv_inmats, shape_code, gaze_code, appea_code,
             self.fg_CD_predictor_face.param_list(), self.fg_CD_predictor_eyes.param_list(),
             n_samples=n_p, world_z1=self.world_z1, world_z2=self.world_z2, t_rand=t_rand,
             return_weights=want_w, hidden=self.hidden, feat_nc=self.featmap_nc, precision=self.precision,
-            ws_budget_bytes=self.ws_budget_bytes, weight_cache=self._wcache)
+            ws_budget_bytes=self.ws_budget_bytes, weight_cache=self._wcache,
+            vd_dims=self.vd_dims, ray_bias_face=rb_face, ray_bias_eyes=rb_eyes)
         if self.hier_sampling:
             zv = R_.sample_zvals(batch_xy, batch_Rmats.detach(), batch_Tvecs.detach(), batch_inv_inmats,
                                  n_samples=n_p, world_z1=self.world_z1, world_z2=self.world_z2, t_rand=t_rand)
@@ -112,7 +151,8 @@ class HotPathRenderer(nn.Module):
                 n_samples=n_p + self.num_sample_fine, world_z1=self.world_z1, world_z2=self.world_z2,
                 z_edges=edges, edges_follow_T=True,       # FineSample detaches only the weights (model_utils.py:418)
                 hidden=self.hidden, feat_nc=self.featmap_nc, precision=self.precision,
-                ws_budget_bytes=self.ws_budget_bytes, weight_cache=self._wcache_fine)
+                ws_budget_bytes=self.ws_budget_bytes, weight_cache=self._wcache_fine,
+                vd_dims=self.vd_dims, ray_bias_face=rb_fine)
             out["feat_fine"], out["bg_alpha_fine"] = fine["feat_face"], fine["bg_alpha_face"]
             out["fine_edges"] = edges
         return out

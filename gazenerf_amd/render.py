@@ -72,19 +72,19 @@ def _weights_struct(plist: Sequence[torch.Tensor], cls=_lib.GnrWeights):
     return w
 
 
-def _expected_param_shapes(hidden, vp, appea, feat_nc):
+def _expected_param_shapes(hidden, vp, appea, feat_nc, vd=0):
     shapes = [(hidden, vp), (hidden,)]
     for i in range(1, 8):
         shapes += [(hidden, hidden + vp if i == 5 else hidden), (hidden,)]
     shapes += [(1, hidden), (1,)]
-    shapes += [(hidden, hidden), (hidden,), (hidden // 2, hidden + appea), (hidden // 2,),
+    shapes += [(hidden, hidden), (hidden,), (hidden // 2, hidden + vd + appea), (hidden // 2,),
                (feat_nc, hidden // 2), (feat_nc,)]
     return shapes
 
 
-def _prep_params(plist, hidden, vp, appea, feat_nc, tag):
+def _prep_params(plist, hidden, vp, appea, feat_nc, tag, vd=0):
     out = []
-    for name, t, shp in zip(PARAM_ORDER, plist, _expected_param_shapes(hidden, vp, appea, feat_nc)):
+    for name, t, shp in zip(PARAM_ORDER, plist, _expected_param_shapes(hidden, vp, appea, feat_nc, vd)):
         _check_tensor("%s.%s" % (tag, name), t)
         if t.dim() == 4:                       # Conv2d [out,in,1,1] == row-major [out,in]
             if t.shape[2:] != (1, 1):
@@ -100,7 +100,7 @@ class _Problem:
     """Validated, contiguous inputs + the ctypes GnrProblem that points at them."""
 
     def __init__(self, xy, R, T, Kinv, shape_code, gaze, appea_code, n_samples, world_z1, world_z2,
-                 t_rand, z_edges, hidden, feat_nc, edges_follow_T=False):
+                 t_rand, z_edges, hidden, feat_nc, edges_follow_T=False, vd_dims=0, ray_bias=(None, None)):
         _check_tensor("batch_xy", xy)
         if xy.dim() != 3 or xy.shape[1] != 2:
             raise ValueError("batch_xy must be [B,2,N_r], got %s" % (tuple(xy.shape),))
@@ -130,6 +130,17 @@ class _Problem:
         p.t_rand = t_rand.data_ptr() if t_rand is not None else None
         p.z_edges = z_edges.data_ptr() if z_edges is not None else None
         p.edges_follow_T = 1 if (edges_follow_T and z_edges is not None) else 0
+        # view-direction option: vd_dims columns of RGB_layer_1.weight are skipped by the kernels, their contribution
+        # arrives as a per-ray bias [B, N_r, hidden/2] per weight set (include/gnr.h)
+        p.vd_dims = int(vd_dims)
+        self.ray_bias = []
+        for s, rb in enumerate(ray_bias):
+            if rb is not None:
+                _check_tensor("ray_bias", rb, (B, n_r, int(hidden) // 2))
+                rb = rb.contiguous()
+                p.ray_bias[s] = rb.data_ptr()
+            self.ray_bias.append(rb)
+        self.uses_vd = p.vd_dims != 0 or any(rb is not None for rb in self.ray_bias)
         self.c = p
         self.B, self.n_r, self.n_p = B, n_r, int(n_samples)
         self.device = xy.device
@@ -201,11 +212,13 @@ def _run_forward(prob: _Problem, streams, save: bool, want_depth: bool, want_wei
         if nb == 0:
             _lib.check(1, _lib.load())
         shape_key = (bool(bf16x3), len(streams), c.batch, c.n_rays, c.n_samples, c.hidden, c.feat_nc, c.shape_dims,
-                     c.gaze_dims, c.appea_dims, int(nb), prob.device)
+                     c.gaze_dims, c.appea_dims, c.vd_dims, int(nb), prob.device)
         cws, packed = cache.lookup(nb, shape_key, cache_params)
         # the parameters the kernels read must be the cached tensors themselves, not contiguous copies of them
         packed = packed and all(a.data_ptr() == b.data_ptr() for a, b in zip(cache_params, [t for st in streams for t in st]))
     prob.c.weights_packed = 1 if packed else 0
+    if prob.uses_vd:
+        ext = None                     # the view-direction option goes through the ctypes binding of the same C ABI
     if ext is not None:                # C++ binding: device guard, current stream, allocation and checks in C++
         t = prob.tensors
         flat = _ext_call(ext.render_fwd, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], streams[0],
@@ -255,15 +268,15 @@ def _run_forward(prob: _Problem, streams, save: bool, want_depth: bool, want_wei
 
 def _run_backward(prob: _Problem, streams, gout, saved_ws, bf16x3: bool):
     """One gnr_bwd call.  ``gout``: per stream (d feat [B,C,N_r] | None, d bg_alpha [B,1,N_r] | None), contiguous
-    fp32.  Returns ([gR, gT, gshape, ggaze, gappea], [[24 parameter gradients] per stream])."""
-    ext = _torch_ext.active()
+    fp32.  Returns ([gR, gT, gshape, ggaze, gappea], [[24 parameter gradients] per stream], [d ray_bias per stream])."""
+    ext = None if prob.uses_vd else _torch_ext.active()
     if ext is not None:
         t = prob.tensors
         flat = _ext_call(ext.render_bwd, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], streams[0],
                               streams[1] if len(streams) > 1 else [], [g[0] for g in gout], [g[1] for g in gout], saved_ws,
                               prob.n_p, prob.c.world_z1, prob.c.world_z2, prob.c.hidden, prob.c.feat_nc, bool(bf16x3),
                               bool(prob.c.edges_follow_T))
-        return list(flat[:5]), [list(flat[5 + 24 * s:5 + 24 * (s + 1)]) for s in range(len(streams))]
+        return list(flat[:5]), [list(flat[5 + 24 * s:5 + 24 * (s + 1)]) for s in range(len(streams))], [None, None]
     lib = _lib.load()
     dev = prob.device
     n_streams = len(streams)
@@ -277,6 +290,11 @@ def _run_backward(prob: _Problem, streams, gout, saved_ws, bf16x3: bool):
            torch.empty(B, prob.c.appea_dims, device=dev)]
     din = _lib.GnrInputGrads()
     din.R, din.T, din.shape_code, din.gaze, din.appea_code = (t.data_ptr() for t in gin)
+    grb = [None, None]
+    for s, rb in enumerate(prob.ray_bias[:n_streams]):
+        if rb is not None:
+            grb[s] = torch.empty_like(rb)
+            din.ray_bias[s] = grb[s].data_ptr()
     gparams = [[torch.empty_like(t) for t in streams[s]] for s in range(n_streams)]
     dw = [_weights_struct(g, _lib.GnrWeightGrads) for g in gparams]
     w = [_weights_struct(st) for st in streams]
@@ -290,7 +308,7 @@ def _run_backward(prob: _Problem, streams, gout, saved_ws, bf16x3: bool):
                  C.c_void_p(saved_ws.data_ptr()), saved_ws.numel(),
                  C.c_void_p(scratch.data_ptr()), scratch.numel(), _stream_ptr(dev))
         _lib.check(rc, lib)
-    return gin, gparams
+    return gin, gparams, grb
 
 
 # Saved activations cost ~31.5 KB per sample (both streams): 16.5 GB at cfg3 (2 x 4096 rays x 64), 540 GB for one
@@ -330,13 +348,14 @@ class _RenderFn(torch.autograd.Function):
     graph), including the activation workspace of the un-tiled mode."""
 
     @staticmethod
-    def forward(ctx, cfg, R, T, shape_code, gaze, appea_code, *flat_params):
+    def forward(ctx, cfg, R, T, shape_code, gaze, appea_code, rb0, rb1, *flat_params):
         n_streams = cfg["n_streams"]
+        vd = cfg.get("vd_dims", 0)
         prob = _Problem(cfg["xy"], R, T, cfg["Kinv"], shape_code, gaze, appea_code, cfg["n_samples"],
                         cfg["world_z1"], cfg["world_z2"], cfg["t_rand"], cfg["z_edges"],
-                        cfg["hidden"], cfg["feat_nc"], cfg.get("edges_follow_T", False))
+                        cfg["hidden"], cfg["feat_nc"], cfg.get("edges_follow_T", False), vd, (rb0, rb1))
         streams = [_prep_params(flat_params[24 * s:24 * (s + 1)], cfg["hidden"], prob.vp,
-                                prob.c.appea_dims, cfg["feat_nc"], "stream%d" % s)
+                                prob.c.appea_dims, cfg["feat_nc"], "stream%d" % s, vd)
                    for s in range(n_streams)]
         need_grad = any(ctx.needs_input_grad[1:])
         bf16x3 = cfg.get("precision", "fp32") == "bf16x3"
@@ -349,7 +368,7 @@ class _RenderFn(torch.autograd.Function):
         ctx.param_shapes = [tuple(t.shape) for t in flat_params]
         if need_grad:
             ctx.save_for_backward(R, T, shape_code, gaze, appea_code, *flat_params, cfg["xy"], cfg["Kinv"],
-                                  cfg["t_rand"], cfg["z_edges"], ws if save else None)
+                                  cfg["t_rand"], cfg["z_edges"], ws if save else None, rb0, rb1)
         outs = []
         nondiff = []
         for feat, bga, dep, wts in res:
@@ -371,14 +390,15 @@ class _RenderFn(torch.autograd.Function):
         n_streams = cfg["n_streams"]
         R, T, shape_code, gaze, appea_code = saved[:5]
         flat_params = saved[5:5 + 24 * n_streams]
-        xy, Kinv, t_rand, z_edges, ws = saved[5 + 24 * n_streams:]
+        xy, Kinv, t_rand, z_edges, ws, rb0, rb1 = saved[5 + 24 * n_streams:]
         bf16x3 = cfg.get("precision", "fp32") == "bf16x3"
+        vd = cfg.get("vd_dims", 0)
 
         def problem(sl=None):
             cut = (lambda t, dim: None if t is None else t[(slice(None),) * dim + (sl,)].contiguous()) if sl else (lambda t, dim: t)
             return _Problem(cut(xy, 2), R, T, Kinv, shape_code, gaze, appea_code, cfg["n_samples"], cfg["world_z1"],
                             cfg["world_z2"], cut(t_rand, 1), cut(z_edges, 1), cfg["hidden"], cfg["feat_nc"],
-                            cfg.get("edges_follow_T", False))
+                            cfg.get("edges_follow_T", False), vd, (cut(rb0, 1), cut(rb1, 1)))
 
         streams = None
         gout_full = []
@@ -391,21 +411,25 @@ class _RenderFn(torch.autograd.Function):
         if ctx.tile is None:
             prob = problem()
             streams = [_prep_params(flat_params[24 * s:24 * (s + 1)], cfg["hidden"], prob.vp, prob.c.appea_dims,
-                                    cfg["feat_nc"], "stream%d" % s) for s in range(n_streams)]
-            gin, gparams = _run_backward(prob, streams, gout_full, ws, bf16x3)
+                                    cfg["feat_nc"], "stream%d" % s, vd) for s in range(n_streams)]
+            gin, gparams, grb = _run_backward(prob, streams, gout_full, ws, bf16x3)
         else:
             gin = gparams = None
+            grb = [None if rb is None else torch.empty_like(rb) for rb in (rb0, rb1)]
             n_r = xy.shape[2]
             for r0 in range(0, n_r, ctx.tile):
                 sl = slice(r0, min(n_r, r0 + ctx.tile))
                 prob = problem(sl)
                 if streams is None:
                     streams = [_prep_params(flat_params[24 * s:24 * (s + 1)], cfg["hidden"], prob.vp,
-                                            prob.c.appea_dims, cfg["feat_nc"], "stream%d" % s) for s in range(n_streams)]
+                                            prob.c.appea_dims, cfg["feat_nc"], "stream%d" % s, vd) for s in range(n_streams)]
                 _, tws = _run_forward(prob, streams, True, False, False, bf16x3)        # recompute with save
                 gout = [tuple(None if g is None else g[:, :, sl].contiguous() for g in pair) for pair in gout_full]
-                tin, tpar = _run_backward(prob, streams, gout, tws, bf16x3)
+                tin, tpar, trb = _run_backward(prob, streams, gout, tws, bf16x3)
                 del tws
+                for full, part in zip(grb, trb):       # a ray's bias gradient belongs to exactly one tile
+                    if full is not None:
+                        full[:, sl] = part
                 if gin is None:
                     gin, gparams = tin, tpar
                 else:                                   # fixed tile order: deterministic accumulation
@@ -416,7 +440,7 @@ class _RenderFn(torch.autograd.Function):
         for s in range(n_streams):
             for g, shp in zip(gparams[s], ctx.param_shapes[24 * s:24 * (s + 1)]):
                 flat.append(g.reshape(shp))
-        return (None, *gin, *flat)
+        return (None, *gin, grb[0], grb[1], *flat)
 
 
 def render_two_stream(batch_xy, R, T, Kinv, shape_code, gaze, appea_code, face_params, eyes_params=None,
@@ -425,7 +449,9 @@ def render_two_stream(batch_xy, R, T, Kinv, shape_code, gaze, appea_code, face_p
                       return_depth: bool = False, return_weights: bool = False,
                       hidden: int = 384, feat_nc: int = 258, precision: str = "fp32",
                       edges_follow_T: bool = False, ray_tile: Optional[int] = None,
-                      ws_budget_bytes: Optional[int] = None, weight_cache: Optional["PackedWeightCache"] = None):
+                      ws_budget_bytes: Optional[int] = None, weight_cache: Optional["PackedWeightCache"] = None,
+                      vd_dims: int = 0, ray_bias_face: Optional[torch.Tensor] = None,
+                      ray_bias_eyes: Optional[torch.Tensor] = None):
     """Run the hot path.  Returns a dict with feat_face [B,feat_nc,N_r], bg_alpha_face [B,1,N_r]
     (and *_eyes when ``eyes_params`` is given; depth_* / w_* [B,1,N_r,N_p] on request).
 
@@ -447,6 +473,11 @@ def render_two_stream(batch_xy, R, T, Kinv, shape_code, gaze, appea_code, face_p
 
     ``weight_cache`` (a ``PackedWeightCache`` the caller keeps): inference calls run in its workspace and skip the
     weight re-layout while the parameters are unchanged.
+
+    ``vd_dims`` / ``ray_bias_*``: the reference's view-direction option (``include_vd``, models/gaze_nerf.py:70-80,
+    140).  ``RGB_layer_1.weight`` is then [H/2, H + vd_dims + appea]; the kernels skip the vd_dims columns and add
+    ``ray_bias_* [B, N_r, H/2]`` (differentiable) to that layer's bias for every sample of a ray -- the direction is
+    constant along a ray, so the caller folds ``W[:, H:H+vd_dims] @ embed(dir)`` per ray (``HotPathRenderer`` does).
     """
     if precision not in ("fp32", "bf16x3"):
         raise ValueError("precision must be 'fp32' or 'bf16x3'")
@@ -457,9 +488,9 @@ def render_two_stream(batch_xy, R, T, Kinv, shape_code, gaze, appea_code, face_p
                t_rand=t_rand, z_edges=z_edges, hidden=hidden, feat_nc=feat_nc, n_streams=len(streams),
                want_depth=return_depth, want_weights=return_weights, precision=precision,
                edges_follow_T=bool(edges_follow_T), ray_tile=ray_tile, ws_budget_bytes=ws_budget_bytes,
-               weight_cache=weight_cache)
+               weight_cache=weight_cache, vd_dims=int(vd_dims))
     flat = [t for st in streams for t in st]
-    outs = _RenderFn.apply(cfg, R, T, shape_code, gaze, appea_code, *flat)
+    outs = _RenderFn.apply(cfg, R, T, shape_code, gaze, appea_code, ray_bias_face, ray_bias_eyes, *flat)
     res: Dict[str, torch.Tensor] = {}
     it = iter(outs)
     for tag in ("face", "eyes")[:len(streams)]:

@@ -79,6 +79,14 @@ typedef struct GnrProblem {
                                  re-layout kernels (2 x 5.4 MB written per call: 1-3 % of a 64 x 64-ray inference).
                                  The caller owns the invalidation (gazenerf_amd.render.PackedWeightCache keys it on
                                  tensor identity + torch's version counter).  ABI 2.             */
+    int32_t vd_dims;          /* columns of RGB_layer_1.weight between the hidden and the appearance columns: 0, or
+                                 27 with the reference's view-direction encoder (`include_vd`, models/gaze_nerf.py:
+                                 70-80, 140: the layer's input is cat([h, vd_embedding(27), appea_code])).  The kernels
+                                 skip those columns; their contribution arrives through ray_bias.  ABI 2.   */
+    const float* ray_bias[2]; /* per weight set: NULL, or [B,N_r,hidden/2] added to the bias of RGB_layer_1 for every
+                                 sample of the ray.  The view direction is constant along a ray, so
+                                 W[:, H:H+vd_dims] . vd_embedding(ray) is a per-ray bias the caller computes (27 MACs
+                                 per ray and channel; gazenerf_amd.module does it in torch, autograd included).  ABI 2. */
 } GnrProblem;
 
 /* Parameters of one MLPforNeRF (models/mlp_nerf.py:13-93).  weight = Conv2d [out,in,1,1] memory
@@ -127,6 +135,7 @@ typedef struct GnrInputGrads {
     float* shape_code;   /* [B,shape_dims] */
     float* gaze;         /* [B,gaze_dims]  */
     float* appea_code;   /* [B,appea_dims] */
+    float* ray_bias[2];  /* [B,N_r,hidden/2] per weight set: d loss / d GnrProblem.ray_bias (NULL == not wanted) */
 } GnrInputGrads;
 
 enum {

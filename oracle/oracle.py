@@ -160,28 +160,34 @@ def fine_sample(weights, sample_dict, n_fine, u=None):
 
 
 # ------------------------------------------------------------------ A1..A5 chained
-def _stream(params, pts_embed, shape_ext, appea, dists, zvals):
-    """models/gaze_nerf.py:136-162 for one stream."""
+def _stream(params, pts_embed, shape_ext, appea, dists, zvals, vd_embed=None):
+    """models/gaze_nerf.py:136-162 for one stream.  ``vd_embed`` [B,27,N_r,N_p]: the view-direction embedding of the
+    ``include_vd`` option, concatenated IN FRONT of the appearance code (gaze_nerf.py:140-143)."""
     B, _, n_r, n_p = pts_embed.shape
     vp_in = torch.cat([pts_embed, shape_ext.view(B, -1, 1, 1).expand(-1, -1, n_r, n_p)], dim=1)
     vd_in = appea.view(B, -1, 1, 1).expand(-1, -1, n_r, n_p)
+    if vd_embed is not None:
+        vd_in = torch.cat([vd_embed, vd_in], dim=1)
     feat, sigma = mlp_forward(params, vp_in, vd_in)
     return calc_ray_color(feat, sigma, dists, zvals)
 
 
 def render_two_stream(xy, R, T, Kinv, shape_code, gaze, appea_code, face_params, eyes_params,
-                      n_samples, world_z1=2.5, world_z2=-3.5, t_rand=None, z_edges=None):
+                      n_samples, world_z1=2.5, world_z2=-3.5, t_rand=None, z_edges=None, include_vd=False):
     """models/gaze_nerf.py:231-262 + 136-162: the whole hot path for both streams.
 
     Returns a dict: feat_face/feat_eyes [B,C_f,N_r], bg_alpha_* [B,1,N_r], depth_* [B,1,N_r],
     w_face/w_eyes [B,1,N_r,N_p] and the sample dict under "samples".
+    ``include_vd``: the sample directions go through the 4-frequency Embedder (gaze_nerf.py:30-31, 71-80, 240-243:
+    27 channels) into RGB_layer_1 of both MLPs.
     """
     sd = gen_sample_points(xy, R, T, Kinv, n_samples, world_z1, world_z2, t_rand, z_edges)
     emb = embed(sd["pts"])
+    vd = embed(sd["dirs"], n_freqs=4) if include_vd else None                 # gaze_nerf.py:240-241
     shape_ext = torch.cat([shape_code, gaze], dim=1)                          # gaze_nerf.py:248
     out = {"samples": sd}
     for tag, params in (("face", face_params), ("eyes", eyes_params)):
-        f, a, d, w = _stream(params, emb, shape_ext, appea_code, sd["z_dists"], sd["zvals"])
+        f, a, d, w = _stream(params, emb, shape_ext, appea_code, sd["z_dists"], sd["zvals"], vd)
         out["feat_" + tag], out["bg_alpha_" + tag] = f, a
         out["depth_" + tag], out["w_" + tag] = d, w
     return out

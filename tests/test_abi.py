@@ -27,11 +27,11 @@ def test_binding_matches_header(lib_built):
     assert lib.gnr_abi_version() == _lib.ABI_VERSION
     assert sorted(_lib.EXPORTS) == _declared_symbols()
     # struct sizes: the library reports its own sizeof() and the binding checked them at load time; spelled out once
-    # more here: 8 ints + 2 floats + 9 pointers + 1 int (+ pad), 24 pointers, 8 pointers
+    # more here: 8 ints + 2 floats + 9 pointers + 3 ints (+ pad) + 2 pointers, 24 pointers, 8 pointers
     for which, cls in enumerate(_lib.STRUCTS):
         assert lib.gnr_sizeof(which) == ctypes.sizeof(cls), cls.__name__
     assert lib.gnr_sizeof(99) == 0
-    assert ctypes.sizeof(_lib.GnrProblem) == 8 * 4 + 2 * 4 + 9 * 8 + 8
+    assert ctypes.sizeof(_lib.GnrProblem) == 8 * 4 + 2 * 4 + 9 * 8 + 16 + 2 * 8
     assert ctypes.sizeof(_lib.GnrWeights) == 24 * 8
     assert ctypes.sizeof(_lib.GnrOutputs) == 8 * 8
     assert ctypes.sizeof(_lib.GnrMergeProblem) == 16 + 6 * 8        # 3 ints (+pad) + 6 pointers

@@ -145,3 +145,20 @@ def test_merge_fixture():
     assert _maxabs(mf, g["out_merge_face"]) <= 1e-6
     assert _maxabs(ep, g["out_eyes_planes"]) <= 1e-6
     assert _maxabs(m, g["out_merge"]) <= 1e-6
+
+
+def test_view_direction_fixture():
+    """g11_vd: the reference with include_vd=True (oracle/gen_golden_vd.py); the oracle's restatement replays it."""
+    g = load_golden("g11_vd")
+    p = golden_problem(g)
+    ds, seed, vd_ch = float(g["density_scale"]), int(g["weight_seed"]), int(g["vd_dims"]) + synth.APPEA_DIMS
+    face = synth.hash_mlp_params("face", seed=seed, vd_ch=vd_ch, density_scale=ds)
+    eyes = synth.hash_mlp_params("eyes", seed=seed, vd_ch=vd_ch, density_scale=ds)
+    R = p["R"].clone().requires_grad_(True)
+    out = O.render_two_stream(p["xy"], R, p["T"], p["Kinv"], p["shape_code"], p["gaze"], p["appea_code"], face, eyes,
+                              int(g["n_samples"]), t_rand=g["t_rand"], include_vd=True)
+    for tag in ("face", "eyes"):
+        assert _maxabs(out["feat_" + tag], g["out_feat_" + tag]) <= 2e-5
+        assert _maxabs(out["bg_alpha_" + tag], g["out_bg_alpha_" + tag]) <= 2e-5
+    O.synthetic_loss(out).backward()
+    assert _maxabs(R.grad, g["grad_R"]) <= 1e-4 * max(1.0, float(g["grad_R"].abs().max()))

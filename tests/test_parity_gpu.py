@@ -936,3 +936,68 @@ def test_narrow_network_vs_oracle_live(hidden, precision):
     with pytest.raises(Exception, match="hidden"):
         big = synth.hash_mlp_params("face", seed=9, hidden=386, density_scale=8.0)
         _grads_hip(p, big, big, 40, t_rand, dev, precision, hidden=386)
+
+
+def _vd_weights(g):
+    ds, seed = float(g["density_scale"]), int(g["weight_seed"])
+    vd_ch = int(g["vd_dims"]) + synth.APPEA_DIMS
+    return (synth.hash_mlp_params("face", seed=seed, vd_ch=vd_ch, density_scale=ds),
+            synth.hash_mlp_params("eyes", seed=seed, vd_ch=vd_ch, density_scale=ds))
+
+
+@pytest.mark.parametrize("tiled", [False, True])
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_view_direction_option_vs_reference_fixture(precision, tiled):
+    """include_vd=True (models/gaze_nerf.py:70-80, 140-143, 240-243): g11_vd holds outputs and A8-loss gradients of the
+    reference's own modules with the 27-channel direction embedding in front of the appearance code.  The HIP path skips
+    those weight columns and takes their per-ray fold as ``ray_bias``; the fold (plain torch) carries the gradient into the
+    columns and the rotation.  tiled: the in-op ray tiling slices the per-ray bias and its gradient."""
+    from gazenerf_amd.module import VD_DIMS, view_direction_embedding
+    dev = _dev()
+    g = load_golden("g11_vd")
+    assert int(g["vd_dims"]) == VD_DIMS
+    face, eyes = _vd_weights(g)
+    pd = _to(golden_problem(g), dev)
+    leaves = {k: pd[k].clone().requires_grad_(True) for k in ("R", "T", "shape_code", "gaze", "appea_code")}
+    fp = {k: v.to(dev).clone().requires_grad_(True) for k, v in face.items()}
+    ep = {k: v.to(dev).clone().requires_grad_(True) for k, v in eyes.items()}
+    vd = view_direction_embedding(pd["xy"], leaves["R"], pd["Kinv"])
+    fold = lambda w: torch.einsum("ok,bkr->bro", w["RGB_layer_1.weight"].reshape(192, -1)[:, 384:384 + VD_DIMS], vd).contiguous()
+    out = render.render_two_stream(pd["xy"], leaves["R"], leaves["T"], pd["Kinv"], leaves["shape_code"], leaves["gaze"],
+                                   leaves["appea_code"], fp, ep, n_samples=int(g["n_samples"]), t_rand=g["t_rand"].to(dev),
+                                   precision=precision, vd_dims=VD_DIMS, ray_bias_face=fold(fp), ray_bias_eyes=fold(ep),
+                                   ray_tile=8 if tiled else None)
+    for tag in ("face", "eyes"):
+        assert _maxabs(out["feat_" + tag], g["out_feat_" + tag]) <= TOL
+        assert _maxabs(out["bg_alpha_" + tag], g["out_bg_alpha_" + tag]) <= TOL
+    (sum((out["feat_" + t] ** 2).mean() + out["bg_alpha_" + t].mean() for t in ("face", "eyes"))).backward()
+    for k, v in leaves.items():
+        _check_grad("d" + k, v.grad, g["grad_" + k])
+    for tag, params in (("face", fp), ("eyes", ep)):
+        for name, v in params.items():
+            ref = g["gradw_%s.%s" % (tag, name)]
+            got = v.grad
+            if name == "RGB_layer_1.weight":
+                _check_grad(tag + " view-direction columns", got.reshape(192, -1)[:, 384:384 + VD_DIMS], g["gradw_vdcols_" + tag])
+            if got.numel() > 4096:
+                got = got.reshape(got.shape[0], -1)[::16]
+            _check_grad("%s.%s" % (tag, name), got.reshape(ref.shape), ref)
+
+
+def test_module_with_view_direction_matches_the_oracle():
+    """HotPathRenderer(include_vd=True): parameter shapes of the reference (RGB_layer_1 [192, 384+27+127, 1, 1]) and the
+    oracle's include_vd forward on the module's own weights."""
+    from gazenerf_amd import HotPathRenderer
+    dev = _dev()
+    net = HotPathRenderer(include_vd=True).to(dev)
+    assert tuple(net.fg_CD_predictor_face.RGB_layer_1.weight.shape) == (192, 384 + 27 + 127, 1, 1)
+    p = synth.synth_problem(64, batch=2, camera="2", seed=4, ray_subset=torch.arange(40) * 97 % 4096)
+    pd = _to(p, dev)
+    with torch.no_grad():
+        got = net(pd["xy"], pd["R"], pd["T"], pd["Kinv"], pd["shape_code"], pd["appea_code"], pd["gaze"])
+        cpu = lambda m: {k: v.detach().cpu() for k, v in m.named_parameters()}
+        ref = O.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"], p["appea_code"],
+                                  cpu(net.fg_CD_predictor_face), cpu(net.fg_CD_predictor_eyes), 64, include_vd=True)
+    for tag in ("face", "eyes"):
+        assert _maxabs(got["feat_" + tag], ref["feat_" + tag]) <= TOL
+        assert _maxabs(got["bg_alpha_" + tag], ref["bg_alpha_" + tag]) <= TOL
