@@ -39,7 +39,8 @@ struct Problem {
 Problem make_problem(const Tensor& xy, const Tensor& R, const Tensor& T, const Tensor& Kinv, const Tensor& shape_code,
                      const Tensor& gaze, const Tensor& appea_code, const OptTensor& t_rand, const OptTensor& z_edges,
                      int64_t n_samples, double world_z1, double world_z2, int64_t hidden, int64_t feat_nc,
-                     bool edges_follow_T) {
+                     bool edges_follow_T, int64_t vd_dims = 0, const OptTensor& ray_bias0 = c10::nullopt,
+                     const OptTensor& ray_bias1 = c10::nullopt) {
     Problem p;
     TORCH_CHECK(xy.defined() && xy.is_cuda(), "batch_xy must live on a CUDA/ROCm device (the render op has no CPU path)");
     p.dev = xy.device();
@@ -70,6 +71,15 @@ Problem make_problem(const Tensor& xy, const Tensor& R, const Tensor& T, const T
     c.t_rand = t_rand ? keep(*t_rand) : nullptr;
     c.z_edges = z_edges ? keep(*z_edges) : nullptr;
     c.edges_follow_T = (edges_follow_T && z_edges) ? 1 : 0;
+    // view-direction option (include/gnr.h): skipped weight columns + per-ray bias of RGB_layer_1 per weight set
+    TORCH_CHECK(vd_dims >= 0, "vd_dims must be >= 0");
+    c.vd_dims = (int32_t)vd_dims;
+    const OptTensor* rb[2] = {&ray_bias0, &ray_bias1};
+    for (int s = 0; s < 2; ++s)
+        if (*rb[s]) {
+            want(**rb[s], "ray_bias", {p.B, p.n_r, hidden / 2});
+            c.ray_bias[s] = keep(**rb[s]);
+        }
     return p;
 }
 
@@ -78,7 +88,7 @@ Problem make_problem(const Tensor& xy, const Tensor& R, const Tensor& T, const T
 void fill_weights(const std::vector<Tensor>& params, const Problem& p, int64_t hidden, int64_t feat_nc, const char* tag,
                   std::vector<Tensor>& keep, GnrWeights* w) {
     TORCH_CHECK(params.size() == 24, tag, ": expected 24 parameter tensors, got ", params.size());
-    const int64_t vp = 63 + p.c.shape_dims + p.c.gaze_dims, ap = p.c.appea_dims;
+    const int64_t vp = 63 + p.c.shape_dims + p.c.gaze_dims, ap = p.c.vd_dims + p.c.appea_dims;
     auto mat = [&](int i, int64_t rows, int64_t cols) {
         Tensor t = params[i];
         check_f32(t, tag, p.dev);
@@ -120,9 +130,10 @@ std::vector<Tensor> render_fwd(const Tensor& xy, const Tensor& R, const Tensor& 
                                const Tensor& gaze, const Tensor& appea_code, const OptTensor& t_rand, const OptTensor& z_edges,
                                const std::vector<Tensor>& face, const std::vector<Tensor>& eyes, int64_t n_samples, double world_z1,
                                double world_z2, int64_t hidden, int64_t feat_nc, bool save, bool want_depth, bool want_weights,
-                               bool bf16x3, bool edges_follow_T, const OptTensor& ws_in, bool weights_packed) {
+                               bool bf16x3, bool edges_follow_T, const OptTensor& ws_in, bool weights_packed, int64_t vd_dims,
+                               const OptTensor& ray_bias0, const OptTensor& ray_bias1) {
     Problem p = make_problem(xy, R, T, Kinv, shape_code, gaze, appea_code, t_rand, z_edges, n_samples, world_z1, world_z2, hidden,
-                             feat_nc, edges_follow_T);
+                             feat_nc, edges_follow_T, vd_dims, ray_bias0, ray_bias1);
     const c10::DeviceGuard guard(p.dev);
     const int n_streams = eyes.empty() ? 1 : 2;
     const size_t nbytes = gnr_workspace_bytes(&p.c, n_streams, save ? GNR_WS_FWD_SAVE : GNR_WS_FWD);
@@ -171,9 +182,9 @@ std::vector<Tensor> render_bwd(const Tensor& xy, const Tensor& R, const Tensor& 
                                const std::vector<Tensor>& face, const std::vector<Tensor>& eyes,
                                const std::vector<OptTensor>& d_feat, const std::vector<OptTensor>& d_bg_alpha, const Tensor& saved_ws,
                                int64_t n_samples, double world_z1, double world_z2, int64_t hidden, int64_t feat_nc, bool bf16x3,
-                               bool edges_follow_T) {
+                               bool edges_follow_T, int64_t vd_dims, const OptTensor& ray_bias0, const OptTensor& ray_bias1) {
     Problem p = make_problem(xy, R, T, Kinv, shape_code, gaze, appea_code, t_rand, z_edges, n_samples, world_z1, world_z2, hidden,
-                             feat_nc, edges_follow_T);
+                             feat_nc, edges_follow_T, vd_dims, ray_bias0, ray_bias1);
     const c10::DeviceGuard guard(p.dev);
     const int n_streams = eyes.empty() ? 1 : 2;
     TORCH_CHECK((int)d_feat.size() == n_streams && (int)d_bg_alpha.size() == n_streams, "one (d_feat, d_bg_alpha) pair per weight set");
@@ -217,6 +228,13 @@ std::vector<Tensor> render_bwd(const Tensor& xy, const Tensor& R, const Tensor& 
         dw[s].density_w = ptr[16]; dw[s].density_b = ptr[17];
         for (int l = 0; l < 3; ++l) { dw[s].rgb_w[l] = ptr[18 + 2 * l]; dw[s].rgb_b[l] = ptr[19 + 2 * l]; }
     }
+    // d ray_bias per weight set, appended after the parameter gradients (an undefined tensor == None where absent)
+    Tensor grb[2];
+    for (int s = 0; s < n_streams; ++s)
+        if (p.c.ray_bias[s]) {
+            grb[s] = at::empty({p.B, p.n_r, hidden / 2}, opt);
+            din.ray_bias[s] = grb[s].data_ptr<float>();
+        }
     const size_t sbytes = gnr_workspace_bytes(&p.c, n_streams, GNR_WS_BWD);
     TORCH_CHECK(sbytes != 0, gnr_last_error());
     Tensor scratch = alloc_ws(sbytes, p.dev);
@@ -224,6 +242,8 @@ std::vector<Tensor> render_bwd(const Tensor& xy, const Tensor& R, const Tensor& 
     auto fn = bf16x3 ? gnr_bwd_bf16x3 : gnr_bwd;
     check_rc(fn(&p.c, &w[0], n_streams > 1 ? &w[1] : nullptr, &dout, &din, &dw[0], n_streams > 1 ? &dw[1] : nullptr,
                 saved_ws.data_ptr(), (size_t)saved_ws.numel(), scratch.data_ptr(), (size_t)scratch.numel(), stream));
+    res.push_back(grb[0]);
+    res.push_back(grb[1]);
     return res;
 }
 

@@ -217,14 +217,13 @@ def _run_forward(prob: _Problem, streams, save: bool, want_depth: bool, want_wei
         # the parameters the kernels read must be the cached tensors themselves, not contiguous copies of them
         packed = packed and all(a.data_ptr() == b.data_ptr() for a, b in zip(cache_params, [t for st in streams for t in st]))
     prob.c.weights_packed = 1 if packed else 0
-    if prob.uses_vd:
-        ext = None                     # the view-direction option goes through the ctypes binding of the same C ABI
     if ext is not None:                # C++ binding: device guard, current stream, allocation and checks in C++
         t = prob.tensors
         flat = _ext_call(ext.render_fwd, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], streams[0],
                               streams[1] if len(streams) > 1 else [], prob.n_p, prob.c.world_z1, prob.c.world_z2,
                               prob.c.hidden, prob.c.feat_nc, bool(save), bool(want_depth), bool(want_weights), bool(bf16x3),
-                              bool(prob.c.edges_follow_T), cws, bool(packed))
+                              bool(prob.c.edges_follow_T), cws, bool(packed), int(prob.c.vd_dims), prob.ray_bias[0],
+                              prob.ray_bias[1])
         if cws is not None:
             cache.store(shape_key, cache_params)
         per = 2 + int(want_depth) + int(want_weights)
@@ -269,14 +268,15 @@ def _run_forward(prob: _Problem, streams, save: bool, want_depth: bool, want_wei
 def _run_backward(prob: _Problem, streams, gout, saved_ws, bf16x3: bool):
     """One gnr_bwd call.  ``gout``: per stream (d feat [B,C,N_r] | None, d bg_alpha [B,1,N_r] | None), contiguous
     fp32.  Returns ([gR, gT, gshape, ggaze, gappea], [[24 parameter gradients] per stream], [d ray_bias per stream])."""
-    ext = None if prob.uses_vd else _torch_ext.active()
+    ext = _torch_ext.active()
     if ext is not None:
         t = prob.tensors
         flat = _ext_call(ext.render_bwd, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], streams[0],
                               streams[1] if len(streams) > 1 else [], [g[0] for g in gout], [g[1] for g in gout], saved_ws,
                               prob.n_p, prob.c.world_z1, prob.c.world_z2, prob.c.hidden, prob.c.feat_nc, bool(bf16x3),
-                              bool(prob.c.edges_follow_T))
-        return list(flat[:5]), [list(flat[5 + 24 * s:5 + 24 * (s + 1)]) for s in range(len(streams))], [None, None]
+                              bool(prob.c.edges_follow_T), int(prob.c.vd_dims), prob.ray_bias[0], prob.ray_bias[1])
+        return (list(flat[:5]), [list(flat[5 + 24 * s:5 + 24 * (s + 1)]) for s in range(len(streams))],
+                [flat[-2], flat[-1]])
     lib = _lib.load()
     dev = prob.device
     n_streams = len(streams)

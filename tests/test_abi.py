@@ -81,4 +81,4 @@ def test_torch_extension_builds_and_loads(lib_built):
         ext.saved_workspace_bytes(1, 16, 64, 385, 258, 2)
     x = torch.zeros(1, 2, 4)
     with pytest.raises(RuntimeError, match="no CPU path"):
-        ext.render_fwd(x, x, x, x, x, x, x, None, None, [], [], 32, 2.5, -3.5, 384, 258, False, False, False, False, False, None, False)
+        ext.render_fwd(x, x, x, x, x, x, x, None, None, [], [], 32, 2.5, -3.5, 384, 258, False, False, False, False, False, None, False, 0, None, None)

@@ -945,14 +945,16 @@ def _vd_weights(g):
             synth.hash_mlp_params("eyes", seed=seed, vd_ch=vd_ch, density_scale=ds))
 
 
+@pytest.mark.parametrize("binding", ["torch_ext", "ctypes"])
 @pytest.mark.parametrize("tiled", [False, True])
 @pytest.mark.parametrize("precision", PRECISIONS)
-def test_view_direction_option_vs_reference_fixture(precision, tiled):
+def test_view_direction_option_vs_reference_fixture(precision, tiled, binding, monkeypatch):
     """include_vd=True (models/gaze_nerf.py:70-80, 140-143, 240-243): g11_vd holds outputs and A8-loss gradients of the
     reference's own modules with the 27-channel direction embedding in front of the appearance code.  The HIP path skips
     those weight columns and takes their per-ray fold as ``ray_bias``; the fold (plain torch) carries the gradient into the
     columns and the rotation.  tiled: the in-op ray tiling slices the per-ray bias and its gradient."""
     from gazenerf_amd.module import VD_DIMS, view_direction_embedding
+    monkeypatch.setenv("GNR_BINDING", binding)
     dev = _dev()
     g = load_golden("g11_vd")
     assert int(g["vd_dims"]) == VD_DIMS
