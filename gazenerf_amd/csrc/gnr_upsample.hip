@@ -355,7 +355,21 @@ __global__ __launch_bounds__(256) void rgb_conv_kernel(const float* __restrict__
     const long b = idx / P, p = idx - b * P;
     const float* np = net + b * C * P + p;
     float a0 = bias[0], a1 = bias[1], a2 = bias[2];
-    for (int c = 0; c < C; ++c) {
+    // channel order kept (three in-order fmaf chains); the activations of 8 channels are loaded ahead of their FMAs: on
+    // the 64 x 64 input (16 blocks, 258 channels) a load-then-fma chain took 124 us
+    int c = 0;
+    for (; c + 8 <= C; c += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = np[(long)(c + u) * P];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a0 = fmaf(w[c + u], v[u], a0);
+            a1 = fmaf(w[C + c + u], v[u], a1);
+            a2 = fmaf(w[2 * C + c + u], v[u], a2);
+        }
+    }
+    for (; c < C; ++c) {
         const float v = np[(long)c * P];
         a0 = fmaf(w[c], v, a0);
         a1 = fmaf(w[C + c], v, a1);
@@ -379,12 +393,25 @@ __global__ __launch_bounds__(256) void rgb_conv_bwd_data_kernel(const float* __r
     const long b = idx / P, p = idx - b * P;
     const float* gp = drgb + b * 3 * P + p;
     const float g0 = gp[0], g1 = gp[P], g2 = gp[2 * P];
-    for (int c = 0; c < C; ++c) {
-        const long o = b * C * P + (long)c * P + p;
-        float v = w[c] * g0 + w[C + c] * g1 + w[2 * C + c] * g2;
-        if (accumulate) v += dnet[o];
-        if (act) v *= act[o] > 0.0f ? 1.0f : LEAK;
-        dnet[o] = v;
+    // 8 channels per round: their dnet / act loads are issued before the first store (every channel is independent)
+    for (int c0 = 0; c0 < C; c0 += 8) {
+        float dv[8], av[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long o = b * C * P + (long)(c0 + u) * P + p;
+            dv[u] = (accumulate && c0 + u < C) ? dnet[o] : 0.0f;
+            av[u] = (act && c0 + u < C) ? act[o] : 1.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u;
+            if (c < C) {
+                float v = w[c] * g0 + w[C + c] * g1 + w[2 * C + c] * g2;
+                if (accumulate) v += dv[u];
+                if (act) v *= av[u] > 0.0f ? 1.0f : LEAK;
+                dnet[b * C * P + (long)c * P + p] = v;
+            }
+        }
     }
 }
 
