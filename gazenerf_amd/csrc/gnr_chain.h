@@ -12,7 +12,15 @@ namespace gnr {
 // Training dumps are written once and read by a later kernel: nontemporal stores keep them from
 // displacing the weight stream in the XCD's L2 (measured on the bf16x3 training forward: -18 %).
 template <class T>
-__device__ __forceinline__ void dump_store(T* p, T v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void dump_store(T* p, T v) {
+#ifdef GNR_NODUMP_TIMING            // timing experiment only (tools/ablate_fwd3.sh): results are incomplete
+    (void)p; (void)v;
+#elif defined(GNR_TEMPORAL_DUMP_TIMING)
+    *p = v;
+#else
+    __builtin_nontemporal_store(v, p);
+#endif
+}
 
 
 // Weight stream.  The packer lays every layer's A-fragment rows (1 KiB per wave: 64 lanes x float4)

@@ -22,7 +22,7 @@ if SAVE:
 with torch.set_grad_enabled(SAVE):
     for i in range(6):
         with timer:
-            render.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"], p["appea_code"], fw, ew, n_samples=64, precision="bf16x3")
+            render.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"], p["appea_code"], fw, ew, n_samples=64, precision=os.environ.get("GNR_ABL_PRECISION", "bf16x3"))
         if i >= 2: ms.append(timer.elapsed_ms())
 t = sum(ms) / len(ms)
 print("%%-28s %%.3f ms  %%.1f k rays/s  %%.0f%%%% of bf16x3 MFMA peak" %% (os.path.basename(sys.argv[1]), t, 16384 / t, 16384 * 346.03e6 / t / 1e9 / 838.9 * 100))
