@@ -69,9 +69,22 @@ struct MergeBwdParams {
     GnrMergeProblem p;
     const float* g_mf; const float* g_ep; const float* g_m;
     float* d_ff; float* d_af; float* d_fe; float* d_ae; float* d_bg;
-    float* rot_part;          // [B][blocks][9]
+    float* rot_part;          // [B][blocks * slices][9]
+    float* af_part;           // [slices][B][n_pix] partial d(bg_alpha_face) per channel slice (slices > 1), then the eyes'
+    float* ae_part;
     int blocks;
 };
+
+// channel-triplet slices of the backward grid: a 64 x 64 map is 16 blocks of pixels on 256 CUs, and one thread walking
+// all images and 86 triplets took 228 us
+static inline int merge_slices(const GnrMergeProblem* p) {
+    const long blocks = (p->n_pix + 255) / 256;
+    long z = 256 / blocks;
+    const int G = p->feat_nc / 3;
+    if (z > 16) z = 16;
+    if (z > G) z = G;
+    return z < 1 ? 1 : (int)z;
+}
 
 __global__ __launch_bounds__(256) void merge_bwd_kernel(const MergeBwdParams mp) {
     __shared__ float red[9][256];
@@ -80,6 +93,8 @@ __global__ __launch_bounds__(256) void merge_bwd_kernel(const MergeBwdParams mp)
     const long pix = (long)blockIdx.x * 256 + tid;
     const bool live = pix < p.n_pix;
     const int C = p.feat_nc, G = C / 3;
+    const int zs = gridDim.y, z = blockIdx.y;
+    const int gbeg = (int)((long)G * z / zs), gend = (int)((long)G * (z + 1) / zs);
     for (int b = 0; b < p.batch; ++b) {
         float dR[9];
 #pragma unroll
@@ -88,7 +103,7 @@ __global__ __launch_bounds__(256) void merge_bwd_kernel(const MergeBwdParams mp)
             const Rot3 R = make_rot(p.gaze, b);
             const float af = p.bg_alpha_face[(long)b * p.n_pix + pix], ae = p.bg_alpha_eyes[(long)b * p.n_pix + pix];
             float daf = 0.0f, dae = 0.0f;
-            for (int g = 0; g < G; ++g) {
+            for (int g = gbeg; g < gend; ++g) {
                 float mf[3], me[3], bg[3], ep[3], Gmf[3], Gep[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
@@ -124,8 +139,13 @@ __global__ __launch_bounds__(256) void merge_bwd_kernel(const MergeBwdParams mp)
                     for (int c2 = 0; c2 < 3; ++c2) dR[3 * c + c2] = fmaf(me[c], Gep[c2], dR[3 * c + c2]);
                 }
             }
-            if (mp.d_af) mp.d_af[(long)b * p.n_pix + pix] = daf;
-            if (mp.d_ae) mp.d_ae[(long)b * p.n_pix + pix] = dae;
+            if (zs == 1) {
+                if (mp.d_af) mp.d_af[(long)b * p.n_pix + pix] = daf;
+                if (mp.d_ae) mp.d_ae[(long)b * p.n_pix + pix] = dae;
+            } else {                         // merge_alpha_kernel adds the slices in order
+                mp.af_part[((long)z * p.batch + b) * p.n_pix + pix] = daf;
+                mp.ae_part[((long)z * p.batch + b) * p.n_pix + pix] = dae;
+            }
         }
 #pragma unroll
         for (int k = 0; k < 9; ++k) red[k][tid] = dR[k];
@@ -136,21 +156,42 @@ __global__ __launch_bounds__(256) void merge_bwd_kernel(const MergeBwdParams mp)
                 for (int k = 0; k < 9; ++k) red[k][tid] += red[k][tid + s];
             __syncthreads();
         }
-        if (tid < 9) mp.rot_part[((long)b * mp.blocks + blockIdx.x) * 9 + tid] = red[tid][0];
+        if (tid < 9) mp.rot_part[((long)b * mp.blocks * zs + (long)blockIdx.x * zs + z) * 9 + tid] = red[tid][0];
         __syncthreads();
     }
 }
 
 // d(gaze) from dRot: Rot = [[c1, s1 s0, s1 c0], [0, c0, -s0], [-s1, c1 s0, c1 c0]]
+// d(bg_alpha)[b][pix] = sum over the channel slices, in slice order
+__global__ void merge_alpha_kernel(const float* __restrict__ part, int slices, long n, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = 0.0f;
+    for (int zz = 0; zz < slices; ++zz) a += part[(long)zz * n + i];       // <= 16 independent loads, unrolled by hipcc
+    out[i] = a;
+}
+
 __global__ void merge_gaze_kernel(const float* rot_part, int blocks, const float* gaze, float* d_gaze) {
+    __shared__ float dsum[9];
     const int b = blockIdx.x;
+    if (threadIdx.x < 9) {          // one thread per matrix entry, loads 16 at a time, additions in block order
+        const float* src = rot_part + (long)b * blocks * 9 + threadIdx.x;
+        float a = 0.0f;
+        int i = 0;
+        for (; i + 16 <= blocks; i += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = src[(long)(i + u) * 9];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a += v[u];
+        }
+        for (; i < blocks; ++i) a += src[(long)i * 9];
+        dsum[threadIdx.x] = a;
+    }
+    __syncthreads();
     if (threadIdx.x != 0) return;
     float d[9];
-    for (int k = 0; k < 9; ++k) {
-        float a = 0.0f;
-        for (int i = 0; i < blocks; ++i) a += rot_part[((long)b * blocks + i) * 9 + k];
-        d[k] = a;
-    }
+    for (int k = 0; k < 9; ++k) d[k] = dsum[k];
     const float c0 = cosf(gaze[2 * b]), s0 = sinf(gaze[2 * b]), c1 = cosf(gaze[2 * b + 1]), s1 = sinf(gaze[2 * b + 1]);
     // pitch (index 0): d/d0 of s0 = c0, of c0 = -s0
     const float g0 = d[1] * (s1 * c0) + d[2] * (-s1 * s0) + d[4] * (-s0) + d[5] * (-c0) + d[7] * (c1 * c0) + d[8] * (-c1 * s0);
@@ -177,8 +218,10 @@ extern "C" {
 
 size_t gnr_merge_scratch_bytes(const GnrMergeProblem* p) {
     if (check_merge(p)) return 0;
-    const size_t blocks = ((size_t)p->n_pix + 255) / 256;
-    return ((size_t)p->batch * blocks * 9 * sizeof(float) + 255) & ~(size_t)255;
+    const size_t blocks = ((size_t)p->n_pix + 255) / 256, zs = (size_t)merge_slices(p);
+    const size_t rot = ((size_t)p->batch * blocks * zs * 9 * sizeof(float) + 255) & ~(size_t)255;
+    const size_t alpha = zs > 1 ? 2 * (((size_t)zs * p->batch * p->n_pix * sizeof(float) + 255) & ~(size_t)255) : 0;
+    return rot + alpha;
 }
 
 int gnr_merge_fwd(const GnrMergeProblem* p, float* merge_face, float* eyes_planes, float* merge, void* stream) {
@@ -204,9 +247,20 @@ int gnr_merge_bwd(const GnrMergeProblem* p, const float* g_merge_face, const flo
     mp.d_ff = d_feat_face; mp.d_af = d_bg_alpha_face; mp.d_fe = d_feat_eyes; mp.d_ae = d_bg_alpha_eyes; mp.d_bg = d_bg_featmap;
     mp.rot_part = (float*)scratch;
     mp.blocks = (int)((p->n_pix + 255) / 256);
+    const int zs = merge_slices(p);
+    const size_t rot = ((size_t)p->batch * mp.blocks * zs * 9 * sizeof(float) + 255) & ~(size_t)255;
+    const size_t aslab = ((size_t)zs * p->batch * p->n_pix * sizeof(float) + 255) & ~(size_t)255;
+    mp.af_part = (float*)((char*)scratch + rot);
+    mp.ae_part = (float*)((char*)scratch + rot + aslab);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(merge_bwd_kernel, dim3(mp.blocks), dim3(256), 0, st, mp);
-    if (d_gaze) hipLaunchKernelGGL(merge_gaze_kernel, dim3(p->batch), dim3(64), 0, st, mp.rot_part, mp.blocks, p->gaze, d_gaze);
+    hipLaunchKernelGGL(merge_bwd_kernel, dim3(mp.blocks, zs), dim3(256), 0, st, mp);
+    if (zs > 1) {
+        const long n = (long)p->batch * p->n_pix;
+        const unsigned nb = (unsigned)((n + 255) / 256);
+        if (d_bg_alpha_face) hipLaunchKernelGGL(merge_alpha_kernel, dim3(nb), dim3(256), 0, st, mp.af_part, zs, n, d_bg_alpha_face);
+        if (d_bg_alpha_eyes) hipLaunchKernelGGL(merge_alpha_kernel, dim3(nb), dim3(256), 0, st, mp.ae_part, zs, n, d_bg_alpha_eyes);
+    }
+    if (d_gaze) hipLaunchKernelGGL(merge_gaze_kernel, dim3(p->batch), dim3(64), 0, st, mp.rot_part, mp.blocks * zs, p->gaze, d_gaze);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("gnr_merge_bwd: launch failed: %s", hipGetErrorString(e));
     return 0;
