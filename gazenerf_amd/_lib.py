@@ -15,13 +15,22 @@ N_RGB = 3
 WS_FWD, WS_FWD_SAVE, WS_BWD = 0, 1, 2
 STAGE_FWD_MLP, STAGE_DGRAD, STAGE_COMP_BWD, STAGE_WGRAD = 0, 1, 2, 3
 N_STAGES = 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _p = C.c_void_p
 
 
-class GnrProblem(C.Structure):
-    _fields_ = [("batch", C.c_int32), ("n_rays", C.c_int32), ("n_samples", C.c_int32),
+class _Sized(C.Structure):
+    """Descriptor structs of ABI 3 start with ``struct_size`` = the caller's sizeof (include/gnr.h): stamped on
+    construction, checked by every entry point that takes the struct."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = C.sizeof(type(self))
+
+
+class GnrProblem(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("batch", C.c_int32), ("n_rays", C.c_int32), ("n_samples", C.c_int32),
                 ("hidden", C.c_int32), ("feat_nc", C.c_int32), ("shape_dims", C.c_int32),
                 ("gaze_dims", C.c_int32), ("appea_dims", C.c_int32),
                 ("world_z1", C.c_float), ("world_z2", C.c_float),
@@ -48,8 +57,8 @@ class GnrOutputGrads(C.Structure):
     _fields_ = [("feat", _p * 2), ("bg_alpha", _p * 2)]
 
 
-class GnrMergeProblem(C.Structure):
-    _fields_ = [("batch", C.c_int32), ("n_pix", C.c_int32), ("feat_nc", C.c_int32),
+class GnrMergeProblem(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("batch", C.c_int32), ("n_pix", C.c_int32), ("feat_nc", C.c_int32),
                 ("feat_face", _p), ("bg_alpha_face", _p), ("feat_eyes", _p), ("bg_alpha_eyes", _p),
                 ("bg_featmap", _p), ("gaze", _p)]
 
@@ -58,8 +67,8 @@ UP_MAX = 4
 UP_WS_FWD, UP_WS_BWD = 0, 1
 
 
-class GnrUpsampleProblem(C.Structure):
-    _fields_ = [("batch", C.c_int32), ("feat_nc", C.c_int32), ("featmap_size", C.c_int32),
+class GnrUpsampleProblem(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("batch", C.c_int32), ("feat_nc", C.c_int32), ("featmap_size", C.c_int32),
                 ("n_blocks", C.c_int32), ("min_feat", C.c_int32), ("final_sigmoid", C.c_int32), ("x", _p)]
 
 

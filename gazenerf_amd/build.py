@@ -16,10 +16,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libgnr.so")
-SOURCES = ["gnr_api.hip", "gnr_prep.hip", "gnr_fwd.hip", "gnr_bwd.hip", "gnr_wgrad.hip", "gnr_merge.hip", "gnr_fwd3.hip", "gnr_bwd3.hip", "gnr_upsample.hip"]
-HEADERS = ["gnr_internal.h", "gnr_device.h", "gnr_chain.h", "gnr_chain3.h", "gnr_bwd_common.h", os.path.join("..", "..", "include", "gnr.h")]
+SOURCES = ["gnr_api.hip", "gnr_prep.hip", "gnr_fwd.hip", "gnr_fwd16.hip", "gnr_bwd.hip", "gnr_bwd16.hip", "gnr_wgrad.hip", "gnr_merge.hip", "gnr_fwd3.hip", "gnr_bwd3.hip", "gnr_upsample.hip"]
+HEADERS = ["gnr_internal.h", "gnr_device.h", "gnr_chain.h", "gnr_chain16.h", "gnr_chain3.h", "gnr_bwd_common.h", os.path.join("..", "..", "include", "gnr.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# timing experiments only (tools/ab_variants.sh): extra -D switches, applied to the files named in GNR_EXTRA_FILES
+EXPERIMENT_FLAGS = os.environ.get("GNR_EXTRA_HIPCC_FLAGS", "").split()
+EXPERIMENT_FILES = [f for f in os.environ.get("GNR_EXTRA_FILES", "").split(",") if f]
 # per-file extras.  gnr_wgrad.hip: the SLP vectoriser packs the scalar rider adds that sit between the MFMAs into
 # v_pk_* with register shuffles around them -- each extra VALU instruction there costs matrix-pipe cycles.
 EXTRA_FLAGS = {"gnr_wgrad.hip": ["-fno-slp-vectorize"]}
@@ -40,12 +43,15 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for s in srcs:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJ, s.replace(".hip", ".o"))
-        if force or _stale(obj, [src] + hdrs):
+        if force or s in EXPERIMENT_FILES or _stale(obj, [src] + hdrs):
             jobs.append((src, obj))
 
     def compile_one(job):
         src, obj = job
-        cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), [])
+        if os.path.basename(src) in EXPERIMENT_FILES:
+            cmd += EXPERIMENT_FLAGS
+        cmd += ["-c", src, "-o", obj]
         if verbose:
             print("[gnr build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

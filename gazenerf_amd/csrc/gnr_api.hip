@@ -4,6 +4,7 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "gnr_internal.h"
@@ -42,8 +43,21 @@ int fail(const char* fmt, ...) {
 
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
+bool chain16_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("GNR_CHAIN32");
+        return !(e && e[0] == '1');
+    }();
+    return on;
+}
+
 int check_problem(const GnrProblem* p, int n_streams) {
     if (!p) return fail("gnr: problem is NULL");
+    // ABI 3 size handshake: a caller built against another header must not have its fields read at our offsets
+    if (p->struct_size != sizeof(GnrProblem))
+        return fail("gnr: GnrProblem.struct_size is %u but this libgnr.so (ABI %d) has sizeof(GnrProblem) = %zu: the caller "
+                    "was built against a different include/gnr.h (or did not set struct_size)", p->struct_size,
+                    GNR_ABI_VERSION, sizeof(GnrProblem));
     if (n_streams < 1 || n_streams > 2) return fail("gnr: n_streams must be 1 or 2 (got %d)", n_streams);
     // narrower networks run zero-padded in the 384-wide kernels: same results, 384-wide cost
     if (p->hidden < 2 || p->hidden > H || (p->hidden & 1))
@@ -56,6 +70,13 @@ int check_problem(const GnrProblem* p, int n_streams) {
     if (!p->xy || !p->R || !p->T || !p->Kinv) return fail("gnr: xy/R/T/Kinv must be non-NULL");
     if ((p->shape_dims && !p->shape_code) || (p->gaze_dims && !p->gaze) || (p->appea_dims && !p->appea_code))
         return fail("gnr: latent code pointer is NULL");
+    // the view-direction columns are skipped by the kernels and must come back through ray_bias (include/gnr.h): a
+    // problem that declares them but supplies no per-ray bias would silently drop them
+    if (p->vd_dims > 0)
+        for (int s = 0; s < n_streams; ++s)
+            if (!p->ray_bias[s])
+                return fail("gnr: vd_dims = %d but ray_bias[%d] is NULL: the view-direction columns of RGB_layer_1 reach the "
+                            "kernels only through the per-ray bias", p->vd_dims, s);
     return 0;
 }
 
@@ -96,8 +117,8 @@ size_t carve_fwd(const GnrProblem* p, int n_streams, bool save, char* base, FwdP
         w.packed = packed_all ? packed_all + (size_t)s * PACKED_FLOATS : nullptr;
         w.bias = take((size_t)N_CHAIN * p->batch * H);
         w.wsig = take(H + 4);
-        w.part_feat = take(n_chunks * FEAT_PAD);
-        w.part_sc = take(n_chunks * 4);
+        w.part_feat = take(2 * n_chunks * FEAT_PAD);      // fp32 kernels: one partial per 16-sample sub-chunk
+        w.part_sc = take(2 * n_chunks * 4);
         w.wl = take(M);
         if (save) {
             w.act_h = take((size_t)8 * M * H);
@@ -192,17 +213,20 @@ static int fwd_impl(const GnrProblem* p, const GnrWeights* face, const GnrWeight
     const GnrWeights* ws_in[2] = {face, eyes};
     // weights_packed: the caller vouches that the packed streams in this workspace are current (inference only)
     const bool reuse = p->weights_packed != 0 && !save;
-    launch_prep(*p, n_streams, ws_in, fp.ws, st, !bf16x3 && !reuse);       // (the code-folded biases are always rebuilt)
+    const bool c16 = !bf16x3 && chain16_enabled();
+    launch_prep(*p, n_streams, ws_in, fp.ws, st, !bf16x3 && !reuse, c16);  // (the code-folded biases are always rebuilt)
     if (bf16x3 && !reuse) launch_prep3(*p, n_streams, ws_in, fp.ws, st);
     stage_mark(GNR_STAGE_FWD_MLP, 0, st);
     if (bf16x3) launch_fwd3(fp, st);
+    else if (c16) launch_fwd16(fp, st);
     else launch_fwd(fp, st);
     stage_mark(GNR_STAGE_FWD_MLP, 1, st);
 
     CombineParams cp{};
     cp.prob = *p;
     cp.n_streams = n_streams;
-    cp.chunks_per_ray = fp.chunks_per_ray;
+    cp.chunks_per_ray = c16 ? 2 * fp.chunks_per_ray : fp.chunks_per_ray;
+    cp.chunk_len = c16 ? 16 : CHUNK;
     for (int s = 0; s < n_streams; ++s) {
         cp.part_feat[s] = fp.ws[s].part_feat;
         cp.part_sc[s] = fp.ws[s].part_sc;

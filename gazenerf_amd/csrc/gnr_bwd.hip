@@ -25,6 +25,8 @@ void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb,
                   int n_crop = -1, int k_crop = -1);
 void launch_vecsum(const float* v, int batch, long per_image, float* out, int out_stride, hipStream_t stream);
 void stage_mark(int stage, int which, hipStream_t st);
+void launch_packT16(const PackTParams& pt, hipStream_t stream);
+void launch_bwd16_chain(const BwdParams& bp, hipStream_t stream);
 
 __global__ void packT_kernel(const PackTParams pp) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < PACKEDT_FLOATS;
@@ -555,7 +557,7 @@ static size_t carve_bwd(const GnrProblem* p, char* base, BwdScratch* sc) {
     s.dY_r0 = take(M * H);
     s.dY_r1 = take(M * H2);
     s.dfeat = take(M * FEAT_PAD);
-    s.geo_chunk = take(n_chunks * 8);
+    s.geo_chunk = take(2 * n_chunks * 8);             // fp32 kernels: one partial per 16-sample sub-chunk
     s.csum = take(n_rays_total);
     s.dsig_ray = take(n_rays_total);
     s.geo_blocks = (p->n_rays + 255) / 256;
@@ -630,7 +632,9 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         setl(10, W.fea_w[1], Hh, Hh, 0, Hh, 0);
         setl(11, W.fea_w[0], vp, Hh, 0, ENC_PAD, 1);
         pt.packed = sc.packedT;
+        const bool c16 = !bf16x3 && chain16_enabled();
         if (bf16x3) launch_packT3(pt, st);
+        else if (c16) launch_packT16(pt, st);
         else hipLaunchKernelGGL(packT_kernel, dim3(1024), dim3(256), 0, st, pt);
         // 4. dgrad chain
         BwdParams bp{};
@@ -643,6 +647,8 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         if (s == 0) stage_mark(GNR_STAGE_DGRAD, 0, st);
         if (bf16x3)
             launch_bwd3_chain(bp, st);
+        else if (c16)
+            launch_bwd16_chain(bp, st);
         else
             hipLaunchKernelGGL(bwd_chain_kernel, dim3((unsigned)((fp.n_chunks + WAVES_PER_WG - 1) / WAVES_PER_WG)),
                                dim3(256), 0, st, bp);
@@ -697,7 +703,7 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
     // geometry: dR, dT
     if (dinz.R || dinz.T) {
         GeoParams gp{};
-        gp.prob = *p; gp.chunks_per_ray = cpr; gp.geo_chunk = sc.geo_chunk; gp.csum = sc.csum;
+        gp.prob = *p; gp.chunks_per_ray = (!bf16x3 && chain16_enabled()) ? 2 * cpr : cpr; gp.geo_chunk = sc.geo_chunk; gp.csum = sc.csum;
         gp.part = sc.geo_part; gp.blocks_per_image = sc.geo_blocks;
         hipLaunchKernelGGL(geo_kernel, dim3(sc.geo_blocks, p->batch), dim3(256), 0, st, gp);
         hipLaunchKernelGGL(geo_final_kernel, dim3(p->batch), dim3(64), 0, st, sc.geo_part, sc.geo_blocks, dinz.R, dinz.T);

@@ -1,0 +1,301 @@
+// gnr_chain16.h -- the fp32 dense chain on v_mfma_f32_16x16x4_f32 with TWO waves per SIMD (round 3).
+//
+// Round 1/2 ran one wave per SIMD on 32-sample tiles (v_mfma_f32_32x32x2_f32; 192 + 192 activation registers).
+// With one wave per SIMD nothing overlaps the wave's own non-MFMA instructions: every buffer load, LDS read or VALU
+// instruction between two MFMAs stalls the matrix pipe (tools/ubench/mfma_stream2.hip: 88-92 % of peak for the bare
+// weight-streaming loop, 0.84-0.88 for the real kernels).  tools/ubench/mfma_2w.hip measured the alternative:
+//
+//     one wave / SIMD, 32x32x2, 6-row buffer-load batches (the round-2 kernels' loop)      88.6-89.3 %
+//     two waves / SIMD, 16x16x4, 4-row buffer-load batches                                 97.3 %
+//     ... 8-row / 12-row batches                                                            96.1 / 97.1 %
+//     ... fed by ds_read_b128 from LDS / by an LDS-DMA ring in a 512-thread workgroup       91.3 / 91.8 %
+//     every VALU instruction among the MFMAs still costs ~4 matrix-pipe cycles (13 before)
+//
+// So: a wave owns 16 samples (the 16 columns of a 16x16x4 tile; same FLOPs per cycle as 32x32x2), its activation
+// sets are 96 + 96 registers, two waves share a SIMD (256 registers each) and keep each other's MFMA pipe busy while
+// one of them issues loads / epilogue VALU.  Waves stay independent (no barriers, per-wave buffer loads): the
+// LDS-fed variants measured slower than plain buffer loads.
+//
+// Register chain, as before: the C/D layout of a 16x16 tile (lane l: sample l&15, register e of tile t: channel
+// 16 t + 4 (l>>4) + e) IS the B-operand layout of the next layer when k-step e of input tile t takes register e
+// (lane group g = l>>4 supplies k = g): a layer's output feeds the next one with no data movement.
+#pragma once
+#include "gnr_chain.h"
+
+namespace gnr {
+
+constexpr int SUB = 16;                    // samples per wavefront
+constexpr int NT16_H = H / 16;             // 24 tiles of 16 channels
+constexpr int NT16_H2 = H2 / 16;           // 12
+constexpr int NT16_F = FEAT_PAD / 16;      // 18
+constexpr int NT16_E = ENC_PAD / 16;       // 4
+constexpr int ENC16 = 16;                  // encoding values per lane (64 slots over 4 lane groups)
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    // v_mfma_f32_16x16x4_f32: lane l holds A[i = l&15][k = l>>4], B[k = l>>4][j = l&15];
+    // D register e: row i = 4 (l>>4) + e, column j = l&15.
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// channel held by register e of tile t in lane group g (C/D layout == next layer's k-order)
+__host__ __device__ constexpr int d16_channel(int t, int e, int g) { return 16 * t + 4 * g + e; }
+
+// ---- positional encoding over four lane groups ------------------------------------------------------------
+// The HBM formats (encoding dump, weight-gradient column map) keep round 1's 64 "slots" (slot = 2 step + h of
+// enc_channel, gnr_internal.h); only the assignment of slots to lanes is new.  The 30 (frequency, axis) pairs
+// p = 15 h + 3 fl + a are dealt to the groups as 7 + 7 + 8 + 8, sin and cos of a pair to the same lane; groups 0 / 1
+// also carry the raw coordinates: g0 {x, z}, g1 {y, pad}.  Lane value idx (0..15) is k-step idx&3 of k-group idx>>2.
+__host__ __device__ constexpr int enc16_pair_base(int g) { return g < 2 ? 7 * g : 14 + 8 * (g - 2); }
+__host__ __device__ constexpr int enc16_slot(int idx, int g) {
+    if (g < 2 && idx < 2) return idx == 0 ? g : 2 + g;             // x: 0, y: 1, z: 2, pad: 3
+    const int k = g < 2 ? idx - 2 : idx;
+    const int p = enc16_pair_base(g) + (k >> 1), sc = k & 1;
+    const int h = p / 15, fl = (p % 15) / 3, a = p % 3;
+    return 2 * (2 + 6 * fl + 3 * sc + a) + h;
+}
+// reference channel (utils/model_utils.py:272-280 order) of lane value idx of group g, or -1 for the pad
+__host__ __device__ constexpr int enc16_channel(int idx, int g) {
+    const int s = enc16_slot(idx, g);
+    const int step = s >> 1, h = s & 1;
+    if (step == 0) return h;
+    if (step == 1) return h == 0 ? 2 : -1;
+    const int i2 = step - 2, fl = i2 / 6, q = i2 % 6;
+    return 3 + 6 * (5 * h + fl) + q;
+}
+
+// Embedder.forward (utils/model_utils.py:272-280) for lane group g: the 16 values of enc16_slot(., g).
+// Arguments and sincosf are exactly round 1's (scale = 2^f exactly; arguments reach ~1.7e3 rad).
+__device__ __forceinline__ void encode_point16(float px, float py, float pz, int g, float (&e)[ENC16]) {
+    const int base = g < 2 ? 7 * g : 14 + 8 * (g - 2);
+    float s[8], c[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int p = min(base + q, 29);               // (groups 0 / 1 have 7 pairs: their q = 7 is discarded)
+        const int h = p >= 15 ? 1 : 0, pp = p - 15 * h, fl = pp / 3, a = pp - 3 * fl;
+        const float scale = (float)(1 << fl) * (h ? 32.0f : 1.0f);
+        const float x = a == 0 ? px : (a == 1 ? py : pz);
+        sincosf(x * scale, &s[q], &c[q]);
+    }
+    const bool lowg = g < 2;
+    const float raw0 = g == 0 ? px : py, raw1 = g == 0 ? pz : 0.0f;
+    e[0] = lowg ? raw0 : s[0];
+    e[1] = lowg ? raw1 : c[0];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) {
+        e[2 * q] = lowg ? s[q - 1] : s[q];
+        e[2 * q + 1] = lowg ? c[q - 1] : c[q];
+    }
+}
+
+// old-format slot of lane value idx (runtime group): used for the encoding dump / its read-back
+__device__ __forceinline__ int enc16_slot_rt(int idx, int g) {
+    if (g < 2 && idx < 2) return idx == 0 ? g : 2 + g;
+    const int k = g < 2 ? idx - 2 : idx;
+    const int p = (g < 2 ? 7 * g : 14 + 8 * (g - 2)) + (k >> 1), sc = k & 1;
+    const int h = p >= 15 ? 1 : 0, pp = p - 15 * h, fl = pp / 3, a = pp - 3 * fl;
+    return 2 * (2 + 6 * fl + 3 * sc + a) + h;
+}
+
+// ---- weight stream: rows of 1 KiB (64 lanes x float4 = the A fragments of 4 MFMAs), batches of 4 ---------------
+constexpr int WB16 = 4;
+#ifndef GNR_DUMP_BURST
+#define GNR_DUMP_BURST 1
+#endif
+constexpr int DUMP_BURST = GNR_DUMP_BURST;      // dump stores per burst (1 = one store every NROW / NREG rows)
+struct WStream16 {
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned voff;               // lane * 16 + byte offset of the batch most recently requested
+    f32x4 g[2][WB16];
+};
+
+template <int Q>
+__device__ __forceinline__ f32x4 wrow16(const WStream16& w) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.voff + (unsigned)Q * 1024u, 0, 0));
+}
+__device__ __forceinline__ void wbatch16(WStream16& w, f32x4 (&g)[WB16]) {
+    g[0] = wrow16<0>(w); g[1] = wrow16<1>(w); g[2] = wrow16<2>(w); g[3] = wrow16<3>(w);
+}
+__device__ __forceinline__ void wstream16_init(WStream16& w, const float* packed, int lane) {
+    w.rs = __builtin_amdgcn_make_buffer_rsrc((void*)packed, 0, 0x7ffffff0, 0x00020000);
+    w.voff = (unsigned)lane * 16u;
+    wbatch16(w, w.g[0]);
+}
+
+// ---- dump destination: buffer stores with a wave-uniform descriptor ---------------------------------------------
+// Element (chunk c, channel n, sample jj) of a chunk-channel-major tensor lives at c*32*C + n*32 + jj.  The wave owns
+// samples 16 hh + j of chunk c and, in register e of tile t, channel 16 t + 4 g + e: with the descriptor based at the
+// chunk, every dump of the wave uses the SAME lane offset ((4 g) 32 + 16 hh + j) 4 bytes and a compile-time constant
+// (16 t + e) 128 bytes split over the 12-bit immediate and one scalar: no 64-bit address arithmetic on the VALU
+// (global_store needed a v_add_co / v_addc pair every few stores -- each VALU instruction among the MFMAs costs ~4
+// matrix-pipe cycles), and one VGPR instead of a pointer pair per destination.
+struct Dump16 {
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned voff;
+};
+__device__ __forceinline__ Dump16 dump_dst16(float* dst, int C, long sub, int j, int g) {
+    Dump16 d;
+    d.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(dst + (sub >> 1) * (CHUNK * (long)C)), 0, 0x7ffffff0, 0x00020000);
+    d.voff = (unsigned)((4 * g) * CHUNK + 16 * (int)(sub & 1) + j) * 4u;
+    return d;
+}
+// element offset (floats, compile-time) -> nontemporal dword store
+template <class T>
+__device__ __forceinline__ void dump_store16(const Dump16& d, int elem, T v) {
+    static_assert(sizeof(T) == 4, "dword dumps");
+#ifdef GNR_NODUMP_TIMING            // timing experiment only: results are incomplete
+    (void)d; (void)elem; (void)v;
+#else
+    const unsigned byte = (unsigned)elem * 4u;
+#ifdef GNR_TEMPORAL_DUMP_TIMING
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), d.rs, d.voff + (byte & 4095u), (int)(byte & ~4095u), 0);
+#else
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), d.rs, d.voff + (byte & 4095u), (int)(byte & ~4095u), 2);   // aux 2 = nt
+#endif
+#endif
+}
+
+// ---- one dense layer: acc[nt] (+)= sum over the channels held in hin[0..NT_IN) --------------------------------
+// Rows are (k-group = input tile, n-tile), k-group outer; the four rows of a batch are interleaved so that
+// consecutive MFMAs never share an accumulator.  INIT: the first MFMA of every output tile takes its C operand from
+// init(nt) (the bias tile, or zeros) instead of the accumulator.  DUMP: the layer also writes its INPUT registers
+// (the previous layer's output) to HBM in the CCM layout, spread over its rows.  epi(nt) runs for every finished
+// output tile inside the tail of the loop, one batch behind the MFMAs that completed it.
+struct ZeroInit16 {
+    __device__ __forceinline__ f32x4 operator()(int) const { return f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+};
+
+template <int NT_IN, int NT_OUT, bool INIT, bool DUMP, class Init, class Epi>
+__device__ __forceinline__ void mm16_h(const f32x4 (&hin)[NT16_H], f32x4 (&acc)[NT16_H], WStream16& w,
+                                       const Dump16& dump_dst, Init init, Epi epi) {
+    constexpr int NROW = NT_IN * NT_OUT;
+    constexpr int NREG = NT_IN * 4;
+    constexpr int NB = NROW / WB16;
+    constexpr int LAST0 = NROW - NT_OUT;
+    static_assert(NROW % (2 * WB16) == 0 && NB % 2 == 0 && NT_OUT >= WB16, "layer rows must keep the batch parity");
+#pragma clang loop unroll(full)
+    for (int kbo = 0; kbo < NB / 2; ++kbo)
+#pragma clang loop unroll(full)
+    for (int kbi = 0; kbi < 2; ++kbi) {
+        const int kb = kbo * 2 + kbi;
+        w.voff += WB16 * 1024u;
+        wbatch16(w, w.g[(kb + 1) & 1]);
+        if (!DUMP) wait_vm<WB16>();
+        __builtin_amdgcn_sched_barrier(0);
+        const int i0 = kb * WB16;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int u = 0; u < WB16; ++u) {
+                const int i = i0 + u, kg = i / NT_OUT, nt = i % NT_OUT;
+                const f32x4 a = w.g[kb & 1][u];
+                acc[nt] = mfma16(a[e], hin[kg][e], (INIT && kg == 0 && e == 0) ? init(nt) : acc[nt]);
+            }
+        if (DUMP) {
+            // stores due by the end of this batch, issued in bursts of DUMP_BURST (the inputs are complete from the start)
+            constexpr int S = DUMP_BURST;
+            const int t0 = (i0 * NREG) / NROW, t1 = ((i0 + WB16) * NREG) / NROW;
+            const int q0 = kb == 0 ? 0 : ((t0 + S - 1) / S) * S, q1 = ((t1 + S - 1) / S) * S;
+#pragma unroll
+            for (int q = q0; q < (q1 < NREG ? q1 : NREG); ++q)
+                dump_store16(dump_dst, (16 * (q >> 2) + (q & 3)) * CHUNK, hin[q >> 2][q & 3]);
+        }
+        // epilogue of the tiles completed by the previous batch
+#pragma unroll
+        for (int u = 0; u < WB16; ++u)
+            if (i0 - WB16 + u >= LAST0) epi(i0 - WB16 + u - LAST0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int u = 0; u < WB16; ++u) epi(NT_OUT - WB16 + u);
+}
+
+// ---- the 64-slot positional-encoding slab (4 k-groups), B operand read back from LDS ----------------------------
+template <int NT_OUT, bool STORES_IN_FLIGHT, class Init>
+__device__ __forceinline__ void mm16_enc(const float* enc_col, f32x4 (&acc)[NT16_H], WStream16& w, Init init) {
+    constexpr int NROW = NT16_E * NT_OUT;
+    constexpr int NB = NROW / WB16;
+    static_assert(NROW % (2 * WB16) == 0 && NT_OUT % WB16 == 0, "layer rows must keep the batch parity");
+    float ev[4] = {0, 0, 0, 0};
+#pragma clang loop unroll(full)
+    for (int kb = 0; kb < NB; ++kb) {
+        w.voff += WB16 * 1024u;
+        wbatch16(w, w.g[(kb + 1) & 1]);
+        const int i0 = kb * WB16, kg = i0 / NT_OUT;
+        if (i0 % NT_OUT == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ev[c] = enc_col[(4 * kg + c) * 256];
+        }
+        if (!STORES_IN_FLIGHT) wait_vm<WB16>();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int u = 0; u < WB16; ++u) {
+                const int nt = (i0 + u) % NT_OUT;
+                const f32x4 a = w.g[kb & 1][u];
+                acc[nt] = mfma16(a[e], ev[e], (kg == 0 && e == 0) ? init(nt) : acc[nt]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void dump16(const f32x4 (&acc)[NT16_H], const Dump16& d) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dump_store16(d, (16 * t + e) * CHUNK, acc[t][e]);
+}
+
+// ReLU sign bits: lane l keeps the signs of its own registers, tiles 8 w .. 8 w + 7 -> word w, bit 4 (t & 7) + e.
+// [layer][sub-chunk][3 words][64 lanes]: the same bytes per 32 samples as the round-1 layout.
+constexpr int RELU16_WORDS = NT16_H / 8;     // 3
+__host__ __device__ constexpr size_t relu16_offset(int layer, long n_sub, long sub) {
+    return ((size_t)layer * n_sub + sub) * RELU16_WORDS * 64;
+}
+
+// sum over the 16 lanes of a DPP row (all lanes receive it): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ float row_sum16(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
+// Sub-chunk-local alpha compositing (CalcRayColor, utils/model_utils.py:498-534) of the 16 samples a wave owns
+// (every lane group holds the same 16 scalars): writes the weighted feature sum (288 floats), the sub-chunk's
+// transmittance, sum w and sum w z; combine_kernel applies the cross-sub-chunk prefix products.
+__device__ __forceinline__ void composite_sub(const f32x4 (&feat)[NT16_H], float sigma_raw, float delta, float z0,
+                                              const StreamWs& ws, long sub, long row, int lane, bool keep_wl) {
+    const int j = lane & 15, g = lane >> 4;
+    const float sigma = fmaxf(sigma_raw, 0.0f);
+    const float alpha = 1.0f - expf(-sigma * delta);
+    const float x = (1.0f - alpha) + 1e-10f;
+    float incl = x;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        const float o = __shfl_up(incl, d, 16);
+        if (j >= d) incl *= o;
+    }
+    float excl = __shfl_up(incl, 1, 16);
+    if (j == 0) excl = 1.0f;
+    const float wl = alpha * excl;
+    const float ptot = __shfl(incl, 15, 16);
+    const float accw = row_sum16(wl);
+    const float dsum = row_sum16(wl * z0);
+    if (lane == 0) *(f32x4*)(ws.part_sc + sub * 4) = f32x4{ptot, accw, dsum, 0.0f};
+    if (keep_wl && g == 0) ws.wl[row] = wl;
+    float* pf = ws.part_feat + sub * FEAT_PAD + 4 * g;
+#pragma unroll
+    for (int t = 0; t < NT16_F; ++t) {
+        f32x4 v;
+        v.x = row_sum16(wl * feat[t][0]);
+        v.y = row_sum16(wl * feat[t][1]);
+        v.z = row_sum16(wl * feat[t][2]);
+        v.w = row_sum16(wl * feat[t][3]);
+        if (j == 0) *(f32x4*)(pf + 16 * t) = v;
+    }
+}
+
+}  // namespace gnr

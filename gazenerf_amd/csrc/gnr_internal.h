@@ -73,8 +73,8 @@ struct StreamWs {
     float* packed;        // [PACKED_FLOATS]
     float* bias;          // [N_CHAIN][B][H]  (folded per image where the layer sees latents)
     float* wsig;          // [H + 4]: density weight, then density bias at [H]
-    float* part_feat;     // [n_chunks][FEAT_PAD]  chunk-local composited features
-    float* part_sc;       // [n_chunks][4]: chunk transmittance, sum w, sum w*z, -
+    float* part_feat;     // [2 n_chunks][FEAT_PAD]  (sub-)chunk-local composited features (fp32: per 16 samples)
+    float* part_sc;       // [2 n_chunks][4]: transmittance, sum w, sum w*z, -
     float* wl;            // [M] chunk-local weights alpha_i * T_local_i            (optional)
     // saved for backward (training forward only)
     float* act_h;         // [8][M][H]  post-ReLU trunk activations
@@ -82,7 +82,8 @@ struct StreamWs {
     float* act_y1;        // [M][H2]    RGB_layer_1 output (post-ReLU)
     float* act_feat;      // [M][FEAT_PAD]
     float* sigma_raw;     // [M]
-    unsigned* relu_bits;  // [9][n_chunks][6][64]: sign bits of h0..h7, y1 in register order (lane-major)
+    unsigned* relu_bits;  // [9][n_chunks][6][64]: sign bits of h0..h7, y1 in register order (lane-major);
+                          // fp32 kernels: [9][2 n_chunks][3][64] (gnr_chain16.h), the same bytes
     const float* ray_bias;  // GnrProblem.ray_bias of this weight set ([B*N_r][hidden/2]) or nullptr
 };
 
@@ -123,7 +124,8 @@ unsigned long long* clock_probe_slot(int stage);     // gnr_api.hip; nullptr whe
 struct CombineParams {
     GnrProblem prob;
     int n_streams;
-    int chunks_per_ray;
+    int chunks_per_ray;       // partials per ray: chunks of 32 samples (bf16x3 kernels) or sub-chunks of 16 (fp32 kernels)
+    int chunk_len;            // samples per partial (32 or 16)
     const float* part_feat[2];
     const float* part_sc[2];
     const float* wl[2];
@@ -132,7 +134,10 @@ struct CombineParams {
 
 // host-side launchers (defined in the .hip translation units)
 void launch_prep(const GnrProblem& p, int n_streams, const GnrWeights* const* w, StreamWs* ws,
-                 hipStream_t stream, bool pack_fp32 = true);
+                 hipStream_t stream, bool pack_fp32 = true, bool chain16 = true);
+void launch_fwd16(const FwdParams& fp, hipStream_t stream);
+bool chain16_enabled();        // gnr_api.hip: the fp32 chain runs on 16x16x4 tiles, two waves per SIMD (default) -- or,
+                               // with GNR_CHAIN32=1 in the environment, on round 2's 32x32x2 kernels (A/B timing)
 void launch_prep3(const GnrProblem& p, int n_streams, const GnrWeights* const* w, StreamWs* ws,
                   hipStream_t stream);
 void launch_fwd3(const FwdParams& fp, hipStream_t stream);

@@ -203,6 +203,10 @@ __global__ void merge_gaze_kernel(const float* rot_part, int blocks, const float
 
 static int check_merge(const GnrMergeProblem* p) {
     if (!p) return fail("gnr_merge: problem is NULL");
+    if (p->struct_size != sizeof(GnrMergeProblem))
+        return fail("gnr_merge: GnrMergeProblem.struct_size is %u but this libgnr.so (ABI %d) has sizeof = %zu: the caller was "
+                    "built against a different include/gnr.h (or did not set struct_size)", p->struct_size, GNR_ABI_VERSION,
+                    sizeof(GnrMergeProblem));
     if (p->batch < 1 || p->n_pix < 1) return fail("gnr_merge: empty problem");
     if (p->feat_nc < 3 || p->feat_nc % 3) return fail("gnr_merge: feat_nc must be a multiple of 3 (got %d)", p->feat_nc);
     if (!p->feat_face || !p->bg_alpha_face || !p->feat_eyes || !p->bg_alpha_eyes || !p->bg_featmap || !p->gaze)

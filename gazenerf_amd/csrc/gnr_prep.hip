@@ -6,7 +6,7 @@
 //                    channels-first [B,C,N_r] via an LDS transpose
 //   resample_kernel  FineSample.forward (utils/model_utils.py:413-490)
 //   zvals_kernel     left sample edges [B,N_r,N_p]
-#include "gnr_device.h"
+#include "gnr_chain16.h"
 
 namespace gnr {
 
@@ -37,6 +37,34 @@ __global__ void pack_kernel(const PackParams pp) {
             col = enc_channel(step, h);                       // encoding occupies source columns 0..62
         } else {
             const int k = dlayout_channel(step - es, h);
+            if (k < pp.kh[l]) col = pp.hcol[l] + k;
+        }
+        float v = 0.0f;
+        if (n < pp.n_out[l] && col >= 0) v = pp.w[l][(size_t)n * pp.ld[l] + col];
+        pp.packed[e] = v;
+    }
+}
+
+// The same stream for the 16x16x4 chain (gnr_chain16.h): rows (k-group of 16 input channels, n-tile of 16 outputs),
+// lane l = (output row l&15, k = l>>4), component e = k-step.  Same number of floats per layer.
+__global__ void pack16_kernel(const PackParams pp) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < PACKED_FLOATS;
+         e += (size_t)gridDim.x * blockDim.x) {
+        int l = 0;
+        size_t off = 0;
+        while (l + 1 < N_CHAIN && e >= off + layer_packed_floats(l)) { off += layer_packed_floats(l); ++l; }
+        const size_t loc = e - off;
+        const int nt_n = 2 * layer_nt(l);
+        const int rowi = (int)(loc / 256), rem = (int)(loc % 256);
+        const int kg = rowi / nt_n, nt = rowi % nt_n;
+        const int lane = rem / 4, ee = rem % 4;
+        const int n = 16 * nt + (lane & 15), gk = lane >> 4;
+        const int ekg = layer_enc_steps(l) ? NT16_E : 0;
+        int col = -1;
+        if (kg < ekg) {
+            col = enc16_channel(4 * kg + ee, gk);             // encoding occupies source columns 0..62
+        } else {
+            const int k = d16_channel(kg - ekg, ee, gk);
             if (k < pp.kh[l]) col = pp.hcol[l] + k;
         }
         float v = 0.0f;
@@ -104,7 +132,7 @@ __global__ void bias_kernel(const BiasParams bp) {
 }
 
 void launch_prep(const GnrProblem& p, int n_streams, const GnrWeights* const* w, StreamWs* ws,
-                 hipStream_t stream, bool pack_fp32) {
+                 hipStream_t stream, bool pack_fp32, bool chain16) {
     const int vp = ENC_CH + p.shape_dims + p.gaze_dims;
     const int Hh = p.hidden, Hh2 = Hh / 2;      // the network's own width; rows / columns beyond it are packed as zeros
     for (int s = 0; s < n_streams; ++s) {
@@ -125,7 +153,8 @@ void launch_prep(const GnrProblem& p, int n_streams, const GnrWeights* const* w,
             }
         }
         pp.packed = ws[s].packed;
-        if (pack_fp32) hipLaunchKernelGGL(pack_kernel, dim3(1024), dim3(256), 0, stream, pp);
+        if (pack_fp32 && chain16) hipLaunchKernelGGL(pack16_kernel, dim3(1024), dim3(256), 0, stream, pp);
+        else if (pack_fp32) hipLaunchKernelGGL(pack_kernel, dim3(1024), dim3(256), 0, stream, pp);
         BiasParams bp;
         bp.prob = p; bp.w = *w[s]; bp.bias = ws[s].bias; bp.wsig = ws[s].wsig;
         hipLaunchKernelGGL(bias_kernel, dim3(N_CHAIN, p.batch), dim3(H), 0, stream, bp);
@@ -136,13 +165,13 @@ void launch_prep(const GnrProblem& p, int n_streams, const GnrWeights* const* w,
 // combine: out[n] = sum_c Tpre_c * partial_c[n];  Tpre_c = prod_{c'<c} P_c'
 // ---------------------------------------------------------------------------------------------
 constexpr int RB = 32;          // rays per block
-constexpr int MAX_CPR = 16;     // chunks per ray supported (N_p <= 512)
+constexpr int MAX_CPR = 32;     // (sub-)chunks per ray supported (N_p <= 512, 16-sample sub-chunks)
 
 __global__ __launch_bounds__(256) void combine_kernel(const CombineParams cp) {
     __shared__ float tile[FEAT_PAD][RB + 1];
     __shared__ float tpre[RB][MAX_CPR];
     const GnrProblem& p = cp.prob;
-    const int cpr = cp.chunks_per_ray;
+    const int cpr = cp.chunks_per_ray, clen = cp.chunk_len;      // partials per ray, samples per partial
     const long n_rays_total = (long)p.batch * p.n_rays;
     const long ray0 = (long)blockIdx.x * RB;
     const int s = blockIdx.y;
@@ -192,9 +221,9 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombineParams cp) {
             const int rl = idx / np, i = idx - rl * np;
             const long rg = ray0 + rl;
             if (rg < n_rays_total) {
-                const int c = i / CHUNK;
+                const int c = i / clen;
                 cp.out.weights[s][rg * np + i] =
-                    cp.wl[s][(rg * cpr + c) * CHUNK + (i - c * CHUNK)] * tpre[rl][c];
+                    cp.wl[s][(rg * cpr + c) * clen + (i - c * clen)] * tpre[rl][c];
             }
         }
     }

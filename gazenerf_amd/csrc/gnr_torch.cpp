@@ -30,7 +30,7 @@ void check_f32(const Tensor& t, const char* name, const c10::Device& dev) {
 }
 
 struct Problem {
-    GnrProblem c{};
+    GnrProblem c = GNR_INIT_PROBLEM;   // zeroed + struct_size stamped (ABI 3 size handshake)
     std::vector<Tensor> keep;          // contiguous versions the pointers refer to
     int64_t B = 0, n_r = 0, n_p = 0;
     c10::Device dev{c10::kCPU};
@@ -248,7 +248,7 @@ std::vector<Tensor> render_bwd(const Tensor& xy, const Tensor& R, const Tensor& 
 }
 
 int64_t saved_workspace_bytes(int64_t batch, int64_t n_rays, int64_t n_samples, int64_t hidden, int64_t feat_nc, int64_t n_streams) {
-    GnrProblem c{};
+    GnrProblem c = GNR_INIT_PROBLEM;
     c.batch = (int32_t)batch; c.n_rays = (int32_t)n_rays; c.n_samples = (int32_t)n_samples; c.hidden = (int32_t)hidden;
     c.feat_nc = (int32_t)feat_nc;
     static const float dummy = 0.0f;                 // sizes only: pointers are checked for NULL, never dereferenced

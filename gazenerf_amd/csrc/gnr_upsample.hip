@@ -517,6 +517,10 @@ struct UpDims {
 
 static int up_dims(const GnrUpsampleProblem* p, UpDims* d) {
     if (!p) return fail("gnr_upsample: problem is NULL");
+    if (p->struct_size != sizeof(GnrUpsampleProblem))
+        return fail("gnr_upsample: GnrUpsampleProblem.struct_size is %u but this libgnr.so (ABI %d) has sizeof = %zu: the caller "
+                    "was built against a different include/gnr.h (or did not set struct_size)", p->struct_size, GNR_ABI_VERSION,
+                    sizeof(GnrUpsampleProblem));
     if (p->batch < 1 || p->feat_nc < 1) return fail("gnr_upsample: batch and feat_nc must be >= 1");
     if (p->n_blocks < 1 || p->n_blocks > UP_MAX) return fail("gnr_upsample: n_blocks must be 1..%d", UP_MAX);
     if (p->featmap_size < 16 || (p->featmap_size & (p->featmap_size - 1)))

@@ -117,6 +117,25 @@ class HotPathRenderer(nn.Module):
         if hier_sampling:
             self.fine_fg_CD_predictor = MLPParams(vp, vd_ch, h_channel=hidden, res_nfeat=featmap_nc)
 
+    # The packed-weight caches key on tensor identity + version counter + data_ptr; an in-place write through ``.data``
+    # is invisible to all three (render.PackedWeightCache).  The usual places where parameters change under an
+    # eval-mode module -- mode switches, device / dtype moves, checkpoint loads -- drop the caches outright.
+    def clear_weight_caches(self):
+        self._wcache.clear()
+        self._wcache_fine.clear()
+
+    def train(self, mode: bool = True):
+        self.clear_weight_caches()
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.clear_weight_caches()
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.clear_weight_caches()
+        return super().load_state_dict(*args, **kwargs)
+
     def forward(self, batch_xy, batch_Rmats, batch_Tvecs, batch_inv_inmats, shape_code, appea_code,
                 gaze_code, for_train: bool = False, t_rand: Optional[torch.Tensor] = None,
                 u_fine: Optional[torch.Tensor] = None, return_weights: bool = False):

@@ -84,23 +84,44 @@ class GradAllReducer:
         self.n_buckets = len(self.buckets)
         self.bytes_per_step = sum(p.numel() for p in self.params) * 4
         self._inflight = {}
-        self._pending = None
+        self._seen = None            # per bucket: ids of the parameters whose hook fired since the last (re)start
         self._hooks = []
+        self.relaunched = 0          # buckets whose exchange was launched twice (accumulation): a statistic
 
     # -- overlap -------------------------------------------------------------------------------------------
     def arm_overlap(self):
         """Launch a bucket's all-reduce from autograd hooks as soon as its last gradient has been accumulated."""
         if self.world == 1 or self._hooks:
             return
-        self._pending = [len(b) for b in self.buckets]
+        self._seen = [set() for _ in self.buckets]
         for bi, bucket in enumerate(self.buckets):
             for p in bucket:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
 
+    def begin_step(self):
+        """Forget partly counted buckets and drop exchanges that were launched but never collected (call it where the
+        training loop zeroes the gradients, or after a step that raised)."""
+        for bi in list(self._inflight):
+            work, _ = self._inflight.pop(bi)
+            work.wait()
+        if self._seen is not None:
+            self._seen = [set() for _ in self.buckets]
+
     def _make_hook(self, bi):
-        def hook(_param):
-            self._pending[bi] -= 1
-            if self._pending[bi] == 0:
+        def hook(param):
+            seen = self._seen[bi]
+            if bi in self._inflight:
+                # a second backward before all_reduce(): the flat copy in flight is stale.  Collect it (every rank
+                # does, in the same order) and count this backward's gradients afresh.
+                work, _ = self._inflight.pop(bi)
+                work.wait()
+                seen.clear()
+                self.relaunched += 1
+            elif id(param) in seen:
+                seen.clear()         # the previous backward never finished this bucket
+            seen.add(id(param))
+            if len(seen) == len(self.buckets[bi]):
+                seen.clear()
                 self._launch(bi)
         return hook
 
@@ -132,5 +153,5 @@ class GradAllReducer:
                 else:
                     p.grad.copy_(g)
                 off += n
-        if self._pending is not None:
-            self._pending = [len(b) for b in self.buckets]
+        if self._seen is not None:
+            self._seen = [set() for _ in self.buckets]

@@ -159,8 +159,10 @@ def _ext_call(fn, *args):
     """TORCH_CHECK failures of the C++ binding surface as the same exception class the ctypes binding raises."""
     try:
         return fn(*args)
+    except torch.cuda.OutOfMemoryError:
+        raise                          # an allocator failure is not an argument error: OOM handlers must still match
     except RuntimeError as e:
-        raise _lib.GnrError(str(e).split("\n")[0]) from None
+        raise _lib.GnrError(str(e).split("\n")[0]) from e
 
 
 class PackedWeightCache:
@@ -172,7 +174,13 @@ class PackedWeightCache:
     SAME ``_version`` (torch bumps it on every in-place write, e.g. an optimizer step or ``load_state_dict``).  The
     cache holds references to the parameter tensors, so a freed-and-reallocated address cannot alias a key.
     Training calls (anything that needs gradients) never use it.  One cache per module and HIP stream: concurrent
-    calls on two streams would share the workspace."""
+    calls on two streams would share the workspace.
+
+    The key also holds every parameter's ``data_ptr()``, so ``p.data = other`` (``Module._apply`` / ``.to()``, EMA
+    swaps) misses.  What torch does NOT record is an in-place write through ``.data`` (``p.data.copy_()``,
+    ``p.data[:] = ...``: same storage, ``_version`` unchanged) -- the reference initialises weights that way
+    (models/mlp_nerf.py:61-75).  ``HotPathRenderer`` therefore clears its caches in ``train()``, ``_apply()`` and
+    ``load_state_dict()``; a caller who edits ``.data`` of an eval-mode module in place must call ``clear()``."""
 
     def __init__(self):
         self.ws = None
@@ -186,8 +194,13 @@ class PackedWeightCache:
         """(workspace, packed weights still valid)."""
         same_shape = self.ws is not None and self.shape_key == shape_key and self.ws.numel() >= nbytes
         hit = (same_shape and self.params is not None and len(self.params) == len(params) and
-               all(a is b and b._version == v for a, b, v in zip(self.params, params, self.versions)))
+               all(a is b and b._version == v and b.data_ptr() == d
+                   for a, b, (v, d) in zip(self.params, params, self.versions)))
         if not same_shape:
+            # a fresh workspace holds no packed weights: forget the key NOW, so that a call that raises before store()
+            # (e.g. an OOM while allocating outputs, swallowed by a trainer's try/except) cannot leave the old key
+            # describing the new, uninitialised buffer
+            self.shape_key = self.params = self.versions = None
             self.ws = _alloc_ws(max(int(nbytes), 256), shape_key[-1])
         self.hits += int(hit)
         self.misses += int(not hit)
@@ -196,7 +209,7 @@ class PackedWeightCache:
     def store(self, shape_key, params):
         self.shape_key = shape_key
         self.params = list(params)
-        self.versions = [p._version for p in params]
+        self.versions = [(p._version, p.data_ptr()) for p in params]
 
     def clear(self):
         self.__init__()
@@ -517,12 +530,16 @@ def sample_zvals(batch_xy, R, T, Kinv, *, n_samples: int, world_z1: float = 2.5,
     return out
 
 
-def importance_resample(w_face, zvals, *, n_fine: int, u: Optional[torch.Tensor] = None):
+def importance_resample(w_face, zvals, *, n_fine: int, u: Optional[torch.Tensor] = None, validate: bool = False):
     """FineSample.forward (utils/model_utils.py:413-490): coarse weights [B,1,N_r,N_c] + coarse left
     edges [B,1,N_r,N_c] -> sorted merged edges [B,N_r,N_c+n_fine+1], to be passed back as
     ``z_edges`` with ``n_samples = N_c + n_fine``.  ``u`` [B*N_r, n_fine+1] replaces torch.rand
     (``disturb=True``); None == the deterministic linspace of ``disturb=False``.  No gradient
-    (the reference detaches the weights, model_utils.py:418)."""
+    (the reference detaches the weights, model_utils.py:418).
+
+    Precondition (include/gnr.h): every row of ``zvals`` is ascending -- what ``sample_zvals`` / the plane sweep gives
+    for ``world_z1 > world_z2`` (the reference's 2.5 / -3.5).  The kernel merges two sorted lists where the reference
+    calls ``torch.sort``; ``validate=True`` checks the rows first (one host synchronisation) and raises otherwise."""
     lib = _lib.load()
     w = w_face.detach()
     _check_tensor("w_face", w)
@@ -530,6 +547,9 @@ def importance_resample(w_face, zvals, *, n_fine: int, u: Optional[torch.Tensor]
     B, _, n_r, nc = w.shape
     w = w.contiguous()
     z = zvals.detach().contiguous()
+    if validate and nc > 1 and not bool((z[..., 1:] >= z[..., :-1]).all()):
+        raise ValueError("importance_resample: zvals must be ascending along the sample axis (world_z1 > world_z2); "
+                         "the merge-based kernel has no general sort")
     if u is not None:
         _check_tensor("u", u, (B * n_r, n_fine + 1))
         u = u.contiguous()

@@ -25,6 +25,13 @@
  *   - every function returns 0 on success, non-zero on error; gnr_last_error() then describes it
  *     (thread-local).  Bindings turn that into an exception so the reference's
  *     `try: ... except: continue` around a batch (trainer/gazenerf_trainer.py:576-582) keeps working.
+ *   - size handshake (ABI 3): the three descriptor structs that have grown over time -- GnrProblem,
+ *     GnrMergeProblem, GnrUpsampleProblem -- start with `uint32_t struct_size`, which the caller sets to ITS
+ *     sizeof() of the struct (GNR_INIT_* below do it in C).  Every entry point that takes one compares it with the
+ *     library's own sizeof and fails with a message naming both sizes: a binder compiled against an older or newer
+ *     header gets an error, never fields read from the wrong offsets.  The pointer-table structs (GnrWeights,
+ *     GnrOutputs, ...) are fixed by GNR_N_TRUNK / GNR_N_RGB / GNR_UPSAMPLE_MAX_BLOCKS; a binding checks them once
+ *     at load time against gnr_sizeof().
  */
 #ifndef GNR_H_
 #define GNR_H_
@@ -36,7 +43,7 @@
 extern "C" {
 #endif
 
-#define GNR_ABI_VERSION 2
+#define GNR_ABI_VERSION 3
 #define GNR_N_TRUNK 8          /* FeaExt_module_0..7   (models/mlp_nerf.py:29-58)  */
 #define GNR_N_RGB 3            /* RGB_layer_0..2       (models/mlp_nerf.py:68-93)  */
 
@@ -44,6 +51,7 @@ extern "C" {
  * Replaces the argument list of GenSamplePoints.forward (utils/model_utils.py:364) plus the
  * latent codes GazeNeRFNet._forward receives (models/gaze_nerf.py:211-224). */
 typedef struct GnrProblem {
+    uint32_t struct_size;   /* = sizeof(GnrProblem) as the CALLER was compiled (ABI 3); mismatch -> error */
     int32_t batch;          /* B                                                              */
     int32_t n_rays;         /* N_r per image                                                  */
     int32_t n_samples;      /* N_p per ray  (opt.num_sample_coarse, or 192 for the fine pass) */
@@ -146,6 +154,11 @@ enum {
 
 int gnr_abi_version(void);
 
+/* C callers: `GnrProblem p = GNR_INIT_PROBLEM;` zero-initialises and stamps the size. */
+#define GNR_INIT_PROBLEM          { (uint32_t)sizeof(GnrProblem) }
+#define GNR_INIT_MERGE_PROBLEM    { (uint32_t)sizeof(GnrMergeProblem) }
+#define GNR_INIT_UPSAMPLE_PROBLEM { (uint32_t)sizeof(GnrUpsampleProblem) }
+
 /* sizeof() of the ABI structs as this library was compiled, so a binding in another language can verify its
  * own declarations at load time (the ctypes binding does).  Unknown id -> 0. */
 enum { GNR_SIZEOF_PROBLEM = 0, GNR_SIZEOF_WEIGHTS = 1, GNR_SIZEOF_OUTPUTS = 2, GNR_SIZEOF_OUTPUT_GRADS = 3,
@@ -194,7 +207,11 @@ int gnr_bwd(const GnrProblem* p, const GnrWeights* face, const GnrWeights* eyes,
  * weights.  weights [n_rays_total, n_coarse], coarse_z [n_rays_total, n_coarse] (left edges),
  * u [n_rays_total, n_fine+1] uniform draws or NULL == linspace(0,1,n_fine+1) (`disturb=False`).
  * Writes the sorted merged edges z_out [n_rays_total, n_coarse + n_fine + 1]; feed them back
- * through GnrProblem.z_edges with n_samples = n_coarse + n_fine. */
+ * through GnrProblem.z_edges with n_samples = n_coarse + n_fine.
+ * PRECONDITION: every row of coarse_z is ASCENDING (what gnr_sample_zvals produces for world_z1 > world_z2, the
+ * reference's 2.5 / -3.5, with or without jitter).  The kernel MERGES the two sorted lists instead of calling a
+ * general sort (the reference's torch.sort accepts any order); descending rows give undefined z_out.  The
+ * precondition is not checked on the device; gazenerf_amd.importance_resample(..., validate=True) checks it. */
 int gnr_resample(const float* weights, const float* coarse_z, const float* u,
                  int64_t n_rays_total, int32_t n_coarse, int32_t n_fine,
                  float* z_out, void* stream);
@@ -238,6 +255,7 @@ int gnr_set_aux_timing(void* ev_start, void* ev_stop);
  *   merge = max(merge_face, eyes_planes).
  * Maps are channels-first [B, feat_nc, n_pix] (n_pix = featmap_size^2), exactly what gnr_fwd writes. */
 typedef struct GnrMergeProblem {
+    uint32_t struct_size;                    /* = sizeof(GnrMergeProblem) of the caller (ABI 3) */
     int32_t batch, n_pix, feat_nc;           /* feat_nc % 3 == 0 (258 = 3 * 86)                 */
     const float* feat_face;     const float* bg_alpha_face;    /* [B,feat_nc,n_pix], [B,1,n_pix] */
     const float* feat_eyes;     const float* bg_alpha_eyes;
@@ -266,6 +284,7 @@ int gnr_merge_bwd(const GnrMergeProblem* p, const float* g_merge_face, const flo
 enum { GNR_UP_WS_FWD = 0, GNR_UP_WS_BWD = 1 };
 
 typedef struct GnrUpsampleProblem {
+    uint32_t struct_size;           /* = sizeof(GnrUpsampleProblem) of the caller (ABI 3) */
     int32_t batch, feat_nc, featmap_size, n_blocks, min_feat;
     int32_t final_sigmoid;          /* NeuralRenderer(final_actvn=True) in the reference (gaze_nerf.py:115) */
     const float* x;                 /* [B, feat_nc, S, S]; S a power of two >= 16 */

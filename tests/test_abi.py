@@ -31,10 +31,78 @@ def test_binding_matches_header(lib_built):
     for which, cls in enumerate(_lib.STRUCTS):
         assert lib.gnr_sizeof(which) == ctypes.sizeof(cls), cls.__name__
     assert lib.gnr_sizeof(99) == 0
-    assert ctypes.sizeof(_lib.GnrProblem) == 8 * 4 + 2 * 4 + 9 * 8 + 16 + 2 * 8
+    # struct_size + 8 ints + 2 floats (+ pad) + 9 pointers + 3 ints (+ pad) + 2 pointers
+    assert ctypes.sizeof(_lib.GnrProblem) == 4 + 8 * 4 + 2 * 4 + 4 + 9 * 8 + 16 + 2 * 8
     assert ctypes.sizeof(_lib.GnrWeights) == 24 * 8
     assert ctypes.sizeof(_lib.GnrOutputs) == 8 * 8
-    assert ctypes.sizeof(_lib.GnrMergeProblem) == 16 + 6 * 8        # 3 ints (+pad) + 6 pointers
+    assert ctypes.sizeof(_lib.GnrMergeProblem) == 16 + 6 * 8        # struct_size + 3 ints + 6 pointers
+
+
+def test_struct_size_handshake(lib_built):
+    """ABI 3: every entry point that takes a descriptor struct refuses one whose struct_size is not the library's
+    sizeof -- a binder compiled against another header gets an error, never fields read at the wrong offsets."""
+    from gazenerf_amd import _lib
+    lib = _lib.load()
+    p = _lib.GnrProblem()
+    assert p.struct_size == ctypes.sizeof(_lib.GnrProblem) == lib.gnr_sizeof(0)
+    p.batch, p.n_rays, p.n_samples, p.hidden, p.feat_nc = 1, 16, 64, 384, 258
+    p.xy = p.R = p.T = p.Kinv = 1024
+    assert lib.gnr_workspace_bytes(ctypes.byref(p), 2, _lib.WS_FWD) > 0
+    for bad in (0, p.struct_size - 16, p.struct_size + 8):      # unset / the ABI-2 layout before ray_bias / a newer header
+        p.struct_size = bad
+        assert lib.gnr_workspace_bytes(ctypes.byref(p), 2, _lib.WS_FWD) == 0
+        msg = lib.gnr_last_error().decode()
+        assert "struct_size is %d" % bad in msg and "sizeof(GnrProblem) = %d" % lib.gnr_sizeof(0) in msg
+        w = _lib.GnrWeights()
+        o = _lib.GnrOutputs()
+        assert lib.gnr_fwd(ctypes.byref(p), ctypes.byref(w), None, ctypes.byref(o), 0, None, 0, None) != 0
+        assert "struct_size" in lib.gnr_last_error().decode()
+        assert lib.gnr_sample_zvals(ctypes.byref(p), None, None) != 0
+    m = _lib.GnrMergeProblem()
+    m.batch, m.n_pix, m.feat_nc = 1, 64, 258
+    m.feat_face = m.bg_alpha_face = m.feat_eyes = m.bg_alpha_eyes = m.bg_featmap = m.gaze = 1024
+    assert lib.gnr_merge_scratch_bytes(ctypes.byref(m)) > 0
+    m.struct_size = 0
+    assert lib.gnr_merge_scratch_bytes(ctypes.byref(m)) == 0 and b"GnrMergeProblem.struct_size is 0" in lib.gnr_last_error()
+    u = _lib.GnrUpsampleProblem()
+    u.batch, u.feat_nc, u.featmap_size, u.n_blocks, u.min_feat, u.x = 1, 258, 64, 3, 32, 1024
+    assert lib.gnr_upsample_workspace_bytes(ctypes.byref(u), _lib.UP_WS_FWD) > 0
+    u.struct_size = 12
+    assert lib.gnr_upsample_workspace_bytes(ctypes.byref(u), _lib.UP_WS_FWD) == 0
+    assert b"GnrUpsampleProblem.struct_size is 12" in lib.gnr_last_error()
+    # declaring view-direction columns without the per-ray bias that carries them is an error, not a silent drop
+    p = _lib.GnrProblem()
+    p.batch, p.n_rays, p.n_samples, p.hidden, p.feat_nc, p.vd_dims = 1, 16, 64, 384, 258, 27
+    p.xy = p.R = p.T = p.Kinv = 1024
+    assert lib.gnr_workspace_bytes(ctypes.byref(p), 1, _lib.WS_FWD) == 0 and b"ray_bias[0] is NULL" in lib.gnr_last_error()
+
+
+def test_integration_stub_matches_the_library(lib_built):
+    """INTEGRATION.md section 4 shows the raw ctypes stub a maintainer would paste into the reference.  Execute its
+    declarations against the built library: the struct layouts must equal gnr_sizeof(), the stale-size error must fire."""
+    import sys
+    import types
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("## 4. Raw ctypes stub"):]
+    code = re.search(r"```python\n(.*?)```", sec, flags=re.S).group(1)
+    code = code.replace('C.CDLL("libgnr.so")', "C.CDLL(%r)" % lib_built)
+    ns = {}
+    exec(compile(code, "INTEGRATION.md#4", "exec"), ns)         # runs the stub's own load-time asserts
+    from gazenerf_amd import _lib
+    for name in ("GnrProblem", "GnrWeights", "GnrOutputs"):
+        mine, theirs = getattr(_lib, name), ns[name]
+        assert [(n, ctypes.sizeof(t)) for n, t in mine._fields_] == [(n, ctypes.sizeof(t)) for n, t in theirs._fields_], name
+        assert ctypes.sizeof(mine) == ctypes.sizeof(theirs)
+
+    class FakeTensor:                       # shape + data_ptr is all problem() touches
+        def __init__(self, *shape): self.shape = shape
+        def data_ptr(self): return 4096
+    p = ns["problem"](FakeTensor(2, 2, 64), FakeTensor(2, 3, 3), FakeTensor(2, 3, 1), FakeTensor(2, 3, 3),
+                      FakeTensor(2, 179), FakeTensor(2, 2), FakeTensor(2, 127))
+    lib = ns["lib"]
+    assert lib.gnr_workspace_bytes(ctypes.byref(p), 2, 0) > 0, lib.gnr_last_error()
+    p.struct_size -= 8
+    assert lib.gnr_workspace_bytes(ctypes.byref(p), 2, 0) == 0 and b"struct_size" in lib.gnr_last_error()
 
 
 def test_validation_errors_without_gpu(lib_built):

@@ -52,3 +52,40 @@ def test_bench_flop_constant_matches_survey():
     # RGB1 384*192, RGB2 192*258
     macs = 63 * 384 + 4 * 384 * 384 + (63 + 384) * 384 + 2 * 384 * 384 + 384 + 384 * 384 + 384 * 192 + 192 * 258
     assert macs == 1351680 and bench.FLOP_PER_SAMPLE_STREAM == 2 * macs
+
+
+def test_packed_weight_cache_invalidation():
+    """render.PackedWeightCache (round-2 advice): a reallocated workspace must forget its key at once (a call that
+    raises before store() must not leave the OLD key describing the NEW buffer), and the key includes data_ptr."""
+    import torch
+    from gazenerf_amd import render
+    c = render.PackedWeightCache()
+    params = [torch.zeros(4), torch.zeros(3)]
+    k1, k2 = ("fp32", 1, torch.device("cpu")), ("fp32", 2, torch.device("cpu"))
+    ws, hit = c.lookup(256, k1, params)
+    assert not hit
+    c.store(k1, params)
+    assert c.lookup(256, k1, params) == (ws, True)
+    ws2, hit = c.lookup(512, k2, params)          # other shape: new buffer ...
+    assert not hit and ws2 is not ws
+    # ... and the call "raised" before store(): the next call with the FIRST shape must not hit on the new buffer
+    ws3, hit = c.lookup(256, k1, params)
+    assert not hit
+    c.store(k1, params)
+    assert c.lookup(256, k1, params)[1]
+    params[0].add_(1.0)                           # in-place write bumps _version
+    assert not c.lookup(256, k1, params)[1]
+    c.store(k1, params)
+    params[1].data = torch.ones(3)                # .data swap keeps _version, moves data_ptr
+    assert not c.lookup(256, k1, params)[1]
+
+
+def test_hot_path_renderer_drops_its_caches_when_parameters_can_change():
+    import torch
+    from gazenerf_amd import HotPathRenderer
+    net = HotPathRenderer()
+    for poke in (lambda: net.train(), lambda: net.eval(), lambda: net.float(),
+                 lambda: net.load_state_dict(net.state_dict())):
+        net._wcache.shape_key, net._wcache.ws = ("x",), torch.zeros(1)
+        poke()
+        assert net._wcache.ws is None and net._wcache.shape_key is None

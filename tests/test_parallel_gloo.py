@@ -143,3 +143,53 @@ def test_whole_network_buckets_cover_all_trainable_floats():
     assert red.n_buckets == 3 and red.bytes_per_step == 4 * 5015714
     assert sum(q.numel() for q in groups["neural_render."]) == 1977756
     assert len(red.params) == len(list(net.parameters()))
+
+
+def _accumulation_case(rank, world):
+    """Two backward passes (gradient accumulation) and a backward aborted half-way before ONE all_reduce(): the
+    exchange must carry the accumulated gradients, and every rank must issue the same collectives (round-2 advice:
+    the hook counters went negative and a stale flat copy overwrote the later micro-batch's gradients)."""
+    a = [torch.nn.Parameter(torch.ones(5)), torch.nn.Parameter(torch.ones(3, 2))]
+    b = [torch.nn.Parameter(torch.ones(4))]
+    red = parallel.GradAllReducer([a, b], world)
+    red.arm_overlap()
+    rs = [r + 1.0 for r in range(world)]
+
+    def loss(scale):
+        x = (b[0] * (rank + 1.0)).sum()
+        return ((a[0] * x).sum() + (a[1] * 2.0 * (rank + 1.0)).sum()) * scale
+
+    ok = True
+    # (1) accumulation: micro-batches with scales 1 and 3, one exchange
+    loss(1.0).backward()
+    loss(3.0).backward()
+    red.all_reduce()
+    ok = ok and torch.allclose(a[0].grad, torch.full((5,), sum(4.0 * r * 4.0 for r in rs) / world))
+    ok = ok and torch.allclose(a[1].grad, torch.full((3, 2), sum(2.0 * r * 4.0 for r in rs) / world))
+    ok = ok and torch.allclose(b[0].grad, torch.full((4,), sum(5.0 * r * 4.0 for r in rs) / world))
+    ok = ok and red.relaunched == 2 and not red._inflight
+    # (2) a backward that dies after bucket 0 has only been partly counted, then a clean step
+    for p in a + b:
+        p.grad = None
+    red._make_hook(0)(a[0])                   # what an aborted backward leaves behind: one of two hooks fired
+    loss(2.0).backward()
+    red.all_reduce()
+    ok = ok and torch.allclose(a[0].grad, torch.full((5,), sum(4.0 * r * 2.0 for r in rs) / world))
+    ok = ok and torch.allclose(b[0].grad, torch.full((4,), sum(5.0 * r * 2.0 for r in rs) / world))
+    # (3) begin_step() drops an exchange nobody collected
+    for p in a + b:
+        p.grad = None
+    loss(1.0).backward()
+    red.begin_step()
+    ok = ok and not red._inflight
+    for p in a + b:
+        p.grad = None
+    loss(5.0).backward()
+    red.all_reduce()
+    ok = ok and torch.allclose(b[0].grad, torch.full((4,), sum(5.0 * r * 5.0 for r in rs) / world))
+    return bool(ok)
+
+
+def test_gradient_accumulation_and_aborted_backward_two_ranks():
+    res = _run(_accumulation_case)
+    assert res == {0: True, 1: True}

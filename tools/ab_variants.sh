@@ -1,0 +1,15 @@
+#!/bin/bash
+# Timing experiments on the GPU box: rebuild the named kernels with extra -D switches, run the bench once, keep its line.
+# usage: tools/ab_variants.sh <tag> "<files,comma>" "<flags>" [bench args]      (results may be WRONG with timing switches)
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=$1; FILES=$2; FLAGSX=$3; shift 3
+mkdir -p $R/gpurun_out/ab
+cd $R
+GNR_EXTRA_FILES="$FILES" GNR_EXTRA_HIPCC_FLAGS="$FLAGSX" python -m gazenerf_amd.build --no-torch-ext > gpurun_out/ab/$TAG.build.log 2>&1
+python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt "$@" 2> gpurun_out/ab/$TAG.err | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('$TAG', 'ms_per_step', round(d['ms_per_step'],1), ' '.join('%s %.3f ms (%.3f)' % (s['stage'], s['avg_ms'], s['frac']) for s in d.get('stages', [])))
+" | tee -a gpurun_out/ab/summary.txt
