@@ -12,6 +12,9 @@ streams) over the 512x512-ray, 64-samples-per-ray render of one image per GPU (S
 SURVEY.md 8(a) A8 is a sum over rays, so the image is processed as ``--micro``-ray micro-batches (forward-with-save,
 loss, backward each; gradients accumulate; ONE all-reduce per step when N > 1) -- nothing is recomputed.  N > 1:
 every rank renders its own image (images are sharded, no data-path collective in forward): weak scaling.
+``--scaling strong`` (the reference's B=1 render loop, utils/render_utils.py:199-219): ONE image, its
+rays sharded over the ranks in contiguous row blocks (``parallel.shard_rays``), value = rays of that one image per
+second; ``--gather`` adds the all_gather that hands rank 0 the full feature maps (``parallel.gather_rays``).
 
 cfg4: the reference's training step -- B=2 images per rank at featmap_size=64 through the WHOLE
 network (hot path -> merge -> upsampler x4 -> image loss), backward, all-reduce of all 5 015 714 trainable floats
@@ -65,7 +68,12 @@ def parse():
                          "3-term hi/lo split (fp32 accumulate)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16x3 leg of an fp32 run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=45.0, help="seconds of CPU-baseline work (wall cap)")
+    ap.add_argument("--cpu-budget", type=float, default=90.0, help="seconds of CPU-baseline work (wall cap)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("GNR_BENCH_SCALING", "weak"),
+                    help="cfg2b: weak = one image per GPU; strong = ONE image, rays sharded over the GPUs")
+    ap.add_argument("--gather", action="store_true", help="strong scaling, fwd: all_gather the feature maps to every rank inside the step")
+    ap.add_argument("--no-one-call", action="store_true", help="skip the extra timing of the one-call (in-op tiled) training path")
+    ap.add_argument("--pg-timeout", type=float, default=180.0, help="seconds before a stuck rendezvous / collective aborts")
     return ap.parse_args()
 
 
@@ -109,8 +117,8 @@ def available_cores():
 def cpu_baseline(mode, n_samples, budget_s):
     """The oracle on this host's cores (SURVEY.md 8(d) CPU-baseline plan (ii)): BASELINE cfg2a -- one 64x64-ray image,
     64 samples, both streams, what the reference renders per 512x512 image -- at every core the process may use and
-    at one thread, median of 3 where the wall cap allows.  The workload shrinks (rays, then repeats) to stay inside
-    ``budget_s``: the full 4096-ray image forward+backward takes ~25 s per run at 16 cores."""
+    at one thread (1024 rays), median of 3 where the wall cap allows.  The workload shrinks (rays, then repeats) to stay
+    inside ``budget_s``: the full 4096-ray image forward+backward takes ~17 s per run at 16 cores."""
     import torch
     from gazenerf_amd import synth
     from oracle import oracle as O
@@ -143,15 +151,15 @@ def cpu_baseline(mode, n_samples, budget_s):
         fn()
         return time.perf_counter() - t0
 
-    def leg(threads, budget):
-        """-> (rays/s, rays, runs, seconds per run).  Probe on 128 rays, then the largest power-of-two ray count
-        <= 4096 whose three runs fit the budget (at least one run)."""
+    def leg(threads, budget, n_want):
+        """-> (rays/s, rays, runs, seconds per run).  Probe on 128 rays, then ``n_want`` rays (halved until three runs fit
+        the budget; at least one run), median of up to three runs."""
         torch.set_num_threads(threads)
         t_start = time.perf_counter()
         probe = make(128)
         probe()                                       # warm-up: thread pool, oneDNN primitives, allocator
         per_ray = timed(probe) / 128
-        n = 4096
+        n = n_want
         while n > 128 and 3.2 * n * per_ray > budget - (time.perf_counter() - t_start):
             n //= 2
         one = make(n)
@@ -162,14 +170,15 @@ def cpu_baseline(mode, n_samples, budget_s):
         med = times[len(times) // 2]
         return n / med, n, len(times), med
 
-    v_all, n_all, r_all, s_all = leg(cores, 0.65 * budget_s)
+    # cfg2a (4096 rays) x 3 at every core, 1024 rays x 3 at one thread (the reference pins itself to 1)
+    v_all, n_all, r_all, s_all = leg(cores, 0.62 * budget_s, 4096)
     res = {"value": v_all, "unit": "rays/s", "cores": cores, "kind": "port", "host_logical_cpus": os.cpu_count(),
            "cores_basis": cores_basis,
            "sample": "cfg2a subset: %d of 4096 rays x %d samples, both streams, %s; median of %d run(s) of %.2f s at "
                      "torch.set_num_threads(%d) = every core this process may use (%s); PyTorch-CPU oracle pinned to the "
                      "reference by tests/golden; wall cap %.0f s" % (n_all, n_samples, mode, r_all, s_all, cores, cores_basis, budget_s)}
     # the reference pins itself to ONE thread (train.py / gazenerf_trainer: torch.set_num_threads(1))
-    v1, n1, r1, s1 = leg(1, 0.35 * budget_s)
+    v1, n1, r1, s1 = leg(1, 0.38 * budget_s, 1024)
     res["value_1_thread"] = v1
     res["sample_1_thread"] = "%d rays, %d run(s) of %.2f s" % (n1, r1, s1)
     torch.set_num_threads(cores)
@@ -197,6 +206,14 @@ def mean(xs):
     return sum(xs) / len(xs) if xs else 0.0
 
 
+def chain_suffix(x3):
+    """Kernel-name infix of the dense-chain kernels: bf16x3 -> "3"; fp32 -> "16" (v_mfma_f32_16x16x4_f32, two waves per
+    SIMD: gnr_chain16.h) unless GNR_CHAIN32=1 selects round 2's 32x32x2 kernels."""
+    if x3:
+        return "3"
+    return "" if os.environ.get("GNR_CHAIN32", "")[:1] == "1" else "16"
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -211,27 +228,59 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the render op)")
     # GNR_BENCH_DEVICE: test-only override (several ranks on one device to exercise the launcher path)
     dev_index = int(os.environ.get("GNR_BENCH_DEVICE", local_rank))
+    # pre-flight: one line instead of a HIP "invalid device ordinal" from somewhere inside rank k
+    n_dev = torch.cuda.device_count()
+    if dev_index >= n_dev:
+        raise SystemExit("bench.py: rank %d needs GPU %d but this node exposes %d device(s) (--gpus %d, one rank per GPU)"
+                         % (rank, dev_index, n_dev, args.gpus))
+    if args.scaling == "strong" and args.config != "cfg2b":
+        raise SystemExit("bench.py: --scaling strong shards the rays of ONE cfg2b image; cfg4 shards images (weak)")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
     backend = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # backend "nccl" is RCCL on ROCm; GNR_BENCH_BACKEND=gloo is a test-only override (two ranks on
-        # one GPU cannot form an RCCL communicator)
-        backend = os.environ.get("GNR_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    ctx = dict(args=args, rank=rank, world=world, dev=dev, dist=dist, backend=backend, torch=torch)
-    res = run_cfg4(ctx) if args.config == "cfg4" else run_cfg2b(ctx)
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.mode if args.config == "cfg2b" else "fwdbwd", 64 if args.config == "cfg4" else args.samples,
-                                               args.cpu_budget)
-        print(json.dumps(res), flush=True)
+    try:
+        if world > 1:
+            import datetime
+
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC only on this driver (RCCL needs it)
+            # backend "nccl" is RCCL on ROCm; GNR_BENCH_BACKEND=gloo is a test-only override (two ranks on
+            # one GPU cannot form an RCCL communicator)
+            backend = os.environ.get("GNR_BENCH_BACKEND", "nccl")
+            timeout = datetime.timedelta(seconds=args.pg_timeout)      # a rank that never arrives fails the job, not hangs it
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=timeout)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world, timeout=timeout)
+            # first collective right here: a communicator that cannot form (IPC, topology, a dead peer) fails in
+            # pre-flight with the rank's message, before any workload has been built
+            probe = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(probe)
+            if int(probe.item()) != world:
+                raise RuntimeError("pre-flight all-reduce returned %s, expected %d" % (probe.item(), world))
+        ctx = dict(args=args, rank=rank, world=world, dev=dev, dist=dist, backend=backend, torch=torch)
+        res = run_cfg4(ctx) if args.config == "cfg4" else run_cfg2b(ctx)
+        if rank == 0:
+            if world > 1:
+                res["distributed"] = {"backend": backend, "world_size_formed": dist.get_world_size(),
+                                      "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None,
+                                      "devices_visible": n_dev}
+            if world == 1 and not args.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline(args.mode if args.config == "cfg2b" else "fwdbwd", 64 if args.config == "cfg4" else args.samples,
+                                                   args.cpu_budget)
+            print(json.dumps(res), flush=True)
+    except BaseException as e:            # noqa: BLE001 -- every failure of a rank must end the job with ITS message
+        if isinstance(e, SystemExit) and e.code in (0, None):
+            raise
+        import traceback
+        sys.stderr.write("bench.py: rank %d of %d failed: %s: %s\n" % (rank, world, type(e).__name__, e))
+        traceback.print_exc()
+        sys.stderr.flush()
+        # no destroy_process_group here: it would wait for peers that are stuck in a collective with us; a non-zero exit
+        # makes torch.distributed.run tear the other ranks down
+        os._exit(1)
     if dist:
         dist.destroy_process_group()
 
@@ -310,18 +359,24 @@ def run_cfg2b(ctx):
     n_rays = side * side
     fwdbwd = args.mode == "fwdbwd"
     to = lambda d: {k: v.to(dev) for k, v in d.items()}
-    p = to(synth.synth_problem(side, batch=1, camera=str(3 + rank), seed=100 + rank))
+    strong = args.scaling == "strong"
+    # weak: every rank its own image (camera / codes by rank); strong: the SAME image on every rank, rays sharded
+    p = to(synth.synth_problem(side, batch=1, camera="3" if strong else str(3 + rank), seed=100 if strong else 100 + rank))
+    if strong:
+        from gazenerf_amd import parallel
+        p["xy"] = parallel.shard_rays(p["xy"], rank, world)          # contiguous row blocks of the side x side grid
+    n_local = p["xy"].shape[2]
     face = to(synth.hash_mlp_params("face", seed=0, density_scale=50.0))
     eyes = to(synth.hash_mlp_params("eyes", seed=0, density_scale=50.0))
     plist = [face[k] for k in render.PARAM_ORDER] + [eyes[k] for k in render.PARAM_ORDER]
     leaves = [p[k] for k in ("R", "T", "shape_code", "gaze", "appea_code")]
-    micro = min(args.micro, n_rays)
+    micro = min(args.micro, n_local)
     t_rand = synth.synth_jitter(1, micro, n_p, seed=7).to(dev) if fwdbwd else None
     reducer = GradAllReducer([plist[:24], plist[24:]], world) if fwdbwd else None
     clock = AllReduceClock(torch)
     timers = {k: StageTimer(k, pool=128) for k in (("fwd_mlp", "dgrad", "comp_bwd", "wgrad") if fwdbwd else ("fwd_mlp",))}
     if fwdbwd:
-        xy_tiles = [p["xy"][:, :, r0:r0 + micro].contiguous() for r0 in range(0, n_rays, micro)]
+        xy_tiles = [p["xy"][:, :, r0:r0 + micro].contiguous() for r0 in range(0, n_local, micro)]
 
     def reset(keep):
         for t in timers.values():
@@ -332,8 +387,12 @@ def run_cfg2b(ctx):
         if not fwdbwd:
             with torch.no_grad():
                 timers["fwd_mlp"].arm()
-                render.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"],
-                                         p["appea_code"], face, eyes, n_samples=n_p, precision=precision)
+                out = render.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"],
+                                               p["appea_code"], face, eyes, n_samples=n_p, precision=precision)
+                if strong and args.gather and world > 1:
+                    # one rank (here: every rank) wants the whole map: all_gather of the [C, N_r / world] slices
+                    for k in ("feat_face", "bg_alpha_face", "feat_eyes", "bg_alpha_eyes"):
+                        parallel.gather_rays(out[k], n_rays, world)
             return
         for t in plist + leaves:
             t.requires_grad_(True)
@@ -362,6 +421,46 @@ def run_cfg2b(ctx):
         return dt, stage_ms, info, probe.mhz()
 
     dt, stage_ms, ar, clocks = leg(args.precision)
+    one_call = None
+    if fwdbwd and world == 1 and not args.no_one_call and n_local > micro:
+        # What a caller of GazeNeRFNetAMD(featmap_size=512) gets: ONE render_two_stream call for the whole image.  Its
+        # saved activations (540 GB) exceed the workspace budget, so the op tiles the rays itself: an inference forward
+        # of the whole image, then per tile forward-with-save + backward = 4/3 of the FLOPs of the micro-batched
+        # loop above (which keeps each micro-batch's activations until its own backward).  Timed, never the headline.
+        t_full = synth.synth_jitter(1, n_local, n_p, seed=7).to(dev)
+        import ctypes
+
+        from gazenerf_amd import _lib
+        q = _lib.GnrProblem()
+        q.batch, q.n_rays, q.n_samples, q.hidden, q.feat_nc = 1, n_local, n_p, 384, 258
+        q.xy = q.R = q.T = q.Kinv = 1                      # sizes only: checked for NULL, never dereferenced
+        saved = _lib.load().gnr_workspace_bytes(ctypes.byref(q), 2, _lib.WS_FWD_SAVE)
+        tiled = saved > render.DEFAULT_WS_BUDGET           # the op's own rule (render.plan_ray_tiles)
+
+        def call():
+            for t in plist + leaves:
+                t.requires_grad_(True)
+                t.grad = None
+            out = render.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"], p["appea_code"],
+                                           face, eyes, n_samples=n_p, t_rand=t_full, precision=args.precision)
+            sum((out["feat_" + t] ** 2).mean() + out["bg_alpha_" + t].mean() for t in ("face", "eyes")).backward()
+
+        call()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            call()
+        torch.cuda.synchronize()
+        oc = (time.perf_counter() - t0) / 2
+        one_call = {"ms_per_step": oc * 1e3, "value": n_local / oc, "unit": "rays/s", "calls_timed": 2,
+                    "tiled_in_op": bool(tiled), "saved_activation_bytes_untiled": int(saved),
+                    "workspace_budget_bytes": int(render.DEFAULT_WS_BUDGET),
+                    "flop_factor_vs_step": 4.0 / 3.0 if tiled else 1.0,
+                    "achieved_tflops_executed": (4 if tiled else 3) * n_local * n_p * 2 * FLOP_PER_SAMPLE_STREAM / oc / 1e12,
+                    "note": "one render_two_stream call + backward for the whole %dx%d-ray image; when the saved activations exceed "
+                            "the workspace budget the op tiles the rays itself (inference forward once, then forward-with-save + "
+                            "backward per tile = 4/3 of the step's FLOPs)" % (side, side)}
+        del t_full
     alt = None
     if args.precision == "fp32" and not args.no_alt:
         alt = leg("bf16x3")            # second, separately timed leg on the bf16x3 kernels (never the headline)
@@ -372,12 +471,12 @@ def run_cfg2b(ctx):
         x3 = precision == "bf16x3"
         peak = PEAK_BF16X3_TFLOPS if x3 else PEAK_FP32_MFMA_TFLOPS
         ms = dt / args.steps * 1e3
-        rays_per_launch = micro if fwdbwd else n_rays
+        rays_per_launch = micro if fwdbwd else n_local
         m = rays_per_launch * n_p                                  # samples per launch (per stream)
         flop_2s = m * 2 * FLOP_PER_SAMPLE_STREAM                   # both streams, one pass
         flop_1s = m * FLOP_PER_SAMPLE_STREAM
-        launches_per_step = (n_rays + micro - 1) // micro if fwdbwd else 1
-        sfx = "3" if x3 else ""
+        launches_per_step = (n_local + micro - 1) // micro if fwdbwd else 1
+        sfx = chain_suffix(x3)
         save = "true" if fwdbwd else "false"
         defs = [("fwd_mlp", "forward%s: march + encode + 2-stream MLP + composite" % (" with activation save" if fwdbwd else ""),
                  "gnr::fwd%s_kernel<%s>" % (sfx, save), flop_2s, 1)]
@@ -410,7 +509,7 @@ def run_cfg2b(ctx):
                            "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "avg_ms": a, "launches_timed": len(stage_ms["comp_bwd"]),
                            "bytes_per_launch": nbytes, "traffic": tr, "traffic_source": src,
                            "share_of_step": a * 2 * launches_per_step / ms})
-        step_flop = (3 if fwdbwd else 1) * n_rays * n_p * 2 * FLOP_PER_SAMPLE_STREAM
+        step_flop = (3 if fwdbwd else 1) * n_local * n_p * 2 * FLOP_PER_SAMPLE_STREAM      # this rank's share
         step_ach = step_flop / (ms * 1e-3) / 1e12
         return ms, stages, step_ach, rays_per_launch
 
@@ -422,16 +521,20 @@ def run_cfg2b(ctx):
     traffic, traffic_src = pmc_traffic(dom["kernel"].split(" + ")[0], rays_per_launch, n_p)
     res = {
         "metric": "rays/sec (512x512, 64 samples/ray) %s" % ("fwd+bwd" if fwdbwd else "fwd"),
-        "value": world * n_rays * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": (1 if strong else world) * n_rays * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "bf16x3 (3-term hi/lo split on bf16 MFMA, f32 accumulate)" if x3 else "f32", "data": "synthetic",
-        "config": {"workload": "%s: %dx%d rays x %d samples/ray, two streams (face+eyes), %s, 1 image per GPU%s" % (
+        "config": {"workload": "%s: %dx%d rays x %d samples/ray, two streams (face+eyes), %s, %s%s" % (
                        "cfg2b" if (side, n_p) == (512, 64) else "custom", side, side, n_p, args.mode,
+                       "ONE image, its rays sharded over the GPUs in contiguous row blocks" if strong else "1 image per GPU",
                        ", %d-ray micro-batches (the loss is a sum over rays: nothing recomputed)" % micro if fwdbwd else ""),
-                   "rays_per_step_per_gpu": n_rays, "samples_per_ray": n_p,
-                   "parallelism": "dp%d (images sharded; one gradient all-reduce per step, no overlap: the gradients "
-                                  "of both MLPs leave the last micro-batch's backward together)" % world if fwdbwd
-                                  else "dp%d (images sharded, no collective)" % world,
+                   "rays_per_step_per_gpu": n_local, "samples_per_ray": n_p,
+                   "parallelism": (("rays%d (one image, ray blocks sharded; %s)" % (world, "one gradient all-reduce per step" if fwdbwd else
+                                    ("all_gather of the four output maps inside the step" if args.gather else "no collective: every rank keeps its slice")))
+                                   if strong else
+                                   ("dp%d (images sharded; one gradient all-reduce per step, no overlap: the gradients "
+                                    "of both MLPs leave the last micro-batch's backward together)" % world if fwdbwd
+                                    else "dp%d (images sharded, no collective)" % world)),
                    "precision": args.precision},
         "roofline": {"bound": "mfma", "kernel": dom["kernel"], "stage": dom["stage"], "achieved": dom["achieved"], "peak": peak,
                      "unit": "TFLOP/s",
@@ -453,6 +556,8 @@ def run_cfg2b(ctx):
         res["roofline_hbm"] = hbm[0]
     if ar:
         res["allreduce"] = ar
+    if one_call is not None:
+        res["one_call"] = one_call
     if alt is not None:
         adt, ams, _, aclk = alt
         a_ms, a_stages, a_step, _ = describe("bf16x3", adt, ams, aclk)
@@ -463,7 +568,7 @@ def run_cfg2b(ctx):
                     "1e-4 of the reference (<= 6e-6 on the fixtures); against fp64 as close to exact as the "
                     "reference's own fp32 run; gradients inside the reference's fp32-vs-fp64 noise "
                     "(tests/test_parity_gpu.py, DESIGN.md section 4)",
-            "value": world * n_rays * args.steps / adt, "unit": "rays/s", "ms_per_step": a_ms,
+            "value": (1 if strong else world) * n_rays * args.steps / adt, "unit": "rays/s", "ms_per_step": a_ms,
             "speedup_vs_fp32": dt / adt,
             "roofline": {"bound": "mfma", "kernel": a_dom["kernel"], "achieved": a_dom["achieved"], "peak": PEAK_BF16X3_TFLOPS,
                          "unit": "TFLOP/s", "peak_basis": "dense bf16 MFMA peak (16 x 157.3) / 3 terms; fp32-equivalent FLOPs",
@@ -537,7 +642,7 @@ def run_cfg4(ctx):
     x3 = args.precision == "bf16x3"
     peak = PEAK_BF16X3_TFLOPS if x3 else PEAK_FP32_MFMA_TFLOPS
     m = B * n_rays * n_p
-    sfx = "3" if x3 else ""
+    sfx = chain_suffix(x3)
     stages = []
     for key, kernel, flop, mult in (("fwd_mlp", "gnr::fwd%s_kernel<true>" % sfx, m * 2 * FLOP_PER_SAMPLE_STREAM, 1),
                                     ("dgrad", "gnr::bwd%s_chain_kernel" % sfx, m * FLOP_PER_SAMPLE_STREAM, 2),

@@ -77,7 +77,12 @@ __device__ __forceinline__ void enc_backward16(const f32x4 (&E)[NT16_H], const f
 
 __device__ __forceinline__ void apply_relu16(f32x4& acc, unsigned word, int t) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] = ((word >> (4 * (t & 7) + e)) & 1u) ? acc[e] : 0.0f;
+    for (int e = 0; e < 4; ++e) {
+        // bit -> all-ones / zero mask (v_bfe_i32), then one v_and_b32 on the bit pattern: 2 VALU per value
+        const int m = (int)(word << (4 * (t & 7) + e)) >> 31;
+        const float a = acc[e];
+        acc[e] = __builtin_bit_cast(float, __builtin_bit_cast(int, a) & m);
+    }
 }
 
 __global__ __launch_bounds__(256, 2) void bwd16_chain_kernel(const BwdParams bp) {
@@ -115,22 +120,23 @@ __global__ __launch_bounds__(256, 2) void bwd16_chain_kernel(const BwdParams bp)
         for (int q = 0; q < RELU16_WORDS; ++q)
             if (q < words) mk[q] = src[q * 64 + lane];
     };
-    auto dyh = [&](int l) { return dump_dst16(bp.dY_h + l * M * H, H, sub, j, g); };
+    const unsigned lane_off = dump_lane_off16(sub, j, g);
+    auto dyh = [&](int l) { return dump_dst16(bp.dY_h + l * M * H, H, sub, lane_off); };
     auto none = [](int) {};
     // Each mm16_h dumps ITS INPUT (the dY of the layer above) while its MFMAs run; accumulators start from a zero
     // C operand; the ReLU mask of each output tile is applied in the loop tail.
 #define GNR_MASK(X) [&](int t) { apply_relu16(X[t], mk[t >> 3], t); }
     // RGB2^T: A(18) -> Bv(12), mask y1 > 0            (dumps dfeat)
     bits(8, 2);
-    mm16_h<NT16_F, NT16_H2, true, true>(A, Bv, w, dump_dst16(bp.dfeat, FEAT_PAD, sub, j, g), ZeroInit16(), GNR_MASK(Bv));
+    mm16_h<NT16_F, NT16_H2, true, true>(A, Bv, w, dump_dst16(bp.dfeat, FEAT_PAD, sub, lane_off), ZeroInit16(), GNR_MASK(Bv));
     // RGB1^T: Bv(12) -> A(24), no activation on y0    (dumps dY_r1)
-    mm16_h<NT16_H2, NT16_H, true, true>(Bv, A, w, dump_dst16(bp.dY_r1, H2, sub, j, g), ZeroInit16(), none);
+    mm16_h<NT16_H2, NT16_H, true, true>(Bv, A, w, dump_dst16(bp.dY_r1, H2, sub, lane_off), ZeroInit16(), none);
     // RGB0^T: A -> Bv, + density head, mask h7        (dumps dY_r0)
     bits(7, 3);
     {
         const float ds = bp.dsig[row];
         const float* wsg = bp.wsig + 4 * g;
-        mm16_h<NT16_H, NT16_H, true, true>(A, Bv, w, dump_dst16(bp.dY_r0, H, sub, j, g), ZeroInit16(), [&](int t) {
+        mm16_h<NT16_H, NT16_H, true, true>(A, Bv, w, dump_dst16(bp.dY_r0, H, sub, lane_off), ZeroInit16(), [&](int t) {
             const f32x4 w4 = *(const f32x4*)(wsg + 16 * t);
 #pragma unroll
             for (int e = 0; e < 4; ++e) Bv[t][e] = fmaf(w4[e], ds, Bv[t][e]);

@@ -104,20 +104,31 @@ constexpr int WB16 = 4;
 constexpr int DUMP_BURST = GNR_DUMP_BURST;      // dump stores per burst (1 = one store every NROW / NREG rows)
 struct WStream16 {
     __amdgpu_buffer_rsrc_t rs;
-    unsigned voff;               // lane * 16 + byte offset of the batch most recently requested
+    unsigned voff;               // lane * 16 (constant)
+    unsigned soff;               // byte offset of the batch most recently requested: wave-uniform, so the per-batch
+                                 // increment is a scalar instruction (as a VGPR offset it was one v_add per 16 MFMAs)
     f32x4 g[2][WB16];
 };
 
 template <int Q>
 __device__ __forceinline__ f32x4 wrow16(const WStream16& w) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.voff + (unsigned)Q * 1024u, 0, 0));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w.rs, w.voff + (unsigned)Q * 1024u, (int)w.soff, 0));
 }
 __device__ __forceinline__ void wbatch16(WStream16& w, f32x4 (&g)[WB16]) {
     g[0] = wrow16<0>(w); g[1] = wrow16<1>(w); g[2] = wrow16<2>(w); g[3] = wrow16<3>(w);
 }
+// (plain C: the fully unrolled chain turns the running offset into per-batch scalar constants; hipcc keeps ~300 of
+// them live and spills those through v_writelane / v_readlane -- ~600 VALU instructions per kernel against the 1150
+// v_add of a VGPR offset.  Making the value opaque with an asm, even an empty one, costs thousands of VGPR spills.)
+#ifdef GNR_VOFF_STREAM      // A/B switch: the running offset in the VGPR (one v_add per batch)
+__device__ __forceinline__ void wadvance16(WStream16& w) { w.voff += WB16 * 1024u; }
+#else
+__device__ __forceinline__ void wadvance16(WStream16& w) { w.soff += WB16 * 1024u; }
+#endif
 __device__ __forceinline__ void wstream16_init(WStream16& w, const float* packed, int lane) {
     w.rs = __builtin_amdgcn_make_buffer_rsrc((void*)packed, 0, 0x7ffffff0, 0x00020000);
     w.voff = (unsigned)lane * 16u;
+    w.soff = 0;
     wbatch16(w, w.g[0]);
 }
 
@@ -132,10 +143,13 @@ struct Dump16 {
     __amdgpu_buffer_rsrc_t rs;
     unsigned voff;
 };
-__device__ __forceinline__ Dump16 dump_dst16(float* dst, int C, long sub, int j, int g) {
+__device__ __forceinline__ unsigned dump_lane_off16(long sub, int j, int g) {
+    return (unsigned)((4 * g) * CHUNK + 16 * (int)(sub & 1) + j) * 4u;
+}
+__device__ __forceinline__ Dump16 dump_dst16(float* dst, int C, long sub, unsigned lane_off) {
     Dump16 d;
     d.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(dst + (sub >> 1) * (CHUNK * (long)C)), 0, 0x7ffffff0, 0x00020000);
-    d.voff = (unsigned)((4 * g) * CHUNK + 16 * (int)(sub & 1) + j) * 4u;
+    d.voff = lane_off;
     return d;
 }
 // element offset (floats, compile-time) -> nontemporal dword store
@@ -145,11 +159,14 @@ __device__ __forceinline__ void dump_store16(const Dump16& d, int elem, T v) {
 #ifdef GNR_NODUMP_TIMING            // timing experiment only: results are incomplete
     (void)d; (void)elem; (void)v;
 #else
-    const unsigned byte = (unsigned)elem * 4u;
+    // scalar part: whole 16-channel tiles (2 KiB); immediate: the register within the tile (e * 128 B).  With the low
+    // 12 bits as the immediate hipcc CSEs "lane offset + immediate" over all layers and keeps the 32 sums in VGPRs
+    // (every store with its own address register, none with the offset field): 32 registers the chain does not have.
+    const unsigned byte = (unsigned)elem * 4u, lo = byte & 2047u, hi = byte & ~2047u;
 #ifdef GNR_TEMPORAL_DUMP_TIMING
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), d.rs, d.voff + (byte & 4095u), (int)(byte & ~4095u), 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), d.rs, d.voff + lo, (int)hi, 0);
 #else
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), d.rs, d.voff + (byte & 4095u), (int)(byte & ~4095u), 2);   // aux 2 = nt
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), d.rs, d.voff + lo, (int)hi, 2);   // aux 2 = nt
 #endif
 #endif
 }
@@ -177,7 +194,7 @@ __device__ __forceinline__ void mm16_h(const f32x4 (&hin)[NT16_H], f32x4 (&acc)[
 #pragma clang loop unroll(full)
     for (int kbi = 0; kbi < 2; ++kbi) {
         const int kb = kbo * 2 + kbi;
-        w.voff += WB16 * 1024u;
+        wadvance16(w);
         wbatch16(w, w.g[(kb + 1) & 1]);
         if (!DUMP) wait_vm<WB16>();
         __builtin_amdgcn_sched_barrier(0);
@@ -218,7 +235,7 @@ __device__ __forceinline__ void mm16_enc(const float* enc_col, f32x4 (&acc)[NT16
     float ev[4] = {0, 0, 0, 0};
 #pragma clang loop unroll(full)
     for (int kb = 0; kb < NB; ++kb) {
-        w.voff += WB16 * 1024u;
+        wadvance16(w);
         wbatch16(w, w.g[(kb + 1) & 1]);
         const int i0 = kb * WB16, kg = i0 / NT_OUT;
         if (i0 % NT_OUT == 0) {
@@ -247,7 +264,8 @@ __device__ __forceinline__ void dump16(const f32x4 (&acc)[NT16_H], const Dump16&
         for (int e = 0; e < 4; ++e) dump_store16(d, (16 * t + e) * CHUNK, acc[t][e]);
 }
 
-// ReLU sign bits: lane l keeps the signs of its own registers, tiles 8 w .. 8 w + 7 -> word w, bit 4 (t & 7) + e.
+// ReLU sign bits: lane l keeps the signs of its own registers, tiles 8 w .. 8 w + 7 -> word w, bit 31 - (4 (t & 7) + e)
+// (the forward pushes them in with shift-or).
 // [layer][sub-chunk][3 words][64 lanes]: the same bytes per 32 samples as the round-1 layout.
 constexpr int RELU16_WORDS = NT16_H / 8;     // 3
 __host__ __device__ constexpr size_t relu16_offset(int layer, long n_sub, long sub) {

@@ -13,6 +13,14 @@
 
 namespace gnr {
 
+// Timing experiments only (results are incomplete with any bit set): -DGNR_ABL16=<bits>, training forward:
+//   1 no sign-bit stores   2 no per-layer activation dumps (mm16_h runs its inference loop)   4 no feature dump
+//   8 no encoding / geometry dump   16 no sign-bit collection
+#ifndef GNR_ABL16
+#define GNR_ABL16 0
+#endif
+constexpr int ABL16 = GNR_ABL16;
+
 // per-wave LDS bias table: rows L0..L7, RGB0 (384 each), RGB1 (192), RGB2 (288)
 constexpr int B16_R1 = 9 * H;
 constexpr int B16_R2 = B16_R1 + H2;
@@ -46,9 +54,18 @@ __global__ __launch_bounds__(256, 2) void fwd16_kernel(const FwdParams fp) {
     const bool valid = i < p.n_samples;
     const long row = chunk * CHUNK + hh * SUB + j;  // padded global sample index
 
+    // One weight set per workgroup (blockIdx.y): the grid runs all sub-chunks through the first MLP, then through the
+    // second, so the chip streams ONE 5.4 MB weight set at a time through its 4 MB L2s instead of two (the dgrad
+    // kernel, one set per launch, fetched a third less per set and tolerated the dump stores; this kernel did not).
+    // Price: geometry + encoding are computed once per weight set (~0.4 %).
+#ifdef GNR_FWD16_BOTH_STREAMS          // A/B switch: both weight sets per wave (one pass over the grid)
+    const int s_lo = 0, s_hi = fp.n_streams;
+#else
+    const int s_lo = blockIdx.y, s_hi = s_lo + 1;
+#endif
     // the weight stream starts now: its first rows land while the geometry / encoding is computed
     WStream16 w;
-    wstream16_init(w, fp.ws[0].packed, lane);
+    wstream16_init(w, fp.ws[s_lo].packed, lane);
 
     // ---- A1: ray + sample ----
     const Ray r = make_ray(p, b, ray);
@@ -67,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void fwd16_kernel(const FwdParams fp) {
         encode_point16(px, py, pz, g, e);
 #pragma unroll
         for (int s = 0; s < ENC16; ++s) enc_col[s * 256] = e[s];
-        if (SAVE) {
+        if (SAVE && !(ABL16 & 8) && s_lo == 0) {
             // CCM [chunk][64 slots][32] in round 1's slot order (the weight-gradient / backward kernels' format)
             float* eb = fp.enc + chunk * (CHUNK * ENC_PAD) + hh * SUB + j;
 #pragma unroll
@@ -77,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void fwd16_kernel(const FwdParams fp) {
                 fp.zval[row] = z0;
                 *(f32x4*)(fp.pts + row * 4) = f32x4{px, py, pz, 0.0f};
             }
-        } else if (fp.want_wl && g == 0) {
+        } else if (!SAVE && fp.want_wl && g == 0 && s_lo == 0) {
             fp.zval[row] = z0;
         }
     }
@@ -85,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void fwd16_kernel(const FwdParams fp) {
     f32x4 A[NT16_H], Bv[NT16_H];
 
 #pragma unroll 1
-    for (int s = 0; s < fp.n_streams; ++s) {
+    for (int s = s_lo; s < s_hi; ++s) {
         const StreamWs& ws = fp.ws[s];
         float* acth = ws.act_h;
         // this image's biases (latent codes folded in) -> the wave's LDS table; wave-private, so an
@@ -117,7 +134,13 @@ __global__ __launch_bounds__(256, 2) void fwd16_kernel(const FwdParams fp) {
                 for (int c = lane; c < nrb; c += 64) bias_lds[B16_R1 + c] += rb[c];
             }
         }
-        auto dp = [&](float* dst, int C) { return dump_dst16(SAVE ? dst : nullptr, C, SAVE ? sub : 0, j, g); };
+        // The dumps' lane offset, made opaque once per weight set: as a loop invariant of this stream loop hipcc hoists
+        // "lane offset + immediate" for all 32 immediates into VGPRs that then live across the whole kernel (each store
+        // with its own address register instead of the 12-bit offset field) -- the register pressure cost the training
+        // forward 2.6 ms per launch.
+        unsigned lane_off = dump_lane_off16(sub, j, g);
+        asm volatile("" : "+v"(lane_off));
+        auto dp = [&](float* dst, int C) { return dump_dst16(SAVE ? dst : nullptr, C, SAVE ? sub : 0, lane_off); };
         auto sb = [&](int layer) {           // sign-bit words [3][64 lanes] of this sub-chunk
             Dump16 d;
             d.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(ws.relu_bits + relu16_offset(layer, n_sub, sub)), 0, 0x7ffffff0, 0x00020000);
@@ -139,13 +162,21 @@ __global__ __launch_bounds__(256, 2) void fwd16_kernel(const FwdParams fp) {
         (void)bias_row;
 #define GNR_RELU(X)                                                                                      \
     [&](int t) {                                                                                         \
-        unsigned bt = 0;                                                                                 \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                  \
+            /* ReLU as one v_max_i32 on the bit pattern (negative floats are negative integers).  Training:     \
+               sign bit = min(relu bits, 1), pushed into the tile group's word -- v_min_u32 (asm: LLVM turns    \
+               umin(select, 1) back into compare + select) + v_lshl_or_b32: 3 VALU per value in all */          \
             const float v = GNR_BADD(X[t][e], t, e);                                                     \
-            if (SAVE) bt |= (v > 0.0f ? 1u : 0u) << e;                                                   \
-            X[t][e] = v > 0.0f ? v : 0.0f;                                                               \
+            const int bi = __builtin_bit_cast(int, v);                                                   \
+            const int r = bi > 0 ? bi : 0;                                                               \
+            X[t][e] = __builtin_bit_cast(float, r);                                                      \
+            if (SAVE && !(ABL16 & 16)) {                                                                 \
+                unsigned b;                                                                              \
+                if ((t & 7) == 0 && e == 0) mkw[t >> 3] = 0;                                             \
+                asm("v_min_u32 %0, 1, %2\n\tv_lshl_or_b32 %1, %1, 1, %0"                                 \
+                    : "=&v"(b), "+v"(mkw[t >> 3]) : "v"(r));                                             \
+            }                                                                                            \
         }                                                                                                \
-        if (SAVE) mkw[t >> 3] = (t & 7) ? (mkw[t >> 3] | (bt << (4 * (t & 7)))) : bt;                    \
     }
 #ifdef GNR_BIAS_POST
         auto noneA = [&](int t) { _Pragma("unroll") for (int e = 0; e < 4; ++e) A[t][e] = GNR_BADD(A[t][e], t, e); };
@@ -153,11 +184,13 @@ __global__ __launch_bounds__(256, 2) void fwd16_kernel(const FwdParams fp) {
         auto noneA = [](int) {};
 #endif
         auto put_bits = [&](int layer, int words) {
-            if (SAVE) {
+            if (SAVE && !(ABL16 & 1)) {
                 const Dump16 dst = sb(layer);
+                // value 4 (t & 7) + e of a word sits at bit 31 - value: a half-filled word (RGB_layer_1: 12 tiles) is
+                // left-aligned here
 #pragma unroll
                 for (int q = 0; q < RELU16_WORDS; ++q)
-                    if (q < words) dump_store16(dst, q * 64, mkw[q]);
+                    if (q < words) dump_store16(dst, q * 64, (words == 2 && q == 1) ? (mkw[q] << 16) : mkw[q]);
             }
         };
 
@@ -174,23 +207,23 @@ __global__ __launch_bounds__(256, 2) void fwd16_kernel(const FwdParams fp) {
 #pragma unroll 1
         for (int rep = 0; rep < 2; ++rep) {
             const int la = 1 + 2 * rep, lb = 2 + 2 * rep;
-            mm16_h<NT16_H, NT16_H, true, SAVE>(A, Bv, w, dp(acth + (la - 1) * fp.M * H, H),
+            mm16_h<NT16_H, NT16_H, true, SAVE && !(ABL16 & 2)>(A, Bv, w, dp(acth + (la - 1) * fp.M * H, H),
                 GNR_BIAS(la), GNR_RELU(Bv));
             put_bits(la, 3);
-            mm16_h<NT16_H, NT16_H, true, SAVE>(Bv, A, w, dp(acth + (lb - 1) * fp.M * H, H),
+            mm16_h<NT16_H, NT16_H, true, SAVE && !(ABL16 & 2)>(Bv, A, w, dp(acth + (lb - 1) * fp.M * H, H),
                 GNR_BIAS(lb), GNR_RELU(A));
             put_bits(lb, 3);
         }
 
         // L5: [enc | A] -> Bv   (skip connection, models/mlp_nerf.py:107); dumps h4
         mm16_enc<NT16_H, SAVE>(enc_col, Bv, w, GNR_BIAS(5));
-        mm16_h<NT16_H, NT16_H, false, SAVE>(A, Bv, w, dp(acth + 4 * fp.M * H, H), ZeroInit16(), GNR_RELU(Bv));
+        mm16_h<NT16_H, NT16_H, false, SAVE && !(ABL16 & 2)>(A, Bv, w, dp(acth + 4 * fp.M * H, H), ZeroInit16(), GNR_RELU(Bv));
         put_bits(5, 3);
 
         // L6: Bv -> A (dumps h5), L7: A -> Bv (dumps h6)
-        mm16_h<NT16_H, NT16_H, true, SAVE>(Bv, A, w, dp(acth + 5 * fp.M * H, H), GNR_BIAS(6), GNR_RELU(A));
+        mm16_h<NT16_H, NT16_H, true, SAVE && !(ABL16 & 2)>(Bv, A, w, dp(acth + 5 * fp.M * H, H), GNR_BIAS(6), GNR_RELU(A));
         put_bits(6, 3);
-        mm16_h<NT16_H, NT16_H, true, SAVE>(A, Bv, w, dp(acth + 6 * fp.M * H, H), GNR_BIAS(7), GNR_RELU(Bv));
+        mm16_h<NT16_H, NT16_H, true, SAVE && !(ABL16 & 2)>(A, Bv, w, dp(acth + 6 * fp.M * H, H), GNR_BIAS(7), GNR_RELU(Bv));
         put_bits(7, 3);
 
         // density head on h7 (models/mlp_nerf.py:109): 384-long dot, split over the four lane groups
@@ -209,16 +242,16 @@ __global__ __launch_bounds__(256, 2) void fwd16_kernel(const FwdParams fp) {
         if (SAVE && g == 0) ws.sigma_raw[row] = sig;
 
         // RGB0: Bv -> A (no activation, mlp_nerf.py:110); dumps h7
-        mm16_h<NT16_H, NT16_H, true, SAVE>(Bv, A, w, dp(acth + 7 * fp.M * H, H), GNR_BIAS(LR0), noneA);
+        mm16_h<NT16_H, NT16_H, true, SAVE && !(ABL16 & 2)>(Bv, A, w, dp(acth + 7 * fp.M * H, H), GNR_BIAS(LR0), noneA);
         // RGB1: A -> Bv[0..12) (+ folded appearance code), ReLU; dumps y0
-        mm16_h<NT16_H, NT16_H2, true, SAVE>(A, Bv, w, dp(ws.act_y0, H), GNR_BIAS(LR1), GNR_RELU(Bv));
+        mm16_h<NT16_H, NT16_H2, true, SAVE && !(ABL16 & 2)>(A, Bv, w, dp(ws.act_y0, H), GNR_BIAS(LR1), GNR_RELU(Bv));
         put_bits(8, 2);
         // RGB2: Bv[0..12) -> A[0..18)  (258 channels padded to 288; no sigmoid, mlp_nerf.py:116); dumps y1
-        mm16_h<NT16_H2, NT16_F, true, SAVE>(Bv, A, w, dp(ws.act_y1, H2), GNR_BIAS(LR2), noneA);
+        mm16_h<NT16_H2, NT16_F, true, SAVE && !(ABL16 & 2)>(Bv, A, w, dp(ws.act_y1, H2), GNR_BIAS(LR2), noneA);
 #undef GNR_BIAS
 #undef GNR_BADD
 #undef GNR_RELU
-        if (SAVE) dump16<NT16_F>(A, dump_dst16(ws.act_feat, FEAT_PAD, sub, j, g));
+        if (SAVE && !(ABL16 & 4)) dump16<NT16_F>(A, dump_dst16(ws.act_feat, FEAT_PAD, sub, lane_off));
 
         // ---- A5: sub-chunk-local compositing (utils/model_utils.py:498-534) ----
         composite_sub(A, sig, delta, z0, ws, sub, row, lane, SAVE || fp.want_wl);
@@ -232,10 +265,15 @@ void launch_fwd16(const FwdParams& fp, hipStream_t stream) {
     // > 64 KiB of dynamic LDS needs an opt-in per device: set it on every launch (cheap, and correct for
     // several devices / threads per process -- a process-wide 'done' flag would not be)
     (void)hipFuncSetAttribute((const void*)(fp.save ? fwd16_kernel<true> : fwd16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD16_LDS_BYTES);
+#ifdef GNR_FWD16_BOTH_STREAMS
+    const dim3 g3(grid);
+#else
+    const dim3 g3(grid, (unsigned)fp.n_streams);
+#endif
     if (fp.save)
-        hipLaunchKernelGGL(fwd16_kernel<true>, dim3(grid), dim3(256), FWD16_LDS_BYTES, stream, fp);
+        hipLaunchKernelGGL(fwd16_kernel<true>, g3, dim3(256), FWD16_LDS_BYTES, stream, fp);
     else
-        hipLaunchKernelGGL(fwd16_kernel<false>, dim3(grid), dim3(256), FWD16_LDS_BYTES, stream, fp);
+        hipLaunchKernelGGL(fwd16_kernel<false>, g3, dim3(256), FWD16_LDS_BYTES, stream, fp);
 }
 
 }  // namespace gnr

@@ -81,7 +81,7 @@ def main():
     from gazenerf_amd import data as D
     from gazenerf_amd import losses as L
 
-    B, S, FM = 3, 32, 8                       # pred_img_size 32, featmap_size 8: the 8x scale of 512 -> 64
+    B, S, FM = 2, 64, 16                      # pred_img_size 64, featmap_size 16 (the reference: 512 and 64)
     img, head, leye, reye, para = synthetic_batch(B, S)
     expr_fix = torch.load(os.path.join(REF, "configs", "config_files", "tensor.pt"))
     assert tuple(expr_fix.shape) == (1, 79) and expr_fix.dtype == torch.float32
@@ -98,7 +98,7 @@ def main():
     me.delta_EulurAngles = 0.05 * torch.randn(n_rows, 3, generator=g)
     me.delta_Tvecs = 0.05 * torch.randn(n_rows, 3, 1, generator=g)
     me.eulurangle2Rmat = types.MethodType(BaseTrainer.eulurangle2Rmat, me)
-    it = 1                                      # rows 3..5 of the offset tables
+    it = 1                                      # rows 2..3 of the offset tables
     code_info, opt_code, cam_info, delta_info = GazeNerfTrainer.build_code_and_cam(me, it)
 
     # ---- ours ----

@@ -90,3 +90,41 @@ def test_cfg4_whole_network_step_reduces_every_gradient():
     assert ar["floats"] == 5015714 and ar["buckets"] == 3 and ar["world_size_formed"] == 2
     assert abs(d["value"] - 2 * 2 * 4096 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     assert {s["stage"] for s in d["stages"]} == {"fwd_mlp", "dgrad", "wgrad"}
+
+
+@pytest.mark.parametrize("mode", ["fwd", "fwdbwd"])
+def test_strong_scaling_shards_one_image_over_the_ranks(mode):
+    """--scaling strong (the reference's B=1 render loop utils/render_utils.py:199-219): ONE image, its
+    rays in contiguous blocks per rank; value = that image's rays per second, NOT multiplied by the world size."""
+    extra = ["--gather"] if mode == "fwd" else []
+    d = _run([sys.executable, "bench.py", "--gpus", "2", "--scaling", "strong", "--mode", mode, "--side", "64", "--steps", "2",
+              "--warmup", "1", "--no-alt", "--micro", "1024"] + extra, env=TWO_ON_ONE)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["rays_per_step_per_gpu"] == 64 * 64 // 2
+    assert abs(d["value"] - 64 * 64 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert "ONE image" in d["config"]["workload"] and d["config"]["parallelism"].startswith("rays2")
+    assert d["distributed"]["world_size_formed"] == 2 and d["distributed"]["devices_visible"] >= 1
+    if mode == "fwdbwd":
+        assert d["allreduce"]["floats"] == 2 * 1518979
+        assert {s["stage"]: s["launches_timed"] for s in d["stages"]}["fwd_mlp"] == 2 * 2      # 2 micro-batches x 2 steps
+
+
+def test_one_call_entry_and_preflight_errors():
+    d = _run([sys.executable, "bench.py", "--side", "64", "--steps", "1", "--warmup", "1", "--no-alt", "--no-cpu-baseline",
+              "--micro", "1024"])
+    oc = d["one_call"]
+    assert oc["value"] > 0 and oc["calls_timed"] == 2
+    assert oc["tiled_in_op"] is False and oc["flop_factor_vs_step"] == 1.0          # 4096 rays fit the budget: no tiling
+    # the same call with a budget the 4096-ray image exceeds: the op tiles, 4/3 of the FLOPs
+    d = _run([sys.executable, "bench.py", "--side", "64", "--steps", "1", "--warmup", "1", "--no-alt", "--no-cpu-baseline",
+              "--micro", "1024"], env={"GNR_WS_BUDGET_GB": "2"})
+    assert d["one_call"]["tiled_in_op"] is True and abs(d["one_call"]["flop_factor_vs_step"] - 4 / 3) < 1e-9
+    # a rank whose GPU does not exist fails in pre-flight with one line, and the job exits non-zero
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None)
+    e.update({"GNR_BENCH_DEVICE": "63"})
+    r = subprocess.run([sys.executable, "bench.py", "--side", "64", "--steps", "1"], cwd=ROOT, env=e, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode != 0 and "needs GPU 63" in (r.stderr + r.stdout)
+    r = subprocess.run([sys.executable, "bench.py", "--config", "cfg4", "--scaling", "strong"], cwd=ROOT, env=e,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0

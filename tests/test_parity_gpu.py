@@ -531,10 +531,24 @@ def test_cfg2b_full_size_forward_properties():
             part = call(p["xy"][:, :, a:b].contiguous())
             for k in ("feat_face", "bg_alpha_face", "feat_eyes", "bg_alpha_eyes"):
                 assert torch.equal(out[k][:, :, a:b], part[k]), (k, a, b)
-    # the fixture rays (reference outputs at side 512) are a subset of this very image
-    g = load_golden("g2b_np64_opaque")          # frontal camera, other latent codes: re-render just those rays
-    sub = g["ray_subset"].to(dev)
-    assert torch.equal(p["xy"][:, :, sub].cpu(), g["in_xy"])
+    # The fixture rays (the reference's own outputs at side 512: oracle/gen_golden_s512.py) are a subset of this very
+    # pixel grid: render the FULL 512 x 512 image with each fixture's codes / camera / weights and compare its 256 rays
+    # inside it, both precisions -- the bench's own image size against reference outputs, not only against itself.
+    for name in ("g2b_np64_opaque", "g2b_np64_frontal", "g2b_np64_orbit3"):
+        g = load_golden(name)
+        sub = g["ray_subset"].to(dev)
+        assert torch.equal(p["xy"][:, :, sub].cpu(), g["in_xy"])
+        q = _to(golden_problem(g), dev)
+        gface, geyes = _weights(g)
+        gface, geyes = _to(gface, dev), _to(geyes, dev)
+        for precision in PRECISIONS:
+            with torch.no_grad():
+                full = render.render_two_stream(p["xy"], q["R"], q["T"], q["Kinv"], q["shape_code"], q["gaze"], q["appea_code"],
+                                                gface, geyes, n_samples=64, precision=precision)
+            for tag in ("face", "eyes"):
+                assert _maxabs(full["feat_" + tag][:, :, sub], g["out_feat_" + tag]) <= TOL, (name, precision, tag)
+                assert _maxabs(full["bg_alpha_" + tag][:, :, sub], g["out_bg_alpha_" + tag]) <= TOL, (name, precision, tag)
+            del full
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -673,8 +687,8 @@ GRAD_STABLE_ABS = {"fp32": 2e-4, "bf16x3": 4e-4}   # mask-stable problem: bound 
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("stable", [False, True])
 def test_backward_error_is_within_the_reference_fp32_noise(stable, precision):
-    """Per tensor (all 53): rel-L2 error of the HIP gradient against the oracle in fp64 <= 1.25 x the error of the
-    oracle's own fp32 autograd against fp64 + eps -- the forward's criterion
+    """Per tensor (all 53): rel-L2 error of the HIP gradient against the oracle in fp64 <= factor x the error of the
+    oracle's own fp32 autograd against fp64 + eps (factor 1.25 where no ReLU mask can flip) -- the forward's criterion
     (test_bf16x3_is_as_close_to_exact_as_the_reference_fp32) applied to the backward.  In the mask-stable problem
     that is a bound of <= 2e-4 (fp32) / 4e-4 (bf16x3) rel-L2 on every parameter / latent gradient."""
     dev = _dev()
@@ -687,12 +701,14 @@ def test_backward_error_is_within_the_reference_fp32_noise(stable, precision):
                      lambda xy, R, T, K, s, g, a, f, e, tr: render.render_two_stream(
                          xy, R, T, K, s, g, a, f, e, n_samples=64, t_rand=tr, precision=precision))
     eps = GRAD_EPS[precision]
-    # Where masks flip, the error IS the set of flipped samples -- a discrete draw per arithmetic.  The fp32 kernels
-    # follow the reference's rounding sequence, so their draw correlates with the fp32 oracle's (factor 1.25 holds);
-    # bf16x3 rounds independently: same distribution, another draw, and with 2 x 24 rays a single flip moves a tensor's
-    # error by a factor of a few.  A wrong kernel is off by 100-1000x this noise; the mask-stable problem, where no
-    # draw is involved, carries the tight bound for both precisions.
-    factor = 1.25 if (stable or precision == "fp32") else 5.0
+    # Where masks flip, the error IS the set of flipped samples -- a discrete draw per arithmetic, and with 2 x 24 rays a
+    # single flip moves a tensor's error by a factor of a few.  Round 2's fp32 kernels happened to draw like the fp32
+    # oracle (factor 1.25 held); round 3's sum every layer in another order (16-channel k-groups, bias first:
+    # gnr_chain16.h) and, like bf16x3, draw independently: same distribution, another draw (observed worst: the eyes
+    # stream's density head, 2.1 x the oracle's 2.6e-4).  fp32 products are exact, so its gate stays tighter (2.5) than
+    # the 3-term split's (5).  A wrong kernel is off by 100-1000x this noise; the mask-stable problem, where no draw
+    # is involved, carries the tight bound (1.25) for both precisions.
+    factor = 1.25 if stable else (2.5 if precision == "fp32" else 5.0)
     bad = []
     for k, r in exact.items():
         n = max(float(r.norm()), 1e-30)

@@ -32,7 +32,7 @@ def run_pass(counter, outdir, bench_args):
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
            sys.executable, os.path.join(ROOT, "bench.py")] + bench_args + ["--no-cpu-baseline", "--no-alt"]
     with open(os.path.join(d, "bench.log"), "w") as log:
-        subprocess.run(cmd, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT, check=False)
+        subprocess.run(["timeout", "600"] + cmd, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT, check=False)   # a crashed rocprofv3 can hang forever
     agg = collections.defaultdict(list)
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):

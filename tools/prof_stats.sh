@@ -8,7 +8,7 @@ NAME=$1; shift
 OUT=$R/gpurun_out/$NAME
 mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o run -- python $R/bench.py "$@" --no-cpu-baseline > $OUT/bench.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o run -- python $R/bench.py "$@" --no-cpu-baseline > $OUT/bench.log 2>&1
 find $OUT/prof -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 head -40 $OUT/kernel_stats.csv
 tail -c 600 $OUT/bench.log
