@@ -30,7 +30,7 @@ def run_pass(counter, outdir, bench_args):
     os.makedirs(d, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
-           sys.executable, os.path.join(ROOT, "bench.py")] + bench_args + ["--no-cpu-baseline", "--no-alt"]
+           sys.executable, os.path.join(ROOT, "bench.py")] + bench_args + ["--no-cpu-baseline", "--no-alt", "--no-one-call"]
     with open(os.path.join(d, "bench.log"), "w") as log:
         subprocess.run(["timeout", "600"] + cmd, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT, check=False)   # a crashed rocprofv3 can hang forever
     agg = collections.defaultdict(list)
