@@ -70,13 +70,17 @@ int check_problem(const GnrProblem* p, int n_streams) {
     if (!p->xy || !p->R || !p->T || !p->Kinv) return fail("gnr: xy/R/T/Kinv must be non-NULL");
     if ((p->shape_dims && !p->shape_code) || (p->gaze_dims && !p->gaze) || (p->appea_dims && !p->appea_code))
         return fail("gnr: latent code pointer is NULL");
-    // the view-direction columns are skipped by the kernels and must come back through ray_bias (include/gnr.h): a
-    // problem that declares them but supplies no per-ray bias would silently drop them
-    if (p->vd_dims > 0)
-        for (int s = 0; s < n_streams; ++s)
-            if (!p->ray_bias[s])
-                return fail("gnr: vd_dims = %d but ray_bias[%d] is NULL: the view-direction columns of RGB_layer_1 reach the "
-                            "kernels only through the per-ray bias", p->vd_dims, s);
+    // The view-direction columns are skipped by the chain kernels and come back as a per-ray bias (include/gnr.h): either
+    // the caller supplies it for EVERY weight set, or for none -- then the library computes the embedding and the fold
+    // itself (gnr_vd.hip).  One set with and one without would silently drop the columns of the latter.
+    if (p->vd_dims > 0) {
+        int given = 0;
+        for (int s = 0; s < n_streams; ++s) given += p->ray_bias[s] ? 1 : 0;
+        if (given != 0 && given != n_streams)
+            return fail("gnr: vd_dims = %d but ray_bias is set for %d of %d weight sets: supply it for all of them, or for "
+                        "none (the library then folds the view-direction columns itself)", p->vd_dims, given, n_streams);
+        if (given == 0 && vd_check(p)) return 1;
+    }
     return 0;
 }
 
@@ -133,7 +137,15 @@ size_t carve_fwd(const GnrProblem* p, int n_streams, bool save, char* base, FwdP
     float* zval = take(M);
     float* enc = nullptr; float* enc3 = nullptr; float* delta = nullptr; float* pts = nullptr;
     if (save) { enc = take(M * ENC_PAD); enc3 = take(M * ENC_PAD); delta = take(M); pts = take(M * 4); }
-    if (fp) { fp->zval = zval; fp->enc = enc; fp->enc3 = enc3; fp->delta = delta; fp->pts = pts; }
+    if (fp) { fp->zval = zval; fp->enc = enc; fp->enc3 = enc3; fp->delta = delta; fp->pts = pts; fp->vd_embed = nullptr; }
+    if (vd_on_device(p)) {          // embedding + one per-ray bias per weight set, kept for the backward
+        float* vbase = take(vd_fwd_floats(p, n_streams));
+        if (fp && vbase) {
+            float* rb[2] = {nullptr, nullptr};
+            vd_carve_fwd(p, n_streams, vbase, &fp->vd_embed, rb);
+            for (int s = 0; s < n_streams; ++s) fp->ws[s].ray_bias = rb[s];
+        }
+    }
     return off;
 }
 
@@ -209,8 +221,13 @@ static int fwd_impl(const GnrProblem* p, const GnrWeights* face, const GnrWeight
     carve_fwd(p, n_streams, save, (char*)workspace, &fp);
     fp.want_wl = (out->weights[0] || (n_streams > 1 && out->weights[1])) ? 1 : 0;
     fp.clk = clock_probe_slot(GNR_STAGE_FWD_MLP);
-    for (int s = 0; s < n_streams; ++s) fp.ws[s].ray_bias = p->ray_bias[s];
     const GnrWeights* ws_in[2] = {face, eyes};
+    if (vd_on_device(p)) {
+        float* rb[2] = {(float*)fp.ws[0].ray_bias, (float*)fp.ws[1].ray_bias};
+        launch_vd_fwd(*p, n_streams, ws_in, fp.vd_embed, rb, st);
+    } else {
+        for (int s = 0; s < n_streams; ++s) fp.ws[s].ray_bias = p->ray_bias[s];
+    }
     // weights_packed: the caller vouches that the packed streams in this workspace are current (inference only)
     const bool reuse = p->weights_packed != 0 && !save;
     const bool c16 = !bf16x3 && chain16_enabled();

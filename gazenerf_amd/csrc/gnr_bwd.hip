@@ -25,6 +25,11 @@ void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb,
                   int n_crop = -1, int k_crop = -1);
 void launch_vecsum(const float* v, int batch, long per_image, float* out, int out_stride, hipStream_t stream);
 void stage_mark(int stage, int which, hipStream_t st);
+struct VdBwdScratch { float* d_rb[2]; float* dR_part; float* dW_part; float* dR_extra; int bpi, segs; };
+size_t vd_bwd_floats(const GnrProblem* p, int n_streams);
+void vd_carve_bwd(const GnrProblem* p, int n_streams, float* base, VdBwdScratch* sc);
+void launch_vd_bwd(const GnrProblem& p, int n_streams, const GnrWeights* const* w, const GnrWeightGrads* const* dw,
+                   const float* embed, const VdBwdScratch& sc, bool want_dR, hipStream_t st);
 void launch_packT16(const PackTParams& pt, hipStream_t stream);
 void launch_bwd16_chain(const BwdParams& bp, hipStream_t stream);
 
@@ -369,12 +374,12 @@ __global__ __launch_bounds__(256) void geo_kernel(const GeoParams gp) {
     if (tid < 12) gp.part[((long)b * gp.blocks_per_image + blockIdx.x) * 12 + tid] = red[tid][0];
 }
 
-__global__ void geo_final_kernel(const float* part, int blocks_per_image, float* dR, float* dT) {
+__global__ void geo_final_kernel(const float* part, int blocks_per_image, float* dR, float* dT, const float* dR_extra) {
     const int b = blockIdx.x, k = threadIdx.x;
     if (k >= 12) return;
     float acc = 0.0f;
     for (int i = 0; i < blocks_per_image; ++i) acc += part[((long)b * blocks_per_image + i) * 12 + k];
-    if (k < 9) { if (dR) dR[b * 9 + k] = acc; }
+    if (k < 9) { if (dR) dR[b * 9 + k] = dR_extra ? acc + dR_extra[b * 9 + k] : acc; }      // + the view-direction part (gnr_vd.hip)
     else if (dT) dT[b * 3 + (k - 9)] = acc;
 }
 
@@ -534,7 +539,7 @@ static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct BwdScratch {
     float *dsig_ray, *packedT, *gT, *wglob, *dsig, *dY_h, *dY_r0, *dY_r1, *dfeat, *geo_chunk, *csum, *geo_part;
-    float *dbias, *cs_part, *wg_part;
+    float *dbias, *cs_part, *wg_part, *vd;
     int geo_blocks;
 };
 
@@ -565,6 +570,7 @@ static size_t carve_bwd(const GnrProblem* p, char* base, BwdScratch* sc) {
     s.dbias = take((size_t)(N_CHAIN + 1) * p->batch * H);
     s.cs_part = nullptr;
     s.wg_part = take(wgrad_scratch_floats());
+    s.vd = vd_on_device(p) ? take(vd_bwd_floats(p, 2)) : nullptr;
     if (sc) *sc = s;
     return off;
 }
@@ -590,11 +596,13 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
     const int cpr = fp.chunks_per_ray;
     const long n_rays_total = (long)p->batch * p->n_rays;
     const long M = fp.M;
-    const long rows_per_image = (long)p->n_rays * cpr * CHUNK;
     const int vp = ENC_CH + p->shape_dims + p->gaze_dims;
     const int Hh = p->hidden, Hh2 = Hh / 2;
     GnrInputGrads dinz{};
     if (din) dinz = *din;
+    const bool vdev = vd_on_device(p);
+    VdBwdScratch vsc{};
+    if (vdev) vd_carve_bwd(p, n_streams, sc.vd, &vsc);
 
     for (int s = 0; s < n_streams; ++s) {
         const StreamWs& ws = fp.ws[s];
@@ -686,9 +694,9 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         if (s == 0) stage_mark(GNR_STAGE_WGRAD, 1, st);
         launch_vecsum(sc.dsig_ray, p->batch, p->n_rays, dbl(N_CHAIN), H, st);
 
-        if (dinz.ray_bias[s])
+        if (dinz.ray_bias[s] || vdev)        // device-side view direction: the per-ray sums feed launch_vd_bwd below
             hipLaunchKernelGGL(ray_bias_grad_kernel, dim3((unsigned)((n_rays_total + 3) / 4)), dim3(256), 0, st, sc.dY_r1, cpr,
-                               n_rays_total, Hh2, bf16x3 ? 1 : 0, dinz.ray_bias[s]);
+                               n_rays_total, Hh2, bf16x3 ? 1 : 0, vdev ? vsc.d_rb[s] : dinz.ray_bias[s]);
 
         // 6. latent gradients from the per-image bias sums
         LatentParams lp{};
@@ -700,13 +708,17 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         hipLaunchKernelGGL(latent_weights_kernel, dim3(H), dim3(64), 0, st, lp);
     }
 
+    // view direction folded by the library: d W1[:, H:H+vd] (after latent_weights_kernel zeroed those columns) and the
+    // direction's share of dR
+    if (vdev) launch_vd_bwd(*p, n_streams, w, dw, fp.vd_embed, vsc, dinz.R != nullptr, st);
     // geometry: dR, dT
     if (dinz.R || dinz.T) {
         GeoParams gp{};
         gp.prob = *p; gp.chunks_per_ray = (!bf16x3 && chain16_enabled()) ? 2 * cpr : cpr; gp.geo_chunk = sc.geo_chunk; gp.csum = sc.csum;
         gp.part = sc.geo_part; gp.blocks_per_image = sc.geo_blocks;
         hipLaunchKernelGGL(geo_kernel, dim3(sc.geo_blocks, p->batch), dim3(256), 0, st, gp);
-        hipLaunchKernelGGL(geo_final_kernel, dim3(p->batch), dim3(64), 0, st, sc.geo_part, sc.geo_blocks, dinz.R, dinz.T);
+        hipLaunchKernelGGL(geo_final_kernel, dim3(p->batch), dim3(64), 0, st, sc.geo_part, sc.geo_blocks, dinz.R, dinz.T,
+                           (vdev && dinz.R) ? vsc.dR_extra : (const float*)nullptr);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("gnr_bwd: launch failed: %s", hipGetErrorString(e));

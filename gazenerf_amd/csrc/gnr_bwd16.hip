@@ -97,6 +97,7 @@ __global__ __launch_bounds__(256, 2) void bwd16_chain_kernel(const BwdParams bp)
     const long ray_g = chunk / bp.chunks_per_ray;
     const long row = chunk * CHUNK + hh * SUB + j;
     const long M = bp.M;
+    dephase_first_round(blockIdx.x);
     WStream16 w;
     wstream16_init(w, bp.packedT, lane);
     const float* enc_base = bp.enc + chunk * (CHUNK * ENC_PAD) + hh * SUB + j;     // CCM: slot stride 32

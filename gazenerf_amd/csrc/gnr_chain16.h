@@ -132,6 +132,26 @@ __device__ __forceinline__ void wstream16_init(WStream16& w, const float* packed
     wbatch16(w, w.g[0]);
 }
 
+// ---- de-phasing the two waves of a SIMD ----------------------------------------------------------------------------
+// Workgroups of equal length that start together stay in step: the two waves of a SIMD would run their non-MFMA phases
+// (ray set-up, encoding, bias-table fill, compositing) at the same time, with the matrix pipe idle.  The workgroups of
+// the FIRST round that land in an odd wave slot sleep ~25 us once; every later workgroup inherits the offset of the slot
+// it takes over.  (HW_ID bits 3:0 = wave slot within the SIMD.)
+__device__ __forceinline__ void dephase_first_round(unsigned linear_block) {
+#ifndef GNR_NO_DEPHASE
+    if (linear_block < 512u) {                          // 2 workgroups x 256 CUs
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        if (hw & 1u) {
+#pragma unroll 1
+            for (int i = 0; i < 8; ++i) __builtin_amdgcn_s_sleep(127);      // 8 x 127 x 64 cycles ~ 27 us at 2.4 GHz
+        }
+    }
+#else
+    (void)linear_block;
+#endif
+}
+
 // ---- dump destination: buffer stores with a wave-uniform descriptor ---------------------------------------------
 // Element (chunk c, channel n, sample jj) of a chunk-channel-major tensor lives at c*32*C + n*32 + jj.  The wave owns
 // samples 16 hh + j of chunk c and, in register e of tile t, channel 16 t + 4 g + e: with the descriptor based at the

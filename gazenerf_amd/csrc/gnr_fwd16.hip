@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256, 2) void fwd16_kernel(const FwdParams fp) {
 #else
     const int s_lo = blockIdx.y, s_hi = s_lo + 1;
 #endif
+    dephase_first_round(blockIdx.y * gridDim.x + blockIdx.x);
     // the weight stream starts now: its first rows land while the geometry / encoding is computed
     WStream16 w;
     wstream16_init(w, fp.ws[s_lo].packed, lane);

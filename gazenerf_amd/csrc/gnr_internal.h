@@ -101,6 +101,7 @@ struct FwdParams {
     float* delta;         // [M]
     float* zval;          // [M]
     float* pts;           // [M][4]        (training only)
+    float* vd_embed;      // [rays][28]  view-direction embedding when the library folds it itself (gnr_vd.hip) or nullptr
     int save;
     int want_wl;
     unsigned long long* clk;   // shader-clock probe or nullptr
@@ -136,6 +137,12 @@ struct CombineParams {
 void launch_prep(const GnrProblem& p, int n_streams, const GnrWeights* const* w, StreamWs* ws,
                  hipStream_t stream, bool pack_fp32 = true, bool chain16 = true);
 void launch_fwd16(const FwdParams& fp, hipStream_t stream);
+// gnr_vd.hip: the view-direction option computed by the library (vd_dims > 0, no caller-supplied ray_bias)
+bool vd_on_device(const GnrProblem* p);
+int vd_check(const GnrProblem* p);
+size_t vd_fwd_floats(const GnrProblem* p, int n_streams);
+void vd_carve_fwd(const GnrProblem* p, int n_streams, float* base, float** embed, float** rb);
+void launch_vd_fwd(const GnrProblem& p, int n_streams, const GnrWeights* const* w, float* embed, float* const* rb, hipStream_t st);
 bool chain16_enabled();        // gnr_api.hip: the fp32 chain runs on 16x16x4 tiles, two waves per SIMD (default) -- or,
                                // with GNR_CHAIN32=1 in the environment, on round 2's 32x32x2 kernels (A/B timing)
 void launch_prep3(const GnrProblem& p, int n_streams, const GnrWeights* const* w, StreamWs* ws,

@@ -94,8 +94,14 @@ class HotPathRenderer(nn.Module):
                  world_z2: float = -3.5, hidden: int = 384, featmap_nc: int = 258,
                  shape_dims: int = synth.SHAPE_DIMS, gaze_dims: int = synth.GAZE_DIMS,
                  appea_dims: int = synth.APPEA_DIMS, hier_sampling: bool = False, precision: str = "fp32",
-                 ws_budget_bytes: Optional[int] = None, include_vd: bool = False):
+                 ws_budget_bytes: Optional[int] = None, include_vd: bool = False, vd_fold: str = "device"):
         super().__init__()
+        if vd_fold not in ("device", "torch"):
+            raise ValueError("vd_fold must be 'device' or 'torch'")
+        # include_vd: who folds the 27 view-direction columns of RGB_layer_1 into the per-ray bias the kernels take --
+        # libgnr itself (round 3: gnr_vd.hip, forward and backward inside gnr_fwd / gnr_bwd) or this module in torch
+        # (rounds 1-2: view_direction_ray_bias + autograd; kept as the cross-check)
+        self.vd_fold = vd_fold
         self.ws_budget_bytes = ws_budget_bytes      # None == render.DEFAULT_WS_BUDGET; see render_two_stream
         # inference calls keep their workspace and skip the weight re-layout while the parameters are unchanged
         self._wcache, self._wcache_fine = R_.PackedWeightCache(), R_.PackedWeightCache()
@@ -145,7 +151,7 @@ class HotPathRenderer(nn.Module):
             t_rand = torch.rand(B, n_r, n_p + 1, device=batch_xy.device)
         want_w = return_weights or self.hier_sampling
         rb_face = rb_eyes = rb_fine = None
-        if self.include_vd:
+        if self.include_vd and self.vd_fold == "torch":
             vd = view_direction_embedding(batch_xy, batch_Rmats, batch_inv_inmats)
             rb_face = view_direction_ray_bias(vd, self.fg_CD_predictor_face)
             rb_eyes = view_direction_ray_bias(vd, self.fg_CD_predictor_eyes)

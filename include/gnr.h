@@ -89,12 +89,17 @@ typedef struct GnrProblem {
                                  tensor identity + torch's version counter).  ABI 2.             */
     int32_t vd_dims;          /* columns of RGB_layer_1.weight between the hidden and the appearance columns: 0, or
                                  27 with the reference's view-direction encoder (`include_vd`, models/gaze_nerf.py:
-                                 70-80, 140: the layer's input is cat([h, vd_embedding(27), appea_code])).  The kernels
-                                 skip those columns; their contribution arrives through ray_bias.  ABI 2.   */
+                                 70-80, 140: the layer's input is cat([h, vd_embedding(27), appea_code])).  The chain kernels
+                                 skip those columns; their contribution is a per-ray bias of that layer (the direction is
+                                 constant along a ray).  With ray_bias NULL for every weight set the LIBRARY computes it
+                                 (ABI 3, gnr_vd.hip: Embedder of the normalised ray direction, utils/model_utils.py:253-280,
+                                 366-369; vd_dims = 3 + 6 n_freqs, n_freqs <= 8), and gnr_bwd returns the gradient of the
+                                 vd columns in rgb_w[1] and the direction's share of dR -- include_vd needs nothing else
+                                 from the caller.  ABI 2: the caller had to supply ray_bias.                      */
     const float* ray_bias[2]; /* per weight set: NULL, or [B,N_r,hidden/2] added to the bias of RGB_layer_1 for every
-                                 sample of the ray.  The view direction is constant along a ray, so
-                                 W[:, H:H+vd_dims] . vd_embedding(ray) is a per-ray bias the caller computes (27 MACs
-                                 per ray and channel; gazenerf_amd.module does it in torch, autograd included).  ABI 2. */
+                                 sample of the ray (a caller-computed fold of the vd columns, or any other per-ray term;
+                                 gnr_bwd returns its gradient in GnrInputGrads.ray_bias).  With vd_dims > 0: set for every
+                                 weight set or for none (see vd_dims); a mix is rejected.                         */
 } GnrProblem;
 
 /* Parameters of one MLPforNeRF (models/mlp_nerf.py:13-93).  weight = Conv2d [out,in,1,1] memory

@@ -70,11 +70,21 @@ def test_struct_size_handshake(lib_built):
     u.struct_size = 12
     assert lib.gnr_upsample_workspace_bytes(ctypes.byref(u), _lib.UP_WS_FWD) == 0
     assert b"GnrUpsampleProblem.struct_size is 12" in lib.gnr_last_error()
-    # declaring view-direction columns without the per-ray bias that carries them is an error, not a silent drop
+    # view-direction columns: a per-ray bias for every weight set (the caller folds) or for none (the library folds,
+    # gnr_vd.hip; its workspace grows by the embedding + one bias per set) -- never for some: that would drop columns
     p = _lib.GnrProblem()
-    p.batch, p.n_rays, p.n_samples, p.hidden, p.feat_nc, p.vd_dims = 1, 16, 64, 384, 258, 27
+    p.batch, p.n_rays, p.n_samples, p.hidden, p.feat_nc = 1, 16, 64, 384, 258
     p.xy = p.R = p.T = p.Kinv = 1024
-    assert lib.gnr_workspace_bytes(ctypes.byref(p), 1, _lib.WS_FWD) == 0 and b"ray_bias[0] is NULL" in lib.gnr_last_error()
+    base = lib.gnr_workspace_bytes(ctypes.byref(p), 2, _lib.WS_FWD)
+    p.vd_dims = 27
+    assert lib.gnr_workspace_bytes(ctypes.byref(p), 2, _lib.WS_FWD) >= base + 16 * (28 + 2 * 192) * 4
+    p.ray_bias[0] = 1024
+    assert lib.gnr_workspace_bytes(ctypes.byref(p), 2, _lib.WS_FWD) == 0 and b"for 1 of 2 weight sets" in lib.gnr_last_error()
+    p.ray_bias[1] = 1024
+    assert lib.gnr_workspace_bytes(ctypes.byref(p), 2, _lib.WS_FWD) == base
+    p.ray_bias[0] = p.ray_bias[1] = None
+    p.vd_dims = 26
+    assert lib.gnr_workspace_bytes(ctypes.byref(p), 2, _lib.WS_FWD) == 0 and b"3 + 6 n_freqs" in lib.gnr_last_error()
 
 
 def test_integration_stub_matches_the_library(lib_built):

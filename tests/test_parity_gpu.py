@@ -961,14 +961,17 @@ def _vd_weights(g):
             synth.hash_mlp_params("eyes", seed=seed, vd_ch=vd_ch, density_scale=ds))
 
 
+@pytest.mark.parametrize("fold", ["device", "torch"])
 @pytest.mark.parametrize("binding", ["torch_ext", "ctypes"])
 @pytest.mark.parametrize("tiled", [False, True])
 @pytest.mark.parametrize("precision", PRECISIONS)
-def test_view_direction_option_vs_reference_fixture(precision, tiled, binding, monkeypatch):
+def test_view_direction_option_vs_reference_fixture(precision, tiled, binding, fold, monkeypatch):
     """include_vd=True (models/gaze_nerf.py:70-80, 140-143, 240-243): g11_vd holds outputs and A8-loss gradients of the
     reference's own modules with the 27-channel direction embedding in front of the appearance code.  The HIP path skips
     those weight columns and takes their per-ray fold as ``ray_bias``; the fold (plain torch) carries the gradient into the
-    columns and the rotation.  tiled: the in-op ray tiling slices the per-ray bias and its gradient."""
+    columns and the rotation.  tiled: the in-op ray tiling slices the per-ray bias and its gradient.
+    fold="device" (round 3): no ray_bias is passed -- gnr_fwd / gnr_bwd compute the embedding, the fold, the gradient of
+    the 27 weight columns and the direction's share of dR themselves (gnr_vd.hip): the C ABI alone runs include_vd."""
     from gazenerf_amd.module import VD_DIMS, view_direction_embedding
     monkeypatch.setenv("GNR_BINDING", binding)
     dev = _dev()
@@ -980,10 +983,11 @@ def test_view_direction_option_vs_reference_fixture(precision, tiled, binding, m
     fp = {k: v.to(dev).clone().requires_grad_(True) for k, v in face.items()}
     ep = {k: v.to(dev).clone().requires_grad_(True) for k, v in eyes.items()}
     vd = view_direction_embedding(pd["xy"], leaves["R"], pd["Kinv"])
-    fold = lambda w: torch.einsum("ok,bkr->bro", w["RGB_layer_1.weight"].reshape(192, -1)[:, 384:384 + VD_DIMS], vd).contiguous()
+    tfold = lambda w: (torch.einsum("ok,bkr->bro", w["RGB_layer_1.weight"].reshape(192, -1)[:, 384:384 + VD_DIMS], vd).contiguous()
+                       if fold == "torch" else None)
     out = render.render_two_stream(pd["xy"], leaves["R"], leaves["T"], pd["Kinv"], leaves["shape_code"], leaves["gaze"],
                                    leaves["appea_code"], fp, ep, n_samples=int(g["n_samples"]), t_rand=g["t_rand"].to(dev),
-                                   precision=precision, vd_dims=VD_DIMS, ray_bias_face=fold(fp), ray_bias_eyes=fold(ep),
+                                   precision=precision, vd_dims=VD_DIMS, ray_bias_face=tfold(fp), ray_bias_eyes=tfold(ep),
                                    ray_tile=8 if tiled else None)
     for tag in ("face", "eyes"):
         assert _maxabs(out["feat_" + tag], g["out_feat_" + tag]) <= TOL
