@@ -370,7 +370,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradParams wp
         const bool isa = j < PA;
         const unsigned i = (unsigned)(isa ? wave * PA + j : wave * PB + (j - PA));
         const unsigned l = lds0 + (unsigned)buf * BUF_BYTES + (isa ? 0u : (unsigned)(TN * CHUNK * 4)) + i * 1024u;
+#ifdef GNR_WG_HOT      /* timing experiment (wrong results): every request re-reads one of the first 8 chunks -> operands L2-resident */
+        const unsigned so = (unsigned)(k & 7) * (isa ? chunk_a : chunk_b) + i * 1024u;
+#else
         const unsigned so = (unsigned)k * (isa ? chunk_a : chunk_b) + i * 1024u;
+#endif
         unsigned keep;
         if (isa)
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
@@ -531,6 +535,257 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradParams wp
 }
 
 // ---------------------------------------------------------------------------------------------
+// wgrad2w_kernel (round 3): wgrad_pipe_kernel's 192 x 192 workgroup tile, LDS-DMA ring of three buffers, split / partial
+// / rider-share layout -- with EIGHT waves (two per SIMD) of 96 x 48 on v_mfma_f32_16x16x4_f32 instead of four waves of
+// 96 x 96 on 32x32x2.  Why: with one wave per SIMD every ds_read / LDS-DMA / rider instruction between two MFMAs stalls
+// the matrix pipe (~13 cycles each; ablations of wgrad_pipe_kernel: reads + loop 2.8 %, DMA issue 1.4 %, riders 1.6 %);
+// with a second wave on the SIMD those issue beside the other wave's MFMAs (tools/ubench/mfma_2w.hip) and a VALU
+// instruction costs ~4.  A wave's registers: 72 accumulators (6 x 3 tiles of 16 x 16) + 2 x 36 operand registers.
+//
+// Contraction order (free): lane group g = l >> 4 of a 16x16x4 MFMA supplies one sample; group g takes the 8 samples
+// 8 g .. 8 g + 7 of the chunk, as two 16-byte pieces (slot t: piece 2 g + ((t + rot) & 1)), component e of a piece at MFMA
+// step 4 t + e.  A lane's operand for 4 steps of one tile is ONE ds_read_b128 of the swizzled [row][32 samples] image.
+// Riders: the 4 tiles_k waves-columns that hold the same dY rows share the 8 steps: holder hc takes component hc & 3 of
+// slot 0 (rot = hc >> 2), or of both slots when there are only 4 holders (tiles_k = 1); the loop body is instantiated
+// for the 4 components and picked once per wave.  The density-head dot (one layer in twelve) is taken by the waves of
+// the first row block alone, through a 0 / 1 scale factor instead of a branch.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 mfma16w(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+template <bool VEC, bool CS2>
+__global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
+    constexpr int TN = 192, TK = 192, WKG = 4;                    // wave grid 2 (rows) x 4 (columns): 96 x 48 per wave
+    constexpr int XA = 6, XB = 3;                                 // 16-row tiles per wave
+    constexpr int BUF_BYTES = (TN + TK) * CHUNK * 4;              // 48 KiB
+    constexpr int NPIECE = BUF_BYTES / 1024 / 8;                  // 6 DMA pieces of 1 KiB per wave per chunk
+    __shared__ __attribute__((aligned(1024))) char lds[3 * BUF_BYTES];
+    const int tiles = wp.tiles_n * wp.tiles_k;
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int split = xcd + 8 * (slot / tiles);
+    const int tile = slot % tiles;
+    if (split >= wp.batch * wp.spi) return;
+    const int tn = tile / wp.tiles_k, tk = tile - tn * wp.tiles_k;
+    const ClkProbe clk0 = clk_begin();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave / WKG, wk = wave % WKG;
+    const int li = lane & 15, lg = lane >> 4;
+    const int b = split / wp.spi, sp = split - b * wp.spi;
+    const long c0 = (long)b * wp.chunks_per_image + (long)sp * wp.chunks_per_split;
+    long c1 = c0 + wp.chunks_per_split;
+    const long cmax = (long)(b + 1) * wp.chunks_per_image;
+    if (c1 > cmax) c1 = cmax;
+    const int nchunks = (int)(c1 - c0);
+
+    const unsigned chunk_a = (unsigned)(wp.lda * CHUNK * 4), chunk_b = (unsigned)(wp.ldb * CHUNK * 4);
+    auto desc = [&](const float* base, long ld, long tile_row0, unsigned chunk_bytes) {
+        const unsigned long long a = (unsigned long long)(base + c0 * (CHUNK * ld) + tile_row0 * CHUNK);
+        long bytes = (long)nchunks * chunk_bytes - tile_row0 * CHUNK * 4;
+        if (bytes < 0) bytes = 0;
+        i32x4 r;
+        r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+        r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+        r.z = __builtin_amdgcn_readfirstlane((int)(unsigned)bytes);
+        r.w = 0x00020000;
+        return r;
+    };
+    const i32x4 rsa = desc(wp.A, wp.lda, (long)tn * TN, chunk_a);
+    const i32x4 rsb = desc(wp.B, wp.ldb, (long)tk * TK, chunk_b);
+    // lane l fills slot l%8 of row 8i + l/8 with source piece (l%8) ^ ((4i + l/16) % 8)   (as wgrad_pipe_kernel)
+    const unsigned voff_even = (unsigned)(lane >> 3) * 128u + (unsigned)((lane & 7) ^ (lane >> 4)) * 16u;
+    const unsigned voff_odd = voff_even ^ 64u;
+    const unsigned lds0 = (unsigned)(size_t)&lds[0];
+    constexpr int PA = TN / 8;                                    // A pieces per chunk (24), then TK / 8 B pieces
+    // piece j (0 .. NPIECE-1) of this wave's share of chunk c0 + k, into ring buffer `buf`: global piece index 8 j + wave
+    auto dma_piece = [&](int k, int buf, int j) {
+        const unsigned gp = (unsigned)(8 * j + wave);
+        const bool isa = 8 * j < PA;                              // static after unrolling (PA = 24: j < 3): no branch
+        const unsigned i = isa ? gp : gp - PA;
+        const unsigned l = lds0 + (unsigned)buf * BUF_BYTES + (isa ? 0u : (unsigned)(TN * CHUNK * 4)) + i * 1024u;
+#ifdef GNR_WG_HOT      /* timing experiment (wrong results): every request re-reads one of the first 8 chunks -> operands L2-resident */
+        const unsigned so = (unsigned)(k & 7) * (isa ? chunk_a : chunk_b) + i * 1024u;
+#else
+        const unsigned so = (unsigned)k * (isa ? chunk_a : chunk_b) + i * 1024u;
+#endif
+        unsigned keep;
+        if (isa)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"((i & 1) ? voff_odd : voff_even), "s"(rsa), "s"(l), "s"(so) : "memory");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"((i & 1) ? voff_odd : voff_even), "s"(rsb), "s"(l), "s"(so) : "memory");
+    };
+    auto dma_chunk = [&](int k, int buf) {
+#pragma unroll
+        for (int j = 0; j < NPIECE; ++j) dma_piece(k, buf, j);
+    };
+
+    // rider shares: holders of the same dY rows = the (tk, wk) waves
+    const int hc = tk * WKG + wk;                                 // 0 .. 4 tiles_k - 1
+    const int rot = CS2 ? 0 : (hc >> 2);                          // which piece is "slot 0"
+    // operand read offsets (bytes within a ring buffer) of slot t: row wn*96 + 16 x + li (A) / wk*48 + 16 y + li (B),
+    // piece 2 lg + ((t + rot) & 1).  The swizzle term depends on (row/2)%8 = (li/2)%8 only: tile x is a constant
+    // + 2048 bytes.
+    int apos[2], bpos[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        apos[t] = 4 * swz(wn * 96 + li, 2 * lg + ((t + rot) & 1));
+        bpos[t] = 4 * (TN * CHUNK + swz(wk * 48 + li, 2 * lg + ((t + rot) & 1)));
+    }
+    float csl[XA], vsl[XB];
+#pragma unroll
+    for (int x = 0; x < XA; ++x) csl[x] = 0.0f;
+#pragma unroll
+    for (int y = 0; y < XB; ++y) vsl[y] = 0.0f;
+    f32x4 acc[XA][XB];
+#pragma unroll
+    for (int x = 0; x < XA; ++x)
+#pragma unroll
+        for (int y = 0; y < XB; ++y) acc[x][y] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const float vscale = (VEC && wn == 0 && tn == 0) ? 1.0f : 0.0f;    // the density dot is taken by the first row block
+
+    f32x4 opa[2][XA], opb[2][XB], vv[2], vnext;
+    auto read_ops = [&](int buf, int t, f32x4 (&a)[XA], f32x4 (&bb)[XB]) {
+        const char* pa = lds + buf * BUF_BYTES + apos[t];
+        const char* pb = lds + buf * BUF_BYTES + bpos[t];
+#pragma unroll
+        for (int x = 0; x < XA; ++x) a[x] = *(const f32x4*)(pa + x * (16 * CHUNK * 4));
+#pragma unroll
+        for (int y = 0; y < XB; ++y) bb[y] = *(const f32x4*)(pb + y * (16 * CHUNK * 4));
+    };
+    // density vector: the samples of slot t of this lane group, scaled by 0 / 1
+    auto load_vec = [&](int k, int t) -> f32x4 {
+        const long c = c0 + (k < nchunks ? k : nchunks - 1);
+        const f32x4 v = *(const f32x4*)(wp.vec + c * CHUNK + 8 * lg + 4 * ((t + rot) & 1));
+        return f32x4{v.x * vscale, v.y * vscale, v.z * vscale, v.w * vscale};
+    };
+
+    // prologue: chunks 0 and 1 in flight; slot 0 of chunk 0 into operand set 0
+    dma_chunk(0, 0);
+    dma_chunk(1, 1);
+    wait_vm_dma<NPIECE>();                                  // everything but the last chunk's pieces
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_ops(0, 0, opa[0], opb[0]);
+    if (VEC) vv[0] = load_vec(0, 0);
+
+    // One chunk = two slots of four MFMA steps (18 MFMAs each).  Operand set t holds slot t; while slot t is multiplied
+    // the other set receives the next slot (the same chunk's slot 1, or slot 0 of chunk k+1 after that chunk's barrier).
+    // PH de-phases the two waves of a SIMD: they pass every barrier together, so with the same code both would issue
+    // their LDS reads and DMA requests at the same moments and neither would have an MFMA to issue meanwhile
+    // (tools/ubench/mfma_2w.hip: two in-phase waves 92 %, two independent ones 97 %).  The second wave of each SIMD
+    // (PH = 1) issues the next slot's reads after MFMA step 1 instead of before step 0 and its DMA pieces a step later.
+    auto chunk = [&](int k, int b0, int b1, int b2, auto etag, auto phtag) {
+        constexpr int E = decltype(etag)::value;
+        constexpr int PH = decltype(phtag)::value;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            auto next_reads = [&]() {
+                if (t == 0) {
+                    read_ops(b0, 1, opa[1], opb[1]);
+                    // both density-vector loads of the coming slots go out HERE, a slot ahead of the LDS-DMA pieces of
+                    // t = 1: the compiler's counted wait for them (it cannot see the asm requests in the same in-order
+                    // vmcnt queue) then never waits on a piece that has just been issued
+                    if (VEC) { vv[1] = load_vec(k, 1); vnext = load_vec(k + 1, 0); }
+                } else {
+                    read_ops(b1, 0, opa[0], opb[0]);
+                    if (VEC) vv[0] = vnext;
+                }
+            };
+            if (t == 1 && !(PABL & 4)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // chunk k+1 (requested one chunk ago) has landed
+                __builtin_amdgcn_s_barrier();                          // ... in every wave; ring buffer b2 is free
+                asm volatile("" ::: "memory");
+            }
+            if (PH == 0) next_reads();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int x = 0; x < XA; ++x)
+#pragma unroll
+                    for (int y = 0; y < XB; ++y) acc[x][y] = mfma16w(opa[t][x][e], opb[t][y][e], acc[x][y]);
+                if (e == E && (t == 0 || CS2) && !(PABL & 1)) {
+#pragma unroll
+                    for (int x = 0; x < XA; ++x) csl[x] += opa[t][x][e];
+                }
+                if (VEC) {
+#pragma unroll
+                    for (int y = 0; y < XB; ++y) vsl[y] = fmaf(vv[t][e], opb[t][y][e], vsl[y]);
+                }
+                if (PH == 1 && e == 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    next_reads();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // the request for chunk k+2 goes out two pieces per MFMA step of the second slot (after the barrier that
+                // freed its ring buffer): steps 0-2 in the first wave of a SIMD, 1-3 in the second
+                if (t == 1 && e >= PH && e < 3 + PH && !(PABL & 2)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    dma_piece(k + 2, b2, 2 * (e - PH));
+                    dma_piece(k + 2, b2, 2 * (e - PH) + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto run = [&](auto etag, auto phtag) {
+        int b0 = 0;
+        for (int k = 0; k < nchunks; ++k) {
+            const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+            chunk(k, b0, b1, b2, etag, phtag);
+            b0 = b1;
+        }
+    };
+    auto run_e = [&](auto etag) {
+        if (wave < 4) run(etag, std::integral_constant<int, 0>{});        // waves w and w + 4 share SIMD w % 4
+        else run(etag, std::integral_constant<int, 1>{});
+    };
+    switch (hc & 3) {
+        case 0: run_e(std::integral_constant<int, 0>{}); break;
+        case 1: run_e(std::integral_constant<int, 1>{}); break;
+        case 2: run_e(std::integral_constant<int, 2>{}); break;
+        default: run_e(std::integral_constant<int, 3>{}); break;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the zero-filled tail requests
+
+    clk_end(clk0, wp.clk);
+    float* pt = wp.partial + (((long)split * wp.tiles_n + tn) * wp.tiles_k + tk) * (long)(TN * TK);
+#pragma unroll
+    for (int x = 0; x < XA; ++x)
+#pragma unroll
+        for (int y = 0; y < XB; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = wn * 96 + x * 16 + 4 * lg + r;      // D register r of a 16x16 tile: row 4 (l>>4) + r
+                const int jx = wk * 48 + y * 16 + li;
+                pt[i * TK + jx] = acc[x][y][r];
+            }
+    // rider shares: colsum_part[split][hc][tiles_n*TN], vec_part[split][0][tiles_k*TK]
+    {
+        const int Qc = wp.tiles_k * WKG;
+#pragma unroll
+        for (int x = 0; x < XA; ++x) {
+            float t = csl[x];
+            t += __shfl_xor(t, 16);
+            t += __shfl_xor(t, 32);
+            if (lg == 0) wp.colsum_part[((long)split * Qc + hc) * (wp.tiles_n * TN) + tn * TN + wn * 96 + 16 * x + li] = t;
+        }
+        if (VEC && wn == 0 && tn == 0) {
+#pragma unroll
+            for (int y = 0; y < XB; ++y) {
+                float t = vsl[y];
+                t += __shfl_xor(t, 16);
+                t += __shfl_xor(t, 32);
+                if (lg == 0) wp.vec_part[(long)split * (wp.tiles_k * TK) + tk * TK + wk * 48 + 16 * y + li] = t;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // wgrad3_tr_kernel: the bf16x3 weight-gradient GEMM from PRE-SPLIT operands, with nothing but LDS-DMA, transposing
 // LDS reads and MFMAs in its loop.
 //
@@ -632,7 +887,11 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr_kernel(const WgradParams wp)
                 const bool isa = j < QA / 2;
                 const unsigned i = (unsigned)(isa ? j : j - QA / 2);
                 const unsigned l = lds0 + (unsigned)buf * BUF_BYTES + (isa ? 0u : (unsigned)A_BYTES) + i * 1024u;
-                const unsigned so = (unsigned)k * (isa ? chunk_a : chunk_b) + i * 1024u;
+        #ifdef GNR_WG_HOT      /* timing experiment (wrong results): every request re-reads one of the first 8 chunks -> operands L2-resident */
+        const unsigned so = (unsigned)(k & 7) * (isa ? chunk_a : chunk_b) + i * 1024u;
+#else
+        const unsigned so = (unsigned)k * (isa ? chunk_a : chunk_b) + i * 1024u;
+#endif
                 if (isa)
                     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" :: "v"(voff), "s"(rsa), "s"(l), "s"(so) : "memory");
                 else
@@ -1040,6 +1299,11 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
         fprintf(stderr, "gnr: bf16x3 weight gradient asked for an unsupported shape (%d x %d, ld %d / %d)\n", n_valid, k_valid, lda, ldb);
         abort();
     }
+#ifdef GNR_WG_NO2W
+    const bool two_wave = false;
+#else
+    const bool two_wave = !bf16x3 && pipe_xk == 3;
+#endif
     const int cfg = pipe_xk ? 0 : choose_tile(n_valid, k_valid, with_vec);
     const int TN = pipe_xk ? 192 : kTileCfgs[cfg].tn, TK = pipe_xk ? 64 * pipe_xk : kTileCfgs[cfg].tk;
     wp.tiles_n = (n_valid + TN - 1) / TN;
@@ -1071,6 +1335,11 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
         if (pipe_xk == 1) hipLaunchKernelGGL((wgrad3_tr_kernel<1, false>), dim3(blocks), dim3(512), 0, stream, wp);
         else if (wp.vec) hipLaunchKernelGGL((wgrad3_tr_kernel<3, true>), dim3(blocks), dim3(512), 0, stream, wp);
         else hipLaunchKernelGGL((wgrad3_tr_kernel<3, false>), dim3(blocks), dim3(512), 0, stream, wp);
+    } else if (pipe_xk == 3 && two_wave) {
+        // round 3: the same 192 x 192 tiles on eight waves (two per SIMD) of 16x16x4 MFMAs
+        if (wp.vec) hipLaunchKernelGGL((wgrad2w_kernel<true, false>), dim3(blocks), dim3(512), 0, stream, wp);
+        else if (wp.tiles_k == 2) hipLaunchKernelGGL((wgrad2w_kernel<false, false>), dim3(blocks), dim3(512), 0, stream, wp);
+        else hipLaunchKernelGGL((wgrad2w_kernel<false, true>), dim3(blocks), dim3(512), 0, stream, wp);
     } else if (pipe_xk) {
         // CSG = rider slots per wave = 4 / (2 tiles_k)
         if (pipe_xk == 1) hipLaunchKernelGGL((wgrad_pipe_kernel<3, 1, false, 2>), dim3(blocks), dim3(256), 0, stream, wp);
@@ -1091,6 +1360,7 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
     rp.partial = scratch; rp.splits = splits; rp.tiles_n = wp.tiles_n; rp.tiles_k = wp.tiles_k;
     rp.tn_rows = TN; rp.tk_cols = TK;
     rp.cs_q = pipe_xk ? 2 * wp.tiles_k : 1; rp.vs_q = pipe_xk ? 2 * wp.tiles_n : 1;
+    if (two_wave) { rp.cs_q = 4 * wp.tiles_k; rp.vs_q = 1; }
     rp.n_valid = n_crop; rp.k_valid = k_crop; rp.dW = dW; rp.ldw = ldw; rp.col_off = col_off; rp.enc_map = enc_map;
     rp.colsum_part = cs_part; rp.colsum_out = colsum_out; rp.colsum_ld = colsum_ld; rp.batch = batch; rp.spi = (int)spi;
     rp.vec_part = vec_part; rp.vec_out = vec_out ? vec_out : nullptr;
