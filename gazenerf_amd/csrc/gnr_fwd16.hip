@@ -152,22 +152,14 @@ __global__ __launch_bounds__(256, 2) void fwd16_kernel(const FwdParams fp) {
         // only the sign bits are written at the layer boundary.  The bias enters through the C operand of the first
         // MFMA of every output tile (read from the LDS table), so the epilogue is the activation alone.
         unsigned mkw[RELU16_WORDS];
-#ifdef GNR_BIAS_POST   /* experiment: bias added after the sum (round 2's order) instead of seeding the accumulator */
-#define GNR_BIAS(L) [&](int nt) { bias_row = bias_lds + b16_off(L); return f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
-#define GNR_BADD(x, t, e) ((x) + bias_row[16 * (t) + 4 * g + (e)])
-#else
 #define GNR_BIAS(L) [&](int nt) { return *(const f32x4*)(bias_lds + b16_off(L) + 16 * nt + 4 * g); }
-#define GNR_BADD(x, t, e) (x)
-#endif
-        const float* bias_row = bias_lds;
-        (void)bias_row;
 #define GNR_RELU(X)                                                                                      \
     [&](int t) {                                                                                         \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                  \
             /* ReLU as one v_max_i32 on the bit pattern (negative floats are negative integers).  Training:     \
                sign bit = min(relu bits, 1), pushed into the tile group's word -- v_min_u32 (asm: LLVM turns    \
                umin(select, 1) back into compare + select) + v_lshl_or_b32: 3 VALU per value in all */          \
-            const float v = GNR_BADD(X[t][e], t, e);                                                     \
+            const float v = X[t][e];                                                                     \
             const int bi = __builtin_bit_cast(int, v);                                                   \
             const int r = bi > 0 ? bi : 0;                                                               \
             X[t][e] = __builtin_bit_cast(float, r);                                                      \
@@ -179,11 +171,7 @@ __global__ __launch_bounds__(256, 2) void fwd16_kernel(const FwdParams fp) {
             }                                                                                            \
         }                                                                                                \
     }
-#ifdef GNR_BIAS_POST
-        auto noneA = [&](int t) { _Pragma("unroll") for (int e = 0; e < 4; ++e) A[t][e] = GNR_BADD(A[t][e], t, e); };
-#else
         auto noneA = [](int) {};
-#endif
         auto put_bits = [&](int layer, int words) {
             if (SAVE && !(ABL16 & 1)) {
                 const Dump16 dst = sb(layer);
@@ -250,7 +238,6 @@ __global__ __launch_bounds__(256, 2) void fwd16_kernel(const FwdParams fp) {
         // RGB2: Bv[0..12) -> A[0..18)  (258 channels padded to 288; no sigmoid, mlp_nerf.py:116); dumps y1
         mm16_h<NT16_H2, NT16_F, true, SAVE && !(ABL16 & 2)>(Bv, A, w, dp(ws.act_y1, H2), GNR_BIAS(LR2), noneA);
 #undef GNR_BIAS
-#undef GNR_BADD
 #undef GNR_RELU
         if (SAVE && !(ABL16 & 4)) dump16<NT16_F>(A, dump_dst16(ws.act_feat, FEAT_PAD, sub, lane_off));
 
