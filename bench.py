@@ -49,7 +49,7 @@ PEAK_BF16X3_TFLOPS = 16.0 * PEAK_FP32_MFMA_TFLOPS / 3.0
 HBM_PEAK_GBS = 8000.0
 PEAK_CLOCK_MHZ = 2400.0                       # the clock both MFMA peaks are quoted at
 # the weight-gradient stage: its main kernel instance first (the 384^2 layers), then what else runs inside the bracket
-WGRAD_KERNEL = {False: "gnr::wgrad_pipe_kernel<3, 3, false, 1> + its other instances + gnr::wgrad_reduce_kernel",
+WGRAD_KERNEL = {False: "gnr::wgrad2w_kernel<false, false> + its other instances + gnr::wgrad_pipe_kernel<3, 1, false, 2> + gnr::wgrad_reduce_kernel",
                 True: "gnr::wgrad3_tr_kernel<3, false> + its other instances + gnr::wgrad_reduce_kernel"}
 
 
@@ -68,7 +68,7 @@ def parse():
                          "3-term hi/lo split (fp32 accumulate)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16x3 leg of an fp32 run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=90.0, help="seconds of CPU-baseline work (wall cap)")
+    ap.add_argument("--cpu-budget", type=float, default=110.0, help="seconds of CPU-baseline work (wall cap)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("GNR_BENCH_SCALING", "weak"),
                     help="cfg2b: weak = one image per GPU; strong = ONE image, rays sharded over the GPUs")
     ap.add_argument("--gather", action="store_true", help="strong scaling, fwd: all_gather the feature maps to every rank inside the step")
@@ -171,14 +171,14 @@ def cpu_baseline(mode, n_samples, budget_s):
         return n / med, n, len(times), med
 
     # cfg2a (4096 rays) x 3 at every core, 1024 rays x 3 at one thread (the reference pins itself to 1)
-    v_all, n_all, r_all, s_all = leg(cores, 0.62 * budget_s, 4096)
+    v_all, n_all, r_all, s_all = leg(cores, 0.52 * budget_s, 4096)
     res = {"value": v_all, "unit": "rays/s", "cores": cores, "kind": "port", "host_logical_cpus": os.cpu_count(),
            "cores_basis": cores_basis,
            "sample": "cfg2a subset: %d of 4096 rays x %d samples, both streams, %s; median of %d run(s) of %.2f s at "
                      "torch.set_num_threads(%d) = every core this process may use (%s); PyTorch-CPU oracle pinned to the "
                      "reference by tests/golden; wall cap %.0f s" % (n_all, n_samples, mode, r_all, s_all, cores, cores_basis, budget_s)}
     # the reference pins itself to ONE thread (train.py / gazenerf_trainer: torch.set_num_threads(1))
-    v1, n1, r1, s1 = leg(1, 0.38 * budget_s, 1024)
+    v1, n1, r1, s1 = leg(1, 0.48 * budget_s, 1024)
     res["value_1_thread"] = v1
     res["sample_1_thread"] = "%d rays, %d run(s) of %.2f s" % (n1, r1, s1)
     torch.set_num_threads(cores)

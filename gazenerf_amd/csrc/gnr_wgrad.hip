@@ -543,8 +543,13 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradParams wp
 // instruction costs ~4.  A wave's registers: 72 accumulators (6 x 3 tiles of 16 x 16) + 2 x 36 operand registers.
 //
 // Contraction order (free): lane group g = l >> 4 of a 16x16x4 MFMA supplies one sample; group g takes the 8 samples
-// 8 g .. 8 g + 7 of the chunk, as two 16-byte pieces (slot t: piece 2 g + ((t + rot) & 1)), component e of a piece at MFMA
-// step 4 t + e.  A lane's operand for 4 steps of one tile is ONE ds_read_b128 of the swizzled [row][32 samples] image.
+// 4 g .. 4 g + 3 and 16 + 4 g .. 16 + 4 g + 3 of the chunk, as two 16-byte pieces (slot t: piece g + 4 ((t + rot) & 1)),
+// component e of a piece at MFMA step 4 t + e.  A lane's operand for 4 steps of one tile is ONE ds_read_b128 of the
+// swizzled [row][32 samples] image.  Pieces g and g + 4 (not 2 g, 2 g + 1): ds_read_b128 executes in four phases of 16
+// NON-contiguous lanes -- {0-3, 12-15, 20-23, 24-27}, {4-7, 8-11, 16-19, 28-31} and the same + 32 -- so a phase mixes two
+// lane groups on different row quartets; with the image's XOR swizzle (piece ^ (row/2)%8, built for 32-row tiles) pieces
+// 2 g of one group and 2 g + 2 of the next collide on half the rows (PMC: 4 conflict cycles per read, 6 % of the
+// kernel), pieces g and g + 1 never do.
 // Riders: the 4 tiles_k waves-columns that hold the same dY rows share the 8 steps: holder hc takes component hc & 3 of
 // slot 0 (rot = hc >> 2), or of both slots when there are only 4 holders (tiles_k = 1); the loop body is instantiated
 // for the 4 components and picked once per wave.  The density-head dot (one layer in twelve) is taken by the waves of
@@ -630,8 +635,8 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
     int apos[2], bpos[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        apos[t] = 4 * swz(wn * 96 + li, 2 * lg + ((t + rot) & 1));
-        bpos[t] = 4 * (TN * CHUNK + swz(wk * 48 + li, 2 * lg + ((t + rot) & 1)));
+        apos[t] = 4 * swz(wn * 96 + li, lg + 4 * ((t + rot) & 1));
+        bpos[t] = 4 * (TN * CHUNK + swz(wk * 48 + li, lg + 4 * ((t + rot) & 1)));
     }
     float csl[XA], vsl[XB];
 #pragma unroll
@@ -657,7 +662,7 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
     // density vector: the samples of slot t of this lane group, scaled by 0 / 1
     auto load_vec = [&](int k, int t) -> f32x4 {
         const long c = c0 + (k < nchunks ? k : nchunks - 1);
-        const f32x4 v = *(const f32x4*)(wp.vec + c * CHUNK + 8 * lg + 4 * ((t + rot) & 1));
+        const f32x4 v = *(const f32x4*)(wp.vec + c * CHUNK + 4 * lg + 16 * ((t + rot) & 1));
         return f32x4{v.x * vscale, v.y * vscale, v.z * vscale, v.w * vscale};
     };
 
