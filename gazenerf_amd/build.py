@@ -16,8 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libgnr.so")
-SOURCES = ["gnr_api.hip", "gnr_prep.hip", "gnr_fwd.hip", "gnr_fwd16.hip", "gnr_bwd.hip", "gnr_bwd16.hip", "gnr_wgrad.hip", "gnr_merge.hip", "gnr_vd.hip", "gnr_fwd3.hip", "gnr_bwd3.hip", "gnr_upsample.hip"]
-HEADERS = ["gnr_internal.h", "gnr_device.h", "gnr_chain.h", "gnr_chain16.h", "gnr_chain3.h", "gnr_bwd_common.h", os.path.join("..", "..", "include", "gnr.h")]
+SOURCES = ["gnr_api.hip", "gnr_prep.hip", "gnr_fwd.hip", "gnr_fwd16.hip", "gnr_bwd.hip", "gnr_bwd16.hip", "gnr_wgrad.hip", "gnr_merge.hip", "gnr_vd.hip", "gnr_fwd3.hip", "gnr_bwd3.hip", "gnr_conv16.hip", "gnr_upsample.hip"]
+HEADERS = ["gnr_internal.h", "gnr_device.h", "gnr_chain.h", "gnr_chain16.h", "gnr_conv16.h", "gnr_chain3.h", "gnr_bwd_common.h", os.path.join("..", "..", "include", "gnr.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # timing experiments only (tools/ab_variants.sh): extra -D switches, applied to the files named in GNR_EXTRA_FILES

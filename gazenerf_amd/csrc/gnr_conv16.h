@@ -1,0 +1,56 @@
+// gnr_conv16.h -- the 1x1-convolution GEMM of the upsampler, round 3: interface between
+// gnr_conv16.hip (kernels) and gnr_upsample.hip (the NeuralRenderer forward / backward that launches them).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+
+namespace gnr {
+
+// Tile variant of one GEMM: a wave owns MT row tiles of 16 channels x NT pixel tiles of 16 pixels.
+struct Conv16Plan {
+    int MT, NT;
+    int slices;          // row slices of 16 MT channels (the last one zero padded)
+    int nkb;             // 16-wide blocks of the contraction index
+    size_t pack_floats;  // size of the packed A operand: slices * nkb * MT * 256
+};
+
+// Chooses the variant for C[M][pixels] = A[M][K] B[K][pixels] over `pixels_total` = batch * pixels per image.
+// `blur_w` != 0: the B operand is read through the 3x3 blur stencil of an image `blur_w` pixels wide (forward
+// feat_layers); only some variants have that instance -- plan.MT == 0 on return means "none fits, run the stencil as
+// its own kernel".
+Conv16Plan conv16_plan(int M, int K, long pixels_total, int blur_w);
+
+constexpr int CONV16_MAX_JOBS = 12;
+struct Conv16PackJobs {
+    int n;
+    struct Job {
+        const float* W; long rs, cs;      // A(m,k) = W[m*rs + k*cs]
+        int M, K, MT, nkb, slices;
+        long dst_off, floats;             // into `dst`
+    } j[CONV16_MAX_JOBS];
+    float* dst;
+};
+// Adds a job; returns the offset (floats) of its packed operand inside the pack buffer.
+long conv16_add_job(Conv16PackJobs& jobs, const float* W, long rs, long cs, int M, int K, const Conv16Plan& plan);
+void launch_conv16_pack(const Conv16PackJobs& jobs, hipStream_t st);      // ONE launch for every GEMM of a call
+
+struct Conv16Params {
+    Conv16Plan plan;
+    const float* At;                               // packed A operand of this GEMM
+    const float* B; long b_batch;                  // B(b,k,n) = B[b*b_batch + k*P + n]
+    float* C; long c_batch;                        // C(b,m,n) = C[b*c_batch + m*P + n]   (plain store)
+    int M, K, P, batch;                            // P = pixels per image, P % 256 == 0
+    const float* bias;                             // [M] or NULL
+    int leaky;                                     // LeakyReLU(0.2) on (acc + bias)
+    const float* mask_ref; long mask_batch;        // result *= (mask_ref(b,m,n) > 0 ? 1 : 0.2)
+    int accumulate;                                // C += result
+    int shuffle, W;                                // PixelShuffleUpsample tail: n = y*W + x
+    const float* res; long res_batch;              // residual res(b, m % (M/4), n)
+    unsigned char* sign_out; long sign_batch;      // shuffle: bit e of byte (b, m/4, n) = (acc + bias > 0) of channel 4(m/4)+e
+    int blur, H;                                   // B operand = blur(B) with reflect padding, image H x W (W above)
+    int dephase;                                   // set by launch_conv16
+};
+void launch_conv16(const Conv16Params& cp, hipStream_t st);
+
+}  // namespace gnr

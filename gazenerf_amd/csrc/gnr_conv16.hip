@@ -1,0 +1,419 @@
+// gnr_conv16.hip -- the 1x1 convolutions of the upsampler as register-fed fp32 MFMA GEMMs, gfx950.
+//
+// C[M][N] = epilogue(A[M][K] B[K][N]) for channels-first images (N = pixels, contiguous): the 1x1 convolutions of
+// PixelShuffleUpsample (models/pixel_shuffle_upsample.py:19-42) and NeuralRenderer.feat_layers
+// (models/neural_renderer.py:60-113) and their data gradients (A = W^T through strides).
+//
+// Round 2's conv_gemm_kernel staged both operands through LDS (LDS-DMA, one barrier per 16 k) and ran at 0.45-0.70 of the
+// fp32-MFMA peak on these shapes: M is one channel past a multiple of 128 (129, 258, 516, 1032: 10-33 % padded rows),
+// K is 64-516 (4-33 k-tiles: prologue, epilogue and barriers are a large share), and at B = 1 most layers launch fewer
+// workgroups than the chip has slots.  This kernel applies what round 3 measured for the MLP chain (DESIGN.md section 5,
+// tools/ubench/mfma_2w.hip): two INDEPENDENT waves per SIMD -- no LDS, no barrier -- each feeding
+// v_mfma_f32_16x16x4_f32 straight from registers reach 97 % of the matrix pipe, because one wave's loads, waits and
+// epilogue issue beside the other's MFMAs.
+//
+// A wave owns MT row tiles (16 channels) x NT pixel tiles (16 pixels) over the WHOLE contraction:
+//   * A (weights, <= 2 MB, re-laid out once per call by conv16_pack_kernel as [slice][k-block][row tile][lane][4]):
+//     one buffer_load_b128 per row tile per 16 k = the lane's A values of 4 MFMA steps; every wave of a row slice
+//     streams the same bytes -- L1 / L2 hits.
+//   * B (activations): the contraction order is free, so lane group g = l >> 4 takes k = 16 kb + 4 s + g at step s;
+//     a lane's load is NT CONSECUTIVE PIXELS of that row (b128 / b64) -- pixel NT*li + t feeds column li of pixel tile
+//     t, so one load feeds NT MFMAs and the lane ends up owning NT consecutive pixels of each of its rows: vector
+//     stores in the epilogue.  Rows k >= K read zeros through the buffer descriptor's bound.
+//   * both operand sets of block kb+1 are requested before the MFMAs of block kb (register double buffer): a whole
+//     block of MFMAs (MT*NT*4 x 32 cycles) covers the latency.  vmcnt is in-order, so A cannot run a shorter prefetch
+//     distance than B without forcing B's loads home early -- hence 2 x MT x 4 A registers.
+//   * MT x NT per layer from a small cost model (padded work x fill of the 1024 SIMDs): 1032 rows = 5 x 13 tiles
+//     exactly, 516 = 3 x 11, 258 -> 2 x 9, 129 -> 9; at B = 1 smaller slices when the chip would be under-filled.
+//   * workgroup id -> (XCD, slot): an XCD takes a contiguous range of (pixel tile, row slice) items, row slice fastest,
+//     so the slices of one pixel tile re-read its B rows from the same L2.
+// BLUR instances (forward feat_layers): the B operand is blur(u), computed on the fly from three rows of u (reflect
+// padding == kornia filter2d border_type='reflect', same taps and order as blur_kernel) -- the blurred map is never
+// written; the backward uses blur's adjoint on the (half as wide) gradient instead (gnr_upsample.hip).
+#include "gnr_conv16.h"
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#include "gnr_chain16.h"
+
+namespace gnr {
+
+int fail(const char* fmt, ...);
+
+namespace {
+
+#ifndef GNR_C16_ABL
+#define GNR_C16_ABL 0       // timing experiments (wrong results): 1 no epilogue, 2 B rows of k-block 0 only, 4 A of k-block 0 only, 8 no de-phasing,
+                            // 16 pseudo-random start offsets in the first 2560 blocks, 32 epilogue without its loads, 64 epilogue without its stores
+#endif
+constexpr float LEAK16 = 0.2f;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x4 mfma16c(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+template <int NT> struct Pix;
+template <> struct Pix<4> {
+    typedef f32x4 T;
+    static __device__ __forceinline__ T load(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (int)soff, 0));
+    }
+};
+template <> struct Pix<2> {
+    typedef f32x2 T;
+    static __device__ __forceinline__ T load(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+        return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, (int)soff, 0));
+    }
+};
+// forward Blur taps at position u of n (reflect padding: the out-of-range neighbour folds onto the inner one)
+__device__ __forceinline__ void blur_taps16(int u, int n, float& wl, float& wc, float& wr) {
+    wc = 0.5f;
+    wl = u >= 1 ? 0.25f : 0.0f;
+    wr = u + 1 < n ? 0.25f : 0.0f;
+    if (u == 0) wr += 0.25f;          // in[-1] -> in[1]
+    if (u == n - 1) wl += 0.25f;      // in[n]  -> in[n-2]
+}
+__device__ __forceinline__ float load1(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (int)soff, 0));
+}
+
+// dst[(((slice*nkb + kb)*MT + mt)*64 + lane)*4 + s] = A(16 (slice MT + mt) + lane%16, 16 kb + 4 s + lane/16), 0 outside
+__global__ __launch_bounds__(256) void conv16_pack_kernel(const Conv16PackJobs jobs) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    int j = 0;
+    while (j < jobs.n && i >= jobs.j[j].floats) { i -= jobs.j[j].floats; ++j; }
+    if (j >= jobs.n) return;
+    const Conv16PackJobs::Job& J = jobs.j[j];
+    const int s = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    long r = i >> 8;
+    const int mt = (int)(r % J.MT); r /= J.MT;
+    const int kb = (int)(r % J.nkb);
+    const int slice = (int)(r / J.nkb);
+    const int m = 16 * (slice * J.MT + mt) + (lane & 15), k = 16 * kb + 4 * s + (lane >> 4);
+    jobs.dst[J.dst_off + i] = (m < J.M && k < J.K) ? J.W[(long)m * J.rs + (long)k * J.cs] : 0.0f;
+}
+
+template <int MT, int NT, bool SHUF, bool BLUR>
+__global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params cp) {
+    typedef typename Pix<NT>::T pv;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int li = lane & 15, g = lane >> 4;
+    const int slices = cp.plan.slices;
+    const unsigned items = (unsigned)((long)cp.batch * cp.P / (64 * NT)) * (unsigned)slices;
+    const unsigned per_xcd = (items + 7u) >> 3;
+    const unsigned item = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (item >= items) return;
+    // The waves of a launch are equally long and start together: left alone, both waves of every SIMD run their prologue
+    // (first loads) and epilogue (stores) at the same moments -- matrix pipe idle, HBM idle during the MFMAs -- and the
+    // launch proceeds in lock-step rounds.  The odd wave slots of the first round start half a wave period late (the
+    // length of one wave alone on the pipe, cp.dephase x 127 x 64 cycles); every later wave inherits the offset of the
+    // slot it takes over.
+    if ((GNR_C16_ABL & 16) && blockIdx.x < 2560u && cp.dephase > 0) {
+        const int nsl = (int)((blockIdx.x * 2654435761u) >> 29) * cp.dephase / 4;
+#pragma unroll 1
+        for (int i = 0; i < nsl; ++i) __builtin_amdgcn_s_sleep(127);
+    } else
+    if (blockIdx.x < 512u && cp.dephase > 0 && !(GNR_C16_ABL & 8)) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        if (hw & 1u) {
+#pragma unroll 1
+            for (int i = 0; i < cp.dephase; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+    }
+    const unsigned pt = item / (unsigned)slices;
+    const int ms = (int)(item - pt * (unsigned)slices);
+    const unsigned pixg = pt * (unsigned)(64 * NT) + (unsigned)wave * (unsigned)(16 * NT);     // batch * P < 2^31
+    const int b = (int)(pixg / (unsigned)cp.P);
+    const int p0 = (int)(pixg - (unsigned)b * (unsigned)cp.P);    // the wave's first pixel inside image b
+    const int nkb = cp.plan.nkb;
+    const int m0 = ms * (16 * MT);
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(cp.At + (long)ms * nkb * (MT * 256)), 0, nkb * (MT * 1024), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(cp.B + (long)b * cp.b_batch), 0, (int)((long)cp.K * cp.P * 4), 0x00020000);
+    const unsigned voffA = (unsigned)lane * 16u;
+    const unsigned rowB = (unsigned)cp.P * 4u;                    // bytes per k row
+    const int n = p0 + NT * li;                                   // this lane's NT consecutive pixels
+    const unsigned voffB = ((unsigned)g * (unsigned)cp.P + (unsigned)n) * 4u;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[mt][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    f32x4 Aq[2][MT];
+    auto load_a = [&](int kb, f32x4 (&A)[MT]) {
+        const unsigned sa = (unsigned)__builtin_amdgcn_readfirstlane(((GNR_C16_ABL & 4) ? 0 : kb) * (MT * 1024));      // keep the stream offset scalar
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            A[mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, voffA, (int)(sa + (unsigned)mt * 1024u), 0));
+    };
+    auto compute = [&](const f32x4 (&A)[MT], const pv (&Bv)[4]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[mt][t] = mfma16c(A[mt][s], Bv[s][t], acc[mt][t]);
+    };
+
+    if constexpr (!BLUR) {
+        pv Bq[2][4];
+        auto load_b = [&](int kb, pv (&Bv)[4]) {
+            const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((GNR_C16_ABL & 2) ? 0 : kb) * 16u * rowB));
+#pragma unroll
+            for (int s = 0; s < 4; ++s) Bv[s] = Pix<NT>::load(rsB, voffB, sb + (unsigned)s * 4u * rowB);
+        };
+        load_b(0, Bq[0]);
+        load_a(0, Aq[0]);
+        int kb = 0;
+        for (; kb + 1 < nkb; kb += 2) {
+            load_b(kb + 1, Bq[1]);
+            load_a(kb + 1, Aq[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(Aq[0], Bq[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int k2 = kb + 2 < nkb ? kb + 2 : nkb - 1;       // even nkb: one redundant request at the end
+            load_b(k2, Bq[0]);
+            load_a(k2, Aq[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(Aq[1], Bq[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (nkb & 1) compute(Aq[0], Bq[0]);
+    } else {
+        // B = blur(u): rows y-1, y, y+1 of the lane's NT pixels plus the two edge neighbours, reflect padding.
+        const int W = cp.W, H = cp.H;
+        const int y = n / W, x = n - y * W;
+        float wl[NT], wr[NT], yl, yc, yr;
+        {
+            float wc;
+            blur_taps16(y, H, yl, yc, yr);
+#pragma unroll
+            for (int e = 0; e < NT; ++e) blur_taps16(x + e, W, wl[e], wc, wr[e]);
+        }
+        const int y0 = y >= 1 ? y - 1 : y, y2 = y + 1 < H ? y + 1 : y;
+        const int xm = x >= 1 ? x - 1 : x, xp = x + NT < W ? x + NT : x + NT - 1;
+        unsigned vc[3], vl[3], vr[3];
+        {
+            const int ys[3] = {y0, y, y2};
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const unsigned base = (unsigned)g * (unsigned)cp.P + (unsigned)(ys[q] * W);
+                vc[q] = (base + (unsigned)x) * 4u;
+                vl[q] = (base + (unsigned)xm) * 4u;
+                vr[q] = (base + (unsigned)xp) * 4u;
+            }
+        }
+        pv rc[4][3];
+        float rl[4][3], rr[4][3];
+        auto load_raw = [&](int kb) {
+            const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((GNR_C16_ABL & 2) ? 0 : kb) * 16u * rowB));
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const unsigned so = sb + (unsigned)s * 4u * rowB;
+                    rc[s][q] = Pix<NT>::load(rsB, vc[q], so);
+                    rl[s][q] = load1(rsB, vl[q], so);
+                    rr[s][q] = load1(rsB, vr[q], so);
+                }
+        };
+        // The raw rows of block kb+1 are requested before the MFMAs of block kb and folded into its B operand right after
+        // them: only the 4 NT operand registers are carried from one iteration to the next (with the raw rows carried
+        // instead, hipcc copies all 18 NT of them at the loop head and spills).
+        pv Bv[2][4];
+        auto combine = [&](pv (&Bo)[4]) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float row[3][NT];
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int e = 0; e < NT; ++e) {
+                        const float left = e == 0 ? rl[s][q] : rc[s][q][e - 1];
+                        const float right = e == NT - 1 ? rr[s][q] : rc[s][q][e + 1];
+                        row[q][e] = wl[e] * left + 0.5f * rc[s][q][e] + wr[e] * right;
+                    }
+#pragma unroll
+                for (int e = 0; e < NT; ++e) Bo[s][e] = yl * row[0][e] + yc * row[1][e] + yr * row[2][e];
+            }
+        };
+        load_raw(0);
+        load_a(0, Aq[0]);
+        combine(Bv[0]);
+        int kb = 0;
+        for (; kb + 1 < nkb; kb += 2) {
+            load_raw(kb + 1);
+            load_a(kb + 1, Aq[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(Aq[0], Bv[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            combine(Bv[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int k2 = kb + 2 < nkb ? kb + 2 : nkb - 1;
+            load_raw(k2);
+            load_a(k2, Aq[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(Aq[1], Bv[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            combine(Bv[0]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (nkb & 1) compute(Aq[0], Bv[0]);
+    }
+
+    // ---- epilogue: register e of acc[mt][t] is channel m0 + 16 mt + 4 g + e at pixel n + t ----
+    if ((GNR_C16_ABL & 1) && cp.K != -12345) return;
+    if constexpr (SHUF) {
+        // PixelShuffleUpsample tail.  A lane's four registers of one tile are in-channels 4c..4c+3 of its NT pixels, i.e.
+        // the 2x2 output blocks of out-channel c at NT consecutive x: two rows of 2 NT consecutive floats; the four
+        // pre-activation signs per pixel go into one nibble, the lane's pixels into one 8 NT-bit store.
+        const int Cq = cp.M / 4;
+        const int py = n / cp.W, px = n - py * cp.W;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int mb = m0 + 16 * mt + 4 * g;                  // multiple of 4
+            if (mb >= cp.M) continue;
+            float v[4][NT];                                       // [e: channel][t: pixel]
+            unsigned nib = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = mb + e;
+                const float bias = (GNR_C16_ABL & 32) ? 0.5f : cp.bias[m];
+                // x.repeat(1,4,1,1): in-channel m reads x channel m % (M/4)
+                pv res;
+                if (GNR_C16_ABL & 32) res = pv(0.25f);
+                else res = *(const pv*)(cp.res + (long)b * cp.res_batch + (long)(m % Cq) * cp.P + n);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    float u = acc[mt][t][e] + bias;
+                    nib |= (u > 0.0f ? 1u : 0u) << (8 * t + e);
+                    u = u > 0.0f ? u : LEAK16 * u;
+                    v[e][t] = u + res[t];
+                }
+            }
+            if ((GNR_C16_ABL & 64) && (nib != 0x12345u || v[0][0] != 1.2345f)) continue;
+            unsigned char* sp = cp.sign_out + (long)b * cp.sign_batch + (long)(mb >> 2) * cp.P + n;
+            if constexpr (NT == 4) *(unsigned*)sp = nib;
+            else *(unsigned short*)sp = (unsigned short)nib;
+            // pixel_shuffle(2): in-channel 4c + 2i + j -> out (c, 2y+i, 2x+j)
+            float* dst = cp.C + (long)b * cp.c_batch + (long)(mb >> 2) * (4L * cp.P) + (long)(2 * py) * (2 * cp.W) + 2 * px;
+#pragma unroll
+            for (int t = 0; t < NT; t += 2) {
+                *(f32x4*)(dst + 2 * t) = f32x4{v[0][t], v[1][t], v[0][t + 1], v[1][t + 1]};
+                *(f32x4*)(dst + 2 * cp.W + 2 * t) = f32x4{v[2][t], v[3][t], v[2][t + 1], v[3][t + 1]};
+            }
+        }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + 16 * mt + 4 * g + e;
+                if (m >= cp.M) continue;
+                pv v;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) v[t] = acc[mt][t][e];
+                if (cp.bias && !(GNR_C16_ABL & 32)) v += cp.bias[m];
+                if (cp.leaky) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) v[t] = v[t] > 0.0f ? v[t] : LEAK16 * v[t];
+                }
+                if (cp.mask_ref && !(GNR_C16_ABL & 32)) {
+                    const pv mk = *(const pv*)(cp.mask_ref + (long)b * cp.mask_batch + (long)m * cp.P + n);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) v[t] *= mk[t] > 0.0f ? 1.0f : LEAK16;
+                }
+                float* dst = cp.C + (long)b * cp.c_batch + (long)m * cp.P + n;
+                if (cp.accumulate && !(GNR_C16_ABL & 32)) v += *(const pv*)dst;
+                if ((GNR_C16_ABL & 64) && v[0] != 1.2345f) continue;
+                *(pv*)dst = v;
+            }
+    }
+}
+
+struct Variant { int MT, NT; bool blur; };
+// (row tiles, pixel tiles) instances; blur: the instance that reads B through the stencil exists (register budget)
+const Variant kVariants[] = {{13, 2, false}, {11, 2, false}, {9, 2, true}, {8, 4, false}, {4, 4, true}, {2, 4, true}};
+
+template <int MT, int NT>
+void launch_variant(const Conv16Params& cp, unsigned blocks, hipStream_t st) {
+    if (cp.shuffle) hipLaunchKernelGGL((conv16_kernel<MT, NT, true, false>), dim3(blocks), dim3(256), 0, st, cp);
+    else hipLaunchKernelGGL((conv16_kernel<MT, NT, false, false>), dim3(blocks), dim3(256), 0, st, cp);
+}
+template <int MT, int NT>
+void launch_variant_blur(const Conv16Params& cp, unsigned blocks, hipStream_t st) {
+    if (cp.blur) hipLaunchKernelGGL((conv16_kernel<MT, NT, false, true>), dim3(blocks), dim3(256), 0, st, cp);
+    else launch_variant<MT, NT>(cp, blocks, st);
+}
+
+}  // namespace
+
+Conv16Plan conv16_plan(int M, int K, long pixels_total, int blur_w) {
+    const int tiles = (M + 15) / 16;
+    Conv16Plan best{};
+    double best_cost = 0.0;
+    static const char* force = getenv("GNR_CONV16_FORCE");      // tuning: "MT,NT" for every GEMM that has the instance
+    int fmt = 0, fnt = 0;
+    if (force) sscanf(force, "%d,%d", &fmt, &fnt);
+    for (const Variant& v : kVariants) {
+        if (blur_w && (!v.blur || blur_w % (16 * v.NT))) continue;      // a wave's pixels must lie in one image row
+        if (fmt && (v.MT != fmt || v.NT != fnt) && !(blur_w && fmt > 9)) continue;
+        const int slices = (tiles + v.MT - 1) / v.MT;
+        const double waves = (double)slices * (double)(pixels_total / (16 * v.NT));
+        // two waves share a SIMD's matrix pipe: below 1024 waves the chip is not full and a wave's length is the time
+        double cost = (waves > 1024.0 ? waves / 1024.0 : 1.0) * v.MT * v.NT * (v.NT == 2 ? 1.06 : 1.0);
+        if (best.MT == 0 || cost < best_cost - 1e-9) {
+            best.MT = v.MT; best.NT = v.NT; best.slices = slices;
+            best_cost = cost;
+        }
+    }
+    best.nkb = (K + 15) / 16;
+    best.pack_floats = (size_t)best.slices * best.nkb * best.MT * 256;
+    return best;
+}
+
+long conv16_add_job(Conv16PackJobs& jobs, const float* W, long rs, long cs, int M, int K, const Conv16Plan& plan) {
+    Conv16PackJobs::Job& J = jobs.j[jobs.n];
+    long off = 0;
+    for (int i = 0; i < jobs.n; ++i) off += jobs.j[i].floats;
+    J.W = W; J.rs = rs; J.cs = cs; J.M = M; J.K = K; J.MT = plan.MT; J.nkb = plan.nkb; J.slices = plan.slices;
+    J.dst_off = off; J.floats = (long)plan.pack_floats;
+    ++jobs.n;
+    return off;
+}
+
+void launch_conv16_pack(const Conv16PackJobs& jobs, hipStream_t st) {
+    long total = 0;
+    for (int i = 0; i < jobs.n; ++i) total += jobs.j[i].floats;
+    if (total == 0) return;
+    hipLaunchKernelGGL(conv16_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, jobs);
+}
+
+void launch_conv16(const Conv16Params& cp_in, hipStream_t st) {
+    Conv16Params cp = cp_in;
+    const long items = (long)cp.batch * cp.P / (64 * cp.plan.NT) * cp.plan.slices;
+    // half a wave period = one wave's MFMAs alone on the pipe: MT NT 4 nkb x 32 cycles; only when the launch is longer
+    // than the first round
+    cp.dephase = items * 4 > 2048 ? (2 * cp.plan.MT * cp.plan.NT * cp.plan.nkb + 126) / 127 : 0;
+    if (cp.dephase > 64) cp.dephase = 64;
+    const unsigned blocks = (unsigned)(8 * ((items + 7) / 8));
+    const int key = cp.plan.MT * 10 + cp.plan.NT;
+    switch (key) {
+        case 132: launch_variant<13, 2>(cp, blocks, st); break;
+        case 112: launch_variant<11, 2>(cp, blocks, st); break;
+        case 92: launch_variant_blur<9, 2>(cp, blocks, st); break;
+        case 84: launch_variant<8, 4>(cp, blocks, st); break;
+        case 44: launch_variant_blur<4, 4>(cp, blocks, st); break;
+        case 24: launch_variant_blur<2, 4>(cp, blocks, st); break;
+        default: fail("conv16: no instance for MT = %d, NT = %d", cp.plan.MT, cp.plan.NT);
+    }
+}
+
+}  // namespace gnr

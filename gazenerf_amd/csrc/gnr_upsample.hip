@@ -23,6 +23,7 @@
 #include <cstdint>
 
 #include "../../include/gnr.h"
+#include "gnr_conv16.h"
 #include "gnr_device.h"
 
 namespace gnr {
@@ -34,216 +35,6 @@ void launch_wgrad_img(const float* A, int lda, int n_valid, const float* B, int 
 
 constexpr float LEAK = 0.2f;
 constexpr int UP_MAX = GNR_UPSAMPLE_MAX_BLOCKS;
-
-// ---------------------------------------------------------------------------------------------
-// C[M][N] = epilogue(A[M][K] B[K][N])
-// ---------------------------------------------------------------------------------------------
-struct GemmParams {
-    const float* A; long a_rs, a_cs;               // A(m,k) = A[m*a_rs + k*a_cs]  (source of the packed copy)
-    const float* At; int Mp;                       // packed k-major copy: At[k*Mp + m], zero padded to Kp x Mp
-    const float* B; long b_batch;                  // B(b,k,n) = B[b*b_batch + k*N + n]
-    float* C; long c_batch;                        // C(b,m,n) = C[b*c_batch + m*N + n]   (plain store)
-    int M, K, N;                                   // N % 128 == 0
-    const float* bias;                             // [M] or NULL
-    int leaky;                                     // LeakyReLU(0.2) on (acc + bias)
-    const float* mask_ref; long mask_batch;        // result *= (mask_ref(b,m,n) > 0 ? 1 : 0.2)
-    int accumulate;                                // C += result
-    int shuffle, W;                                // PixelShuffleUpsample tail: n = y*W + x
-    const float* res; long res_batch;              // residual res(b, m % (M/4), n)
-    unsigned char* sign_out; long sign_batch;      // shuffle: bit e of byte (b, m/4, n) = (acc + bias > 0) of channel 4(m/4)+e
-};
-
-constexpr int GK = 16;             // k per LDS tile: two 4-step groups per lane-half
-constexpr int GN = 256;            // pixels per workgroup tile: 2 waves x 128
-
-// At[k/4][m][k%4] = A(m,k) for k < K, m < M, else 0; Kp % 16 == 0, Mp % 128 == 0.  The weights are tiny (<= 2 MB):
-// re-laying them out per call makes the A tile of a k-group ONE contiguous block for the LDS-DMA, and a lane's
-// ds_read_b128 the four k-steps of its row.
-__global__ void pack_a_kernel(const float* __restrict__ A, long a_rs, long a_cs, int M, int K, int Mp, int Kp,
-                              float* __restrict__ At) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)Mp * Kp) return;
-    const int k4 = (int)(i / (4L * Mp)), r = (int)(i - (long)k4 * 4 * Mp), m = r >> 2, k = 4 * k4 + (r & 3);
-    At[i] = (m < M && k < K) ? A[(long)m * a_rs + (long)k * a_cs] : 0.0f;
-}
-
-typedef int gi32x4 __attribute__((ext_vector_type(4)));
-
-// C[M][N] tile of (64 XM) x 256 per 256-thread workgroup: 2 (M) x 2 (N) waves, a wave = XM row tiles x 4 pixel
-// "tiles" of v_mfma_f32_32x32x2_f32.  Operand order: the contraction index k is free, so lane-half h takes the
-// 4-step groups 2q + h of a 16-k tile; the A value of 4 consecutive steps is one ds_read_b128 of the packed weights;
-// a lane's B operand of one step is a ds_read_b128 of FOUR CONSECUTIVE PIXELS of row k -- pixel 4 li + t feeds column
-// li of pixel-tile t, so one read feeds four MFMAs and a lane ends up owning 4 consecutive pixels of each of its
-// rows: float4 stores in the epilogue.  10-12 ds_read_b128 per 32 XM MFMAs (was: one ds_read_b32 per MFMA).
-// Both operand tiles arrive by LDS-DMA (the B rows are 1 KiB contiguous, the packed A groups 16 bytes x rows), rows
-// k >= K read zeros through the buffer descriptor's bound: no staging registers, no VALU, no ds_write.
-template <int XM>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams gp) {
-    constexpr int TM = 64 * XM;
-    constexpr int A_BYTES = (GK / 4) * TM * 16, B_BYTES = GK * GN * 4, BUF = A_BYTES + B_BYTES;
-    constexpr int PA = A_BYTES / 1024, PB = B_BYTES / 1024;            // 1 KiB DMA pieces per k-tile
-    __shared__ __attribute__((aligned(1024))) char lds[2 * BUF];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, lh = lane >> 5, wm = wave >> 1, wn = wave & 1;
-    const int n0 = blockIdx.x * GN, m0 = blockIdx.y * TM, b = blockIdx.z;
-    const int nk = (gp.K + GK - 1) / GK;
-
-    auto desc = [&](const float* base, long bytes) {
-        const unsigned long long a = (unsigned long long)base;
-        if (bytes > 0xFFFFFFFFL) bytes = 0xFFFFFFFFL;
-        gi32x4 r;
-        r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-        r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
-        r.z = __builtin_amdgcn_readfirstlane((int)(unsigned)bytes);
-        r.w = 0x00020000;
-        return r;
-    };
-    // A: packed [Kp/4][Mp][4], tile rows m0.. ; B: image b, [K][N] with the bound at row K
-    const gi32x4 rsa = desc(gp.At + (long)m0 * 4, ((long)nk * (GK / 4) * gp.Mp - m0) * 16);
-    const gi32x4 rsb = desc(gp.B + (long)b * gp.b_batch + n0, ((long)gp.K * gp.N - n0) * 4);
-    const unsigned lds0 = (unsigned)(size_t)&lds[0];
-    const unsigned voff = (unsigned)lane * 16u;
-    auto dma_tile = [&](int kt, int buf) {
-        const unsigned la = lds0 + (unsigned)buf * BUF, lb = la + A_BYTES;
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
-#pragma unroll
-        for (int j = wave; j < PA; j += 4) {      // piece j: k-group j / (TM/64), 64-row slice j % (TM/64)
-            const unsigned g = (unsigned)j / (TM / 64), sl = (unsigned)j % (TM / 64);
-            const unsigned so = ((unsigned)(kt * (GK / 4) + g) * (unsigned)gp.Mp + sl * 64u) * 16u;
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
-                         :: "v"(voff), "s"(rsa), "s"(la + (unsigned)j * 1024u), "s"(so) : "memory");
-        }
-#pragma unroll
-        for (int j = wave; j < PB; j += 4) {      // piece j: row kt*16 + j, 256 pixels
-            const unsigned so = (unsigned)(kt * GK + j) * (unsigned)gp.N * 4u;
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
-                         :: "v"(voff), "s"(rsb), "s"(lb + (unsigned)j * 1024u), "s"(so) : "memory");
-        }
-        asm volatile("s_mov_b32 m0, %0" :: "s"(keep));
-    };
-
-    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    f32x16 acc[XM][4];
-#pragma unroll
-    for (int x = 0; x < XM; ++x)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[x][t] = zero;
-    // byte offsets inside a buffer: A group g, row r -> (g*TM + r)*16;  B row k, pixel p -> A_BYTES + (k*256 + p)*4
-    const int a_off = (lh * TM + wm * 32 * XM + li) * 16;                  // + (2q*TM + 32x)*16
-    const int b_off = A_BYTES + (4 * lh * GN + wn * 128 + 4 * li) * 4;    // + ((8q + s)*GN)*4
-
-    dma_tile(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) dma_tile(kt + 1, buf ^ 1);
-        const char* base = lds + buf * BUF;
-        f32x4 av[XM][2], bv[2][4];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-#pragma unroll
-            for (int x = 0; x < XM; ++x) av[x][q] = *(const f32x4*)(base + a_off + (2 * q * TM + 32 * x) * 16);
-#pragma unroll
-            for (int sst = 0; sst < 4; ++sst) bv[q][sst] = *(const f32x4*)(base + b_off + (8 * q + sst) * GN * 4);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int sst = 0; sst < 4; ++sst)
-#pragma unroll
-                for (int x = 0; x < XM; ++x)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[x][t] = mfma32(av[x][q][sst], bv[q][sst][t], acc[x][t]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-
-    const int Cq = gp.M / 4;
-    const int n = n0 + 128 * wn + 4 * li;                                   // this lane's 4 consecutive pixels
-    if (gp.shuffle) {
-        // PixelShuffleUpsample tail.  A lane's registers 4q..4q+3 are in-channels 4c..4c+3 of its 4 pixels, i.e. the
-        // 2x2 output blocks of out-channel c at 4 consecutive x: two rows of 8 consecutive floats (float4 stores); the
-        // four pre-activation signs per pixel go into one nibble, four pixels into one 32-bit store.
-        const int py = n / gp.W, px = n - py * gp.W;
-#pragma unroll
-        for (int x = 0; x < XM; ++x)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int mb = m0 + 32 * XM * wm + 32 * x + 8 * q + 4 * lh;      // multiple of 4
-                if (mb >= gp.M) continue;
-                float v[4][4];                                                   // [e: channel][t: pixel]
-                unsigned nib = 0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int m = mb + e;
-                    const float bias = gp.bias[m];
-                    // x.repeat(1,4,1,1): in-channel m reads x channel m % (M/4)
-                    const f32x4 res = *(const f32x4*)(gp.res + (long)b * gp.res_batch + (long)(m % Cq) * gp.N + n);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        float u = acc[x][t][4 * q + e] + bias;
-                        nib |= (u > 0.0f ? 1u : 0u) << (8 * t + e);
-                        u = u > 0.0f ? u : LEAK * u;
-                        v[e][t] = u + res[t];
-                    }
-                }
-                *(unsigned*)(gp.sign_out + (long)b * gp.sign_batch + (long)(mb >> 2) * gp.N + n) = nib;
-                // pixel_shuffle(2): in-channel 4c + 2i + j -> out (c, 2y+i, 2x+j)
-                float* dst = gp.C + (long)b * gp.c_batch + (long)(mb >> 2) * (4L * gp.N) + (long)(2 * py) * (2 * gp.W) + 2 * px;
-                *(f32x4*)dst = f32x4{v[0][0], v[1][0], v[0][1], v[1][1]};
-                *(f32x4*)(dst + 4) = f32x4{v[0][2], v[1][2], v[0][3], v[1][3]};
-                *(f32x4*)(dst + 2 * gp.W) = f32x4{v[2][0], v[3][0], v[2][1], v[3][1]};
-                *(f32x4*)(dst + 2 * gp.W + 4) = f32x4{v[2][2], v[3][2], v[2][3], v[3][3]};
-            }
-        return;
-    }
-#pragma unroll
-    for (int x = 0; x < XM; ++x)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + 32 * XM * wm + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (m >= gp.M) continue;
-            f32x4 v = {acc[x][0][r], acc[x][1][r], acc[x][2][r], acc[x][3][r]};
-            if (gp.bias) v += gp.bias[m];
-            if (gp.leaky) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = v[t] > 0.0f ? v[t] : LEAK * v[t];
-            }
-            if (gp.mask_ref) {
-                const f32x4 mk = *(const f32x4*)(gp.mask_ref + (long)b * gp.mask_batch + (long)m * gp.N + n);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] *= mk[t] > 0.0f ? 1.0f : LEAK;
-            }
-            float* dst = gp.C + (long)b * gp.c_batch + (long)m * gp.N + n;
-            if (gp.accumulate) v += *(const f32x4*)dst;
-            *(f32x4*)dst = v;
-        }
-}
-
-static size_t pack_floats(int M, int K) {      // padded size of one packed operand, either orientation
-    auto one = [](int m, int k) { return (size_t)((m + 127) / 128 * 128) * ((k + GK - 1) / GK * GK); };
-    const size_t a = one(M, K), b = one(K, M);
-    return a > b ? a : b;
-}
-
-static void launch_gemm(GemmParams gp, int batch, float* pack, hipStream_t st) {
-    gp.Mp = (gp.M + 127) / 128 * 128;
-    const int Kp = (gp.K + GK - 1) / GK * GK;
-    hipLaunchKernelGGL(pack_a_kernel, dim3((unsigned)(((long)gp.Mp * Kp + 255) / 256)), dim3(256), 0, st, gp.A, gp.a_rs, gp.a_cs,
-                       gp.M, gp.K, gp.Mp, Kp, pack);
-    gp.At = pack;
-    // 64-row tiles where they waste fewer padded rows (M = 129, 258, 516: one channel past a multiple of 128); their
-    // MFMA-per-read ratio is lower, hence the 1.1
-    const long w128 = (long)((gp.M + 127) / 128) * 128, w64 = (long)((gp.M + 63) / 64) * 64;
-    if (w64 * 11 < w128 * 10)
-        hipLaunchKernelGGL((conv_gemm_kernel<1>), dim3(gp.N / GN, (gp.M + 63) / 64, batch), dim3(256), 0, st, gp);
-    else
-        hipLaunchKernelGGL((conv_gemm_kernel<2>), dim3(gp.N / GN, (gp.M + 127) / 128, batch), dim3(256), 0, st, gp);
-}
 
 // ---------------------------------------------------------------------------------------------
 // stencils: out(plane, y, x) over planes = B*C images of H x W
@@ -346,10 +137,12 @@ __global__ __launch_bounds__(256) void bilinear2x_adj_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------
 // the 3-channel RGB branch
 // ---------------------------------------------------------------------------------------------
-// rgb(b,o,p) = [rgb(b,o,p) +] sum_c W[o][c] net(b,c,p) + bias[o];  img = sigmoid(rgb) if wanted
+// rgb(b,o,p) = [rgb(b,o,p) +] sum_c W[o][c] net(b,c,p) + bias[o];  img = sigmoid(rgb) if wanted;  out = the caller's
+// image (img if given, else rgb) -- the last block writes it directly instead of a device-to-device copy afterwards
 __global__ __launch_bounds__(256) void rgb_conv_kernel(const float* __restrict__ net, int C, long P, int batch,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
-                                                       float* __restrict__ rgb, int accumulate, float* __restrict__ img) {
+                                                       float* __restrict__ rgb, int accumulate, float* __restrict__ img,
+                                                       float* __restrict__ out) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)batch * P) return;
     const long b = idx / P, p = idx - b * P;
@@ -380,7 +173,12 @@ __global__ __launch_bounds__(256) void rgb_conv_kernel(const float* __restrict__
     rp[0] = a0; rp[P] = a1; rp[2 * P] = a2;
     if (img) {
         float* ip = img + b * 3 * P + p;
-        ip[0] = 1.0f / (1.0f + expf(-a0)); ip[P] = 1.0f / (1.0f + expf(-a1)); ip[2 * P] = 1.0f / (1.0f + expf(-a2));
+        a0 = 1.0f / (1.0f + expf(-a0)); a1 = 1.0f / (1.0f + expf(-a1)); a2 = 1.0f / (1.0f + expf(-a2));
+        ip[0] = a0; ip[P] = a1; ip[2 * P] = a2;
+    }
+    if (out) {
+        float* op = out + b * 3 * P + p;
+        op[0] = a0; op[P] = a1; op[2 * P] = a2;
     }
 }
 
@@ -539,14 +337,67 @@ static int up_dims(const GnrUpsampleProblem* p, UpDims* d) {
     return 0;
 }
 
+// The three 1x1 convolutions of a block, forward or backward: tile variants + offsets of their packed weights
+struct BlockPlans {
+    Conv16Plan c1, c2, c3;
+    long o1, o2, o3;
+    bool blur_fused;                    // forward only: feat_layers reads blur(u) on the fly
+};
+
+// Forward GEMMs: a1 = W1 net (2C x C), u = shuffle(W2 a1) (4C x 2C), net' = Wf blur(u) (Cn x C over 4P pixels).
+// w == NULL: sizes only.  Returns the floats of the packed operands.
+static size_t plan_fwd(const UpDims& d, int B, const GnrUpsampleWeights* w, BlockPlans* bp, Conv16PackJobs* jobs) {
+    Conv16PackJobs J{};
+    for (int i = 0; i < d.n_blocks; ++i) {
+        const int C = d.ch[i], Cn = d.ch[i + 1], S = d.side[i];
+        const long px = (long)B * S * S;
+        BlockPlans q{};
+        q.c1 = conv16_plan(2 * C, C, px, 0);
+        q.o1 = conv16_add_job(J, w ? w->up1_w[i] : nullptr, C, 1, 2 * C, C, q.c1);
+        q.c2 = conv16_plan(4 * C, 2 * C, px, 0);
+        q.o2 = conv16_add_job(J, w ? w->up2_w[i] : nullptr, 2 * C, 1, 4 * C, 2 * C, q.c2);
+        q.c3 = conv16_plan(Cn, C, 4 * px, 2 * S);
+        q.blur_fused = q.c3.MT != 0;
+        if (!q.blur_fused) q.c3 = conv16_plan(Cn, C, 4 * px, 0);
+        q.o3 = conv16_add_job(J, w ? w->feat_w[i] : nullptr, C, 1, Cn, C, q.c3);
+        if (bp) bp[i] = q;
+    }
+    size_t total = 0;
+    for (int i = 0; i < J.n; ++i) total += (size_t)J.j[i].floats;
+    if (jobs) *jobs = J;
+    return total;
+}
+
+// Backward GEMMs (A = W^T through strides): du = Wf^T g (C x Cn over 4P), dpre1 = W2^T dpre2 (2C x 4C), dnet += W1^T dpre1
+// (C x 2C).
+static size_t plan_bwd(const UpDims& d, int B, const GnrUpsampleWeights* w, BlockPlans* bp, Conv16PackJobs* jobs) {
+    Conv16PackJobs J{};
+    for (int i = 0; i < d.n_blocks; ++i) {
+        const int C = d.ch[i], Cn = d.ch[i + 1], S = d.side[i];
+        const long px = (long)B * S * S;
+        BlockPlans q{};
+        q.c3 = conv16_plan(C, Cn, 4 * px, 0);
+        q.o3 = conv16_add_job(J, w ? w->feat_w[i] : nullptr, 1, C, C, Cn, q.c3);
+        q.c2 = conv16_plan(2 * C, 4 * C, px, 0);
+        q.o2 = conv16_add_job(J, w ? w->up2_w[i] : nullptr, 1, 2 * C, 2 * C, 4 * C, q.c2);
+        q.c1 = conv16_plan(C, 2 * C, px, 0);
+        q.o1 = conv16_add_job(J, w ? w->up1_w[i] : nullptr, 1, C, C, 2 * C, q.c1);
+        if (bp) bp[i] = q;
+    }
+    size_t total = 0;
+    for (int i = 0; i < J.n; ++i) total += (size_t)J.j[i].floats;
+    if (jobs) *jobs = J;
+    return total;
+}
+
 struct UpSaved {                        // kept for the backward
     float* a1[UP_MAX];                  // [B][2C][P]
     unsigned char* sign2[UP_MAX];       // [B][C][P]    four pre-activation sign bits per (out-channel quad, pixel)
-    float* pack;                        // packed A operand of the GEMM in flight
-    float* v[UP_MAX];                   // [B][C][4P]   blurred
+    float* pack;                        // packed A operands of every GEMM of the call in flight (forward, then backward)
+    float* u[UP_MAX];                   // [B][C][4P]   shuffled map (pre-blur); the backward re-uses it as d(net) once consumed
     float* net[UP_MAX];                 // [B][C'][4P]  block output
     float* img;                         // [B][3][Pn]
-    float* u;                           // [B][C][4P]   scratch (largest block)
+    float* vtmp;                        // [B][C][4P]   blurred map, only for blocks whose feat GEMM cannot blur on the fly
     float* rgb_a; float* rgb_b;         // [B][3][Pn]   scratch
 };
 
@@ -554,26 +405,22 @@ static size_t up_carve(const GnrUpsampleProblem* p, const UpDims& d, char* base,
     size_t off = 0;
     auto take = [&](size_t bytes) { char* q = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return q; };
     UpSaved z{};
-    size_t umax = 0;
     const size_t B = (size_t)p->batch;
+    BlockPlans bp[UP_MAX];
+    const size_t pk_f = plan_fwd(d, p->batch, nullptr, bp, nullptr), pk_b = plan_bwd(d, p->batch, nullptr, nullptr, nullptr);
+    size_t vmax = 0;
     for (int i = 0; i < d.n_blocks; ++i) {
         const size_t C = d.ch[i], Cn = d.ch[i + 1], P = (size_t)d.side[i] * d.side[i];
         z.a1[i] = (float*)take(B * 2 * C * P * 4);
         z.sign2[i] = (unsigned char*)take(B * C * P);
-        z.v[i] = (float*)take(B * C * 4 * P * 4);
+        z.u[i] = (float*)take(B * C * 4 * P * 4);
         z.net[i] = (float*)take(B * Cn * 4 * P * 4);
-        if (B * C * 4 * P * 4 > umax) umax = B * C * 4 * P * 4;
+        if (!bp[i].blur_fused && B * C * 4 * P * 4 > vmax) vmax = B * C * 4 * P * 4;
     }
     const size_t Pn = (size_t)d.side[d.n_blocks] * d.side[d.n_blocks];
     z.img = (float*)take(B * 3 * Pn * 4);
-    size_t pk = 0;
-    for (int i = 0; i < d.n_blocks; ++i) {
-        const int C = d.ch[i], Cn = d.ch[i + 1];
-        const size_t c3[3] = {pack_floats(2 * C, C), pack_floats(4 * C, 2 * C), pack_floats(Cn, C)};
-        for (size_t v : c3) if (v > pk) pk = v;
-    }
-    z.pack = (float*)take(pk * 4);
-    z.u = (float*)take(umax);
+    z.pack = (float*)take((pk_f > pk_b ? pk_f : pk_b) * 4);
+    z.vtmp = (float*)take(vmax);
     z.rgb_a = (float*)take(B * 3 * Pn * 4);
     z.rgb_b = (float*)take(B * 3 * Pn * 4);
     if (s) *s = z;
@@ -664,43 +511,51 @@ int gnr_upsample_fwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, f
     {
         const long P = (long)d.side[0] * d.side[0];
         hipLaunchKernelGGL(rgb_conv_kernel, dim3(blocks_for((long)B * P)), dim3(256), 0, st, p->x, d.ch[0], P, B, w->rgb_w[0],
-                           w->rgb_b[0], s.rgb_a, 0, (float*)nullptr);
+                           w->rgb_b[0], s.rgb_a, 0, (float*)nullptr, (float*)nullptr);
         up_rgb(s.rgb_a, s.rgb_b, s.rgb_a, B, d.side[0], st);          // in -> tmp -> out: in may be overwritten
     }
+    BlockPlans bp[UP_MAX];
+    Conv16PackJobs jobs;
+    plan_fwd(d, B, w, bp, &jobs);
+    jobs.dst = s.pack;
+    launch_conv16_pack(jobs, st);                 // every weight matrix of the call, one launch
     const float* net = p->x;
     float* rgb = s.rgb_a;
     float* rgb_tmp = s.rgb_b;
     for (int i = 0; i < d.n_blocks; ++i) {
         const int C = d.ch[i], Cn = d.ch[i + 1], S = d.side[i];
         const long P = (long)S * S;
-        GemmParams g{};
+        Conv16Params g{};
         // a1 = lrelu(W1 net + b1)
-        g.A = w->up1_w[i]; g.a_rs = C; g.a_cs = 1; g.B = net; g.b_batch = (long)C * P; g.C = s.a1[i]; g.c_batch = 2L * C * P;
-        g.M = 2 * C; g.K = C; g.N = (int)P; g.bias = w->up1_b[i]; g.leaky = 1;
-        launch_gemm(g, B, s.pack, st);
+        g.plan = bp[i].c1; g.At = s.pack + bp[i].o1; g.B = net; g.b_batch = (long)C * P; g.C = s.a1[i]; g.c_batch = 2L * C * P;
+        g.M = 2 * C; g.K = C; g.P = (int)P; g.batch = B; g.bias = w->up1_b[i]; g.leaky = 1;
+        launch_conv16(g, st);
         // u = pixel_shuffle(lrelu(W2 a1 + b2) + repeat(net))
-        g = GemmParams{};
-        g.A = w->up2_w[i]; g.a_rs = 2 * C; g.a_cs = 1; g.B = s.a1[i]; g.b_batch = 2L * C * P; g.C = s.u; g.c_batch = 4L * C * P;
-        g.M = 4 * C; g.K = 2 * C; g.N = (int)P; g.bias = w->up2_b[i]; g.leaky = 1; g.shuffle = 1; g.W = S;
+        g = Conv16Params{};
+        g.plan = bp[i].c2; g.At = s.pack + bp[i].o2; g.B = s.a1[i]; g.b_batch = 2L * C * P; g.C = s.u[i]; g.c_batch = 4L * C * P;
+        g.M = 4 * C; g.K = 2 * C; g.P = (int)P; g.batch = B; g.bias = w->up2_b[i]; g.leaky = 1; g.shuffle = 1; g.W = S;
         g.res = net; g.res_batch = (long)C * P; g.sign_out = s.sign2[i]; g.sign_batch = (long)C * P;
-        launch_gemm(g, B, s.pack, st);
-        // v = blur(u)
-        hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * C * P)), dim3(256), 0, st, s.u, s.v[i], (long)B * C, 2 * S,
-                           2 * S, 0);
-        // net' = lrelu(Wf v + bf)
-        g = GemmParams{};
-        g.A = w->feat_w[i]; g.a_rs = C; g.a_cs = 1; g.B = s.v[i]; g.b_batch = 4L * C * P; g.C = s.net[i]; g.c_batch = 4L * Cn * P;
-        g.M = Cn; g.K = C; g.N = (int)(4 * P); g.bias = w->feat_b[i]; g.leaky = 1;
-        launch_gemm(g, B, s.pack, st);
-        // rgb += conv_rgb(i+1)(net');  last block: img = sigmoid(rgb) (or rgb itself)
+        launch_conv16(g, st);
+        // net' = lrelu(Wf blur(u) + bf): the stencil inside the GEMM's operand load, or as its own kernel
+        g = Conv16Params{};
+        g.plan = bp[i].c3; g.At = s.pack + bp[i].o3; g.B = s.u[i]; g.b_batch = 4L * C * P; g.C = s.net[i]; g.c_batch = 4L * Cn * P;
+        g.M = Cn; g.K = C; g.P = (int)(4 * P); g.batch = B; g.bias = w->feat_b[i]; g.leaky = 1;
+        if (bp[i].blur_fused) {
+            g.blur = 1; g.W = 2 * S; g.H = 2 * S;
+        } else {
+            hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * C * P)), dim3(256), 0, st, s.u[i], s.vtmp, (long)B * C, 2 * S,
+                               2 * S, 0);
+            g.B = s.vtmp;
+        }
+        launch_conv16(g, st);
+        // rgb += conv_rgb(i+1)(net');  last block: img = sigmoid(rgb) (or rgb itself), also straight into the caller's image
         const bool last = i == d.n_blocks - 1;
         hipLaunchKernelGGL(rgb_conv_kernel, dim3(blocks_for((long)B * 4 * P)), dim3(256), 0, st, s.net[i], Cn, 4 * P, B,
-                           w->rgb_w[i + 1], w->rgb_b[i + 1], rgb, 1, last && p->final_sigmoid ? s.img : (float*)nullptr);
+                           w->rgb_w[i + 1], w->rgb_b[i + 1], rgb, 1, last && p->final_sigmoid ? s.img : (float*)nullptr,
+                           last ? img : (float*)nullptr);
         if (!last) up_rgb(rgb, rgb_tmp, rgb, B, 2 * S, st);
         net = s.net[i];
     }
-    const size_t out_bytes = (size_t)B * 3 * d.side[d.n_blocks] * d.side[d.n_blocks] * 4;
-    (void)hipMemcpyAsync(img, p->final_sigmoid ? s.img : rgb, out_bytes, hipMemcpyDeviceToDevice, st);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("gnr_upsample_fwd: launch failed: %s", hipGetErrorString(e));
     return 0;
@@ -735,6 +590,16 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
     else
         (void)hipMemcpyAsync(drgb, d_img, (size_t)B * 3 * Pn * 4, hipMemcpyDeviceToDevice, st);
 
+    BlockPlans bp[UP_MAX];
+    Conv16PackJobs jobs;
+    plan_bwd(d, B, w, bp, &jobs);
+    jobs.dst = s.pack;
+    launch_conv16_pack(jobs, st);                 // every transposed weight matrix of the call, one launch
+
+    // Blur and the 1x1 convolution act on different axes (pixels / channels) and commute: with g = blur^T(dhid)
+    //   dWf = g u^T,  dbf = sum g (= sum dhid: blur's rows sum to 1),  du = Wf^T g,
+    // so the adjoint stencil runs on the C/2 channels of dhid instead of the C channels of dv, and the forward never has to
+    // write blur(u).
     float* dnet_next = nullptr;       // gradient w.r.t. net' of block i coming from block i+1 (its input)
     for (int i = nb - 1; i >= 0; --i) {
         const int C = d.ch[i], Cn = d.ch[i + 1], S = d.side[i];
@@ -753,48 +618,39 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
             hipLaunchKernelGGL(rgb_conv_bwd_weight_kernel, dim3(Cn + 1, RGBW_SPLITS), dim3(256), 0, st, drgb, s.net[i], Cn, P4, B, t.colsum);
             hipLaunchKernelGGL(rgb_wsum_kernel, dim3((3 * (Cn + 1) + 63) / 64), dim3(64), 0, st, t.colsum, Cn, G.rgb_w[i + 1], G.rgb_b[i + 1]);
         }
-        float* dhid = dnet_next ? dnet_next : t.g0;
+        float* X = dnet_next ? dnet_next : t.g0;       // dhid, later du, later dpre1
+        float* Y = X == t.g0 ? t.g1 : t.g0;            // g, later dpre2
         hipLaunchKernelGGL(rgb_conv_bwd_data_kernel, dim3(blocks_for((long)B * P4)), dim3(256), 0, st, drgb, Cn, P4, B, w->rgb_w[i + 1],
-                           dhid, dnet_next ? 1 : 0, s.net[i]);
-        float* other = dhid == t.g0 ? t.g1 : t.g0;
-        // feat_layers[i]: dWf = dhid v^T, dbf; dv = Wf^T dhid
-        launch_wgrad_img(dhid, Cn, Cn, s.v[i], C, C, B, P4, G.feat_w[i], C, t.colsum, Cn + 128, t.wg, st);
+                           X, dnet_next ? 1 : 0, s.net[i]);
+        // g = blur^T dhid
+        hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * Cn * P)), dim3(256), 0, st, X, Y, (long)B * Cn, 2 * S, 2 * S, 1);
+        // feat_layers[i]: dWf = g u^T, dbf; du = Wf^T g
+        launch_wgrad_img(Y, Cn, Cn, s.u[i], C, C, B, P4, G.feat_w[i], C, t.colsum, Cn + 128, t.wg, st);
         if (G.feat_b[i]) hipLaunchKernelGGL(sum_batch_kernel, dim3((Cn + 63) / 64), dim3(64), 0, st, t.colsum, B, Cn, Cn + 128, G.feat_b[i]);
-        GemmParams g{};
-        g.A = w->feat_w[i]; g.a_rs = 1; g.a_cs = C; g.B = dhid; g.b_batch = (long)Cn * P4; g.C = other; g.c_batch = (long)C * P4;
-        g.M = C; g.K = Cn; g.N = (int)P4;
-        launch_gemm(g, B, s.pack, st);                                           // other = dv
-        // du = blur^T dv  (into dhid's buffer)
-        hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * C * P)), dim3(256), 0, st, other, dhid, (long)B * C, 2 * S, 2 * S, 1);
-        float* du = dhid;
-        // un-shuffle: dpre2 (-> other) and the residual part of d(net_in) (-> s.u, free in the backward)
-        float* dpre2 = other;
-        float* dnet = s.u;
-        hipLaunchKernelGGL(unshuffle_bwd_kernel, dim3(blocks_for((long)B * 2 * C * P)), dim3(256), 0, st, du, s.sign2[i], C, S, S, B, dpre2,
+        Conv16Params g{};
+        g.plan = bp[i].c3; g.At = s.pack + bp[i].o3; g.B = Y; g.b_batch = (long)Cn * P4; g.C = X; g.c_batch = (long)C * P4;
+        g.M = C; g.K = Cn; g.P = (int)P4; g.batch = B;
+        launch_conv16(g, st);                                                    // X = du
+        // un-shuffle: dpre2 (-> Y) and the residual part of d(net_in): into u[i]'s buffer, which nothing reads any more
+        // (block 0: straight into the caller's d_x)
+        float* dnet = (i == 0 && d_x) ? d_x : s.u[i];
+        hipLaunchKernelGGL(unshuffle_bwd_kernel, dim3(blocks_for((long)B * 2 * C * P)), dim3(256), 0, st, X, s.sign2[i], C, S, S, B, Y,
                            dnet);
-        // layer_2: dW2 = dpre2 a1^T, db2; dpre1 = (W2^T dpre2) * lrelu'(a1)  (-> du's buffer)
-        launch_wgrad_img(dpre2, 4 * C, 4 * C, s.a1[i], 2 * C, 2 * C, B, P, G.up2_w[i], 2 * C, t.colsum, 4 * C + 128, t.wg, st);
+        // layer_2: dW2 = dpre2 a1^T, db2; dpre1 = (W2^T dpre2) * lrelu'(a1)  (-> X)
+        launch_wgrad_img(Y, 4 * C, 4 * C, s.a1[i], 2 * C, 2 * C, B, P, G.up2_w[i], 2 * C, t.colsum, 4 * C + 128, t.wg, st);
         if (G.up2_b[i]) hipLaunchKernelGGL(sum_batch_kernel, dim3((4 * C + 63) / 64), dim3(64), 0, st, t.colsum, B, 4 * C, 4 * C + 128, G.up2_b[i]);
-        float* dpre1 = du;
-        g = GemmParams{};
-        g.A = w->up2_w[i]; g.a_rs = 1; g.a_cs = 2 * C; g.B = dpre2; g.b_batch = 4L * C * P; g.C = dpre1; g.c_batch = 2L * C * P;
-        g.M = 2 * C; g.K = 4 * C; g.N = (int)P; g.mask_ref = s.a1[i]; g.mask_batch = 2L * C * P;
-        launch_gemm(g, B, s.pack, st);
+        g = Conv16Params{};
+        g.plan = bp[i].c2; g.At = s.pack + bp[i].o2; g.B = Y; g.b_batch = 4L * C * P; g.C = X; g.c_batch = 2L * C * P;
+        g.M = 2 * C; g.K = 4 * C; g.P = (int)P; g.batch = B; g.mask_ref = s.a1[i]; g.mask_batch = 2L * C * P;
+        launch_conv16(g, st);
         // layer_1: dW1 = dpre1 net_in^T, db1; dnet += W1^T dpre1
-        launch_wgrad_img(dpre1, 2 * C, 2 * C, net_in, C, C, B, P, G.up1_w[i], C, t.colsum, 2 * C + 128, t.wg, st);
+        launch_wgrad_img(X, 2 * C, 2 * C, net_in, C, C, B, P, G.up1_w[i], C, t.colsum, 2 * C + 128, t.wg, st);
         if (G.up1_b[i]) hipLaunchKernelGGL(sum_batch_kernel, dim3((2 * C + 63) / 64), dim3(64), 0, st, t.colsum, B, 2 * C, 2 * C + 128, G.up1_b[i]);
-        g = GemmParams{};
-        g.A = w->up1_w[i]; g.a_rs = 1; g.a_cs = C; g.B = dpre1; g.b_batch = 2L * C * P; g.C = dnet; g.c_batch = (long)C * P;
-        g.M = C; g.K = 2 * C; g.N = (int)P; g.accumulate = 1;
-        launch_gemm(g, B, s.pack, st);
-        // hand d(net_in) to block i-1 in a buffer that survives: g0/g1 are free again -> copy into the one not used next
-        if (i > 0) {
-            (void)hipMemcpyAsync(t.g0, dnet, (size_t)B * C * P * 4, hipMemcpyDeviceToDevice, st);
-            dnet_next = t.g0;
-        } else {
-            // block 0: + conv_rgb0 path below, then out
-            dnet_next = dnet;
-        }
+        g = Conv16Params{};
+        g.plan = bp[i].c1; g.At = s.pack + bp[i].o1; g.B = X; g.b_batch = 2L * C * P; g.C = dnet; g.c_batch = (long)C * P;
+        g.M = C; g.K = 2 * C; g.P = (int)P; g.batch = B; g.accumulate = 1;
+        launch_conv16(g, st);
+        dnet_next = dnet;             // block i-1's dhid accumulates into it (its Cn x 4P' is this C x P)
     }
     // rgb_0 = up(conv_rgb0(x)): adjoint of up at side S0 -> 2 S0, then the conv
     {
@@ -806,9 +662,9 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
             hipLaunchKernelGGL(rgb_conv_bwd_weight_kernel, dim3(d.ch[0] + 1, RGBW_SPLITS), dim3(256), 0, st, drgb, p->x, d.ch[0], P, B, t.colsum);
             hipLaunchKernelGGL(rgb_wsum_kernel, dim3((3 * (d.ch[0] + 1) + 63) / 64), dim3(64), 0, st, t.colsum, d.ch[0], G.rgb_w[0], G.rgb_b[0]);
         }
-        hipLaunchKernelGGL(rgb_conv_bwd_data_kernel, dim3(blocks_for((long)B * P)), dim3(256), 0, st, drgb, d.ch[0], P, B, w->rgb_w[0],
-                           dnet_next, 1, (const float*)nullptr);
-        if (d_x) (void)hipMemcpyAsync(d_x, dnet_next, (size_t)B * d.ch[0] * P * 4, hipMemcpyDeviceToDevice, st);
+        if (d_x)
+            hipLaunchKernelGGL(rgb_conv_bwd_data_kernel, dim3(blocks_for((long)B * P)), dim3(256), 0, st, drgb, d.ch[0], P, B, w->rgb_w[0],
+                               dnet_next, 1, (const float*)nullptr);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("gnr_upsample_bwd: launch failed: %s", hipGetErrorString(e));

@@ -71,6 +71,7 @@ struct WgradParams {
     //   b*img + lc*chunk + n*row + j.  CCM dumps: row = 32, chunk = 32*ld, img = chunks_per_image*32*ld;
     //   channels-first images [B][C][P]: row = P, chunk = 32, img = C*P.
     long a_row, a_chunk, a_img, b_row, b_chunk, b_img;
+    int linear_map;               // wgrad2w_kernel: workgroup id -> contiguous ranges of (split, tile) per XCD instead of split % 8
     unsigned long long* clk;      // shader-clock probe (gnr_internal.h) or nullptr
 };
 
@@ -567,9 +568,20 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
     const int tiles = wp.tiles_n * wp.tiles_k;
     const int id = blockIdx.x;
     const int xcd = id & 7, slot = id >> 3;
-    const int split = xcd + 8 * (slot / tiles);
-    const int tile = slot % tiles;
-    if (split >= wp.batch * wp.spi) return;
+    int split, tile;
+    if (wp.linear_map) {
+        // image operands: any number of (split, tile) pairs, an XCD takes a contiguous range of them (the tiles of a split
+        // share its operand rows in that XCD's L2)
+        const int total = wp.batch * wp.spi * tiles, per_xcd = (total + 7) >> 3;
+        const int gi = xcd * per_xcd + slot;
+        if (slot >= per_xcd || gi >= total) return;
+        split = gi / tiles;
+        tile = gi - split * tiles;
+    } else {
+        split = xcd + 8 * (slot / tiles);
+        tile = slot % tiles;
+        if (split >= wp.batch * wp.spi) return;
+    }
     const int tn = tile / wp.tiles_k, tk = tile - tn * wp.tiles_k;
     const ClkProbe clk0 = clk_begin();
     const int tid = threadIdx.x, lane = tid & 63;
@@ -583,11 +595,27 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
     if (c1 > cmax) c1 = cmax;
     const int nchunks = (int)(c1 - c0);
 
-    const unsigned chunk_a = (unsigned)(wp.lda * CHUNK * 4), chunk_b = (unsigned)(wp.ldb * CHUNK * 4);
-    auto desc = [&](const float* base, long ld, long tile_row0, unsigned chunk_bytes) {
-        const unsigned long long a = (unsigned long long)(base + c0 * (CHUNK * ld) + tile_row0 * CHUNK);
-        long bytes = (long)nchunks * chunk_bytes - tile_row0 * CHUNK * 4;
+    // Operand addressing.  Chunk-channel-major dumps: chunk k of the split is one block of ld rows x 128 bytes, a DMA
+    // piece (8 rows) is 1 KiB of it.  Channels-first images [B][C][P] (the upsampler's weight gradients): row r of the
+    // tile is P floats long, chunk k = its pixels 32 k .. 32 k + 31; the LDS image is the same [row][32] -- only the
+    // lane's source offset (row stride P) and the two scalar strides change.  Rows >= n_valid read zeros through the
+    // descriptor's bound in both layouts.
+    const bool img = wp.a_row != CHUNK;
+    const unsigned kstride_a = img ? 128u : (unsigned)(wp.lda * CHUNK * 4), kstride_b = img ? 128u : (unsigned)(wp.ldb * CHUNK * 4);
+    const unsigned pstride_a = img ? (unsigned)(8 * wp.a_row * 4) : 1024u, pstride_b = img ? (unsigned)(8 * wp.b_row * 4) : 1024u;
+    auto desc = [&](const float* base, long ld, long tile_row0, unsigned chunk_bytes, int valid, long row, long img_stride) {
+        unsigned long long a;
+        long bytes;
+        if (img) {
+            const long start = ((long)sp * wp.chunks_per_split) * CHUNK;              // first pixel of the split
+            a = (unsigned long long)(base + (long)b * img_stride + tile_row0 * row + start);
+            bytes = ((long)valid - tile_row0) * row * 4 - start * 4;
+        } else {
+            a = (unsigned long long)(base + c0 * (CHUNK * ld) + tile_row0 * CHUNK);
+            bytes = (long)nchunks * chunk_bytes - tile_row0 * CHUNK * 4;
+        }
         if (bytes < 0) bytes = 0;
+        if (bytes > 0xFFFFFFFFL) bytes = 0xFFFFFFFFL;
         i32x4 r;
         r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
         r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
@@ -595,11 +623,13 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
         r.w = 0x00020000;
         return r;
     };
-    const i32x4 rsa = desc(wp.A, wp.lda, (long)tn * TN, chunk_a);
-    const i32x4 rsb = desc(wp.B, wp.ldb, (long)tk * TK, chunk_b);
+    const i32x4 rsa = desc(wp.A, wp.lda, (long)tn * TN, kstride_a, wp.n_valid, wp.a_row, wp.a_img);
+    const i32x4 rsb = desc(wp.B, wp.ldb, (long)tk * TK, kstride_b, wp.k_valid, wp.b_row, wp.b_img);
     // lane l fills slot l%8 of row 8i + l/8 with source piece (l%8) ^ ((4i + l/16) % 8)   (as wgrad_pipe_kernel)
-    const unsigned voff_even = (unsigned)(lane >> 3) * 128u + (unsigned)((lane & 7) ^ (lane >> 4)) * 16u;
-    const unsigned voff_odd = voff_even ^ 64u;
+    const unsigned vpiece = (unsigned)((lane & 7) ^ (lane >> 4)) * 16u;
+    const unsigned voff_even_a = (unsigned)(lane >> 3) * (img ? (unsigned)(wp.a_row * 4) : 128u) + vpiece;
+    const unsigned voff_even_b = (unsigned)(lane >> 3) * (img ? (unsigned)(wp.b_row * 4) : 128u) + vpiece;
+    const unsigned voff_odd_a = voff_even_a ^ 64u, voff_odd_b = voff_even_b ^ 64u;
     const unsigned lds0 = (unsigned)(size_t)&lds[0];
     constexpr int PA = TN / 8;                                    // A pieces per chunk (24), then TK / 8 B pieces
     // piece j (0 .. NPIECE-1) of this wave's share of chunk c0 + k, into ring buffer `buf`: global piece index 8 j + wave
@@ -609,17 +639,17 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
         const unsigned i = isa ? gp : gp - PA;
         const unsigned l = lds0 + (unsigned)buf * BUF_BYTES + (isa ? 0u : (unsigned)(TN * CHUNK * 4)) + i * 1024u;
 #ifdef GNR_WG_HOT      /* timing experiment (wrong results): every request re-reads one of the first 8 chunks -> operands L2-resident */
-        const unsigned so = (unsigned)(k & 7) * (isa ? chunk_a : chunk_b) + i * 1024u;
+        const unsigned so = (unsigned)(k & 7) * (isa ? kstride_a : kstride_b) + i * (isa ? pstride_a : pstride_b);
 #else
-        const unsigned so = (unsigned)k * (isa ? chunk_a : chunk_b) + i * 1024u;
+        const unsigned so = (unsigned)k * (isa ? kstride_a : kstride_b) + i * (isa ? pstride_a : pstride_b);
 #endif
         unsigned keep;
         if (isa)
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"((i & 1) ? voff_odd : voff_even), "s"(rsa), "s"(l), "s"(so) : "memory");
+                         : "=&s"(keep) : "v"((i & 1) ? voff_odd_a : voff_even_a), "s"(rsa), "s"(l), "s"(so) : "memory");
         else
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"((i & 1) ? voff_odd : voff_even), "s"(rsb), "s"(l), "s"(so) : "memory");
+                         : "=&s"(keep) : "v"((i & 1) ? voff_odd_b : voff_even_b), "s"(rsb), "s"(l), "s"(so) : "memory");
     };
     auto dma_chunk = [&](int k, int buf) {
 #pragma unroll
@@ -628,7 +658,10 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
 
     // rider shares: holders of the same dY rows = the (tk, wk) waves
     const int hc = tk * WKG + wk;                                 // 0 .. 4 tiles_k - 1
-    const int rot = CS2 ? 0 : (hc >> 2);                          // which piece is "slot 0"
+    const int rot = CS2 ? 0 : ((hc >> 2) & 1);                    // which piece is "slot 0"
+    // the 8 (slot, component) steps of a chunk go to the first 8 holders; with three column tiles (image operands only)
+    // holders 8 .. 11 contribute zeros
+    const float cscale = (CS2 || hc < 8) ? 1.0f : 0.0f;
     // operand read offsets (bytes within a ring buffer) of slot t: row wn*96 + 16 x + li (A) / wk*48 + 16 y + li (B),
     // piece 2 lg + ((t + rot) & 1).  The swizzle term depends on (row/2)%8 = (li/2)%8 only: tile x is a constant
     // + 2048 bytes.
@@ -713,7 +746,7 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
                     for (int y = 0; y < XB; ++y) acc[x][y] = mfma16w(opa[t][x][e], opb[t][y][e], acc[x][y]);
                 if (e == E && (t == 0 || CS2) && !(PABL & 1)) {
 #pragma unroll
-                    for (int x = 0; x < XA; ++x) csl[x] += opa[t][x][e];
+                    for (int x = 0; x < XA; ++x) csl[x] = fmaf(opa[t][x][e], cscale, csl[x]);
                 }
                 if (VEC) {
 #pragma unroll
@@ -1304,6 +1337,17 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
         fprintf(stderr, "gnr: bf16x3 weight gradient asked for an unsupported shape (%d x %d, ld %d / %d)\n", n_valid, k_valid, lda, ldb);
         abort();
     }
+    // channels-first images (the upsampler's 1x1 convolutions): the same pipelined kernel through its image addressing
+    // when the 192 x 192 tiles are reasonably full (measured against wgrad_kernel's per-shape tiles: DESIGN.md 3.5)
+    bool img2w = false;
+#ifndef GNR_WG_NOIMG2W
+    if (!bf16x3 && pixels_per_image > 0 && !with_vec && pixels_per_image % CHUNK == 0) {
+        const int tn = (n_valid + 191) / 192, tk = (k_valid + 191) / 192;
+        const double fill = (double)n_valid * k_valid / ((double)tn * tk * 192.0 * 192.0);
+        img2w = fill >= 0.45 && tk <= 3;
+    }
+    if (img2w) pipe_xk = 3;
+#endif
 #ifdef GNR_WG_NO2W
     const bool two_wave = false;
 #else
@@ -1322,6 +1366,12 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
     long splits_total = 8L * ((pipe_xk ? 32 : 64) / tiles);
     if (splits_total < 8) splits_total = 8;
     long spi = splits_total / batch;
+    if (img2w) {
+        // (split, tile) pairs are spread over the XCDs as one contiguous range each (linear_map): any count that fills
+        // the 256 one-workgroup CUs once
+        wp.linear_map = 1;
+        spi = 256 / ((long)batch * tiles);
+    }
     if (spi < 1) spi = 1;
     if (spi > chunks_per_image) spi = chunks_per_image;
     while ((long)batch * spi * tiles > WG_MAX_BLOCKS && spi > 1) --spi;
@@ -1335,7 +1385,7 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
     wp.vec = with_vec ? vec : nullptr;
     wp.vec_part = vec_part;
     const int splits = batch * (int)spi;
-    const unsigned blocks = (unsigned)(8 * ((splits + 7) / 8) * tiles);
+    const unsigned blocks = img2w ? (unsigned)(8 * (((long)splits * tiles + 7) / 8)) : (unsigned)(8 * ((splits + 7) / 8) * tiles);
     if (pipe_xk && bf16x3) {
         if (pipe_xk == 1) hipLaunchKernelGGL((wgrad3_tr_kernel<1, false>), dim3(blocks), dim3(512), 0, stream, wp);
         else if (wp.vec) hipLaunchKernelGGL((wgrad3_tr_kernel<3, true>), dim3(blocks), dim3(512), 0, stream, wp);
@@ -1343,7 +1393,7 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
     } else if (pipe_xk == 3 && two_wave) {
         // round 3: the same 192 x 192 tiles on eight waves (two per SIMD) of 16x16x4 MFMAs
         if (wp.vec) hipLaunchKernelGGL((wgrad2w_kernel<true, false>), dim3(blocks), dim3(512), 0, stream, wp);
-        else if (wp.tiles_k == 2) hipLaunchKernelGGL((wgrad2w_kernel<false, false>), dim3(blocks), dim3(512), 0, stream, wp);
+        else if (wp.tiles_k >= 2) hipLaunchKernelGGL((wgrad2w_kernel<false, false>), dim3(blocks), dim3(512), 0, stream, wp);
         else hipLaunchKernelGGL((wgrad2w_kernel<false, true>), dim3(blocks), dim3(512), 0, stream, wp);
     } else if (pipe_xk) {
         // CSG = rider slots per wave = 4 / (2 tiles_k)
