@@ -49,7 +49,6 @@ struct Conv16Params {
     const float* res; long res_batch;              // residual res(b, m % (M/4), n)
     unsigned char* sign_out; long sign_batch;      // shuffle: bit e of byte (b, m/4, n) = (acc + bias > 0) of channel 4(m/4)+e
     int blur, H;                                   // B operand = blur(B) with reflect padding, image H x W (W above)
-    int dephase;                                   // set by launch_conv16
 };
 void launch_conv16(const Conv16Params& cp, hipStream_t st);
 

@@ -45,9 +45,10 @@ int fail(const char* fmt, ...);
 namespace {
 
 #ifndef GNR_C16_ABL
-#define GNR_C16_ABL 0       // timing experiments (wrong results): 1 no epilogue, 2 B rows of k-block 0 only, 4 A of k-block 0 only, 8 no de-phasing,
-                            // 16 pseudo-random start offsets in the first 2560 blocks, 32 epilogue without its loads, 64 epilogue without its stores
+#define GNR_C16_ABL 0       // timing experiments (wrong results; tools/ab_n1.sh): 1 no epilogue, 2 B rows of k-block 0 only, 4 A of k-block 0
+                            // only, 32 epilogue without its loads, 64 epilogue without its stores
 #endif
+constexpr int WPB = 4;       // waves per workgroup: they share a row slice (the A stream hits in L1) and take adjacent pixels
 constexpr float LEAK16 = 0.2f;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -95,37 +96,19 @@ __global__ __launch_bounds__(256) void conv16_pack_kernel(const Conv16PackJobs j
 }
 
 template <int MT, int NT, bool SHUF, bool BLUR>
-__global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params cp) {
+__global__ __launch_bounds__(64 * WPB, 2) void conv16_kernel(const Conv16Params cp) {
     typedef typename Pix<NT>::T pv;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int li = lane & 15, g = lane >> 4;
     const int slices = cp.plan.slices;
-    const unsigned items = (unsigned)((long)cp.batch * cp.P / (64 * NT)) * (unsigned)slices;
+    const unsigned items = (unsigned)((long)cp.batch * cp.P / (16 * WPB * NT)) * (unsigned)slices;
     const unsigned per_xcd = (items + 7u) >> 3;
     const unsigned item = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if (item >= items) return;
-    // The waves of a launch are equally long and start together: left alone, both waves of every SIMD run their prologue
-    // (first loads) and epilogue (stores) at the same moments -- matrix pipe idle, HBM idle during the MFMAs -- and the
-    // launch proceeds in lock-step rounds.  The odd wave slots of the first round start half a wave period late (the
-    // length of one wave alone on the pipe, cp.dephase x 127 x 64 cycles); every later wave inherits the offset of the
-    // slot it takes over.
-    if ((GNR_C16_ABL & 16) && blockIdx.x < 2560u && cp.dephase > 0) {
-        const int nsl = (int)((blockIdx.x * 2654435761u) >> 29) * cp.dephase / 4;
-#pragma unroll 1
-        for (int i = 0; i < nsl; ++i) __builtin_amdgcn_s_sleep(127);
-    } else
-    if (blockIdx.x < 512u && cp.dephase > 0 && !(GNR_C16_ABL & 8)) {
-        unsigned hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        if (hw & 1u) {
-#pragma unroll 1
-            for (int i = 0; i < cp.dephase; ++i) __builtin_amdgcn_s_sleep(127);
-        }
-    }
     const unsigned pt = item / (unsigned)slices;
     const int ms = (int)(item - pt * (unsigned)slices);
-    const unsigned pixg = pt * (unsigned)(64 * NT) + (unsigned)wave * (unsigned)(16 * NT);     // batch * P < 2^31
+    const unsigned pixg = pt * (unsigned)(16 * WPB * NT) + (unsigned)wave * (unsigned)(16 * NT);     // batch * P < 2^31
     const int b = (int)(pixg / (unsigned)cp.P);
     const int p0 = (int)(pixg - (unsigned)b * (unsigned)cp.P);    // the wave's first pixel inside image b
     const int nkb = cp.plan.nkb;
@@ -340,16 +323,17 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Params cp) {
 
 struct Variant { int MT, NT; bool blur; };
 // (row tiles, pixel tiles) instances; blur: the instance that reads B through the stencil exists (register budget)
-const Variant kVariants[] = {{13, 2, false}, {11, 2, false}, {9, 2, true}, {8, 4, false}, {4, 4, true}, {2, 4, true}};
+// (ties in the cost model go to the earlier entry: the smaller tiles, which measured equal or better -- DESIGN.md 3.5)
+const Variant kVariants[] = {{2, 4, true}, {4, 4, true}, {8, 4, false}, {9, 2, true}, {11, 2, false}, {13, 2, false}};
 
 template <int MT, int NT>
 void launch_variant(const Conv16Params& cp, unsigned blocks, hipStream_t st) {
-    if (cp.shuffle) hipLaunchKernelGGL((conv16_kernel<MT, NT, true, false>), dim3(blocks), dim3(256), 0, st, cp);
-    else hipLaunchKernelGGL((conv16_kernel<MT, NT, false, false>), dim3(blocks), dim3(256), 0, st, cp);
+    if (cp.shuffle) hipLaunchKernelGGL((conv16_kernel<MT, NT, true, false>), dim3(blocks), dim3(64 * WPB), 0, st, cp);
+    else hipLaunchKernelGGL((conv16_kernel<MT, NT, false, false>), dim3(blocks), dim3(64 * WPB), 0, st, cp);
 }
 template <int MT, int NT>
 void launch_variant_blur(const Conv16Params& cp, unsigned blocks, hipStream_t st) {
-    if (cp.blur) hipLaunchKernelGGL((conv16_kernel<MT, NT, false, true>), dim3(blocks), dim3(256), 0, st, cp);
+    if (cp.blur) hipLaunchKernelGGL((conv16_kernel<MT, NT, false, true>), dim3(blocks), dim3(64 * WPB), 0, st, cp);
     else launch_variant<MT, NT>(cp, blocks, st);
 }
 
@@ -396,13 +380,8 @@ void launch_conv16_pack(const Conv16PackJobs& jobs, hipStream_t st) {
     hipLaunchKernelGGL(conv16_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, jobs);
 }
 
-void launch_conv16(const Conv16Params& cp_in, hipStream_t st) {
-    Conv16Params cp = cp_in;
-    const long items = (long)cp.batch * cp.P / (64 * cp.plan.NT) * cp.plan.slices;
-    // half a wave period = one wave's MFMAs alone on the pipe: MT NT 4 nkb x 32 cycles; only when the launch is longer
-    // than the first round
-    cp.dephase = items * 4 > 2048 ? (2 * cp.plan.MT * cp.plan.NT * cp.plan.nkb + 126) / 127 : 0;
-    if (cp.dephase > 64) cp.dephase = 64;
+void launch_conv16(const Conv16Params& cp, hipStream_t st) {
+    const long items = (long)cp.batch * cp.P / (16 * WPB * cp.plan.NT) * cp.plan.slices;
     const unsigned blocks = (unsigned)(8 * ((items + 7) / 8));
     const int key = cp.plan.MT * 10 + cp.plan.NT;
     switch (key) {

@@ -182,72 +182,119 @@ __global__ __launch_bounds__(256) void rgb_conv_kernel(const float* __restrict__
     }
 }
 
-// dnet(b,c,p) = ([dnet(b,c,p)] + sum_o W[o][c] drgb(b,o,p)) * (net(b,c,p) > 0 ? 1 : 0.2)   [mask optional]
-__global__ __launch_bounds__(256) void rgb_conv_bwd_data_kernel(const float* __restrict__ drgb, int C, long P, int batch,
-                                                                const float* __restrict__ w, float* __restrict__ dnet,
-                                                                int accumulate, const float* __restrict__ act) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)batch * P) return;
-    const long b = idx / P, p = idx - b * P;
-    const float* gp = drgb + b * 3 * P + p;
-    const float g0 = gp[0], g1 = gp[P], g2 = gp[2 * P];
-    // 8 channels per round: their dnet / act loads are issued before the first store (every channel is independent)
-    for (int c0 = 0; c0 < C; c0 += 8) {
-        float dv[8], av[8];
+// The RGB branch's backward in one pass over the activations (round 2: a weight-gradient kernel that re-read d(rgb) once
+// per channel, then a data-gradient kernel that read the activations again):
+//   dnet(b,c,p) = ([dnet(b,c,p)] + sum_o W[o][c] drgb(b,o,p)) * (net(b,c,p) > 0 ? 1 : 0.2)        [mask optional]
+//   dW[o][c]    = sum_{b,p} drgb(b,o,p) net(b,c,p);  db[o] = sum drgb(b,o,p)   (channel c == C stands for the bias)
+// A thread owns RGBF_IT pixel quads (their d(rgb) stays in registers) and walks the channels: per channel one b128 load of
+// the activation (+ one of dnet when accumulating), one b128 store, and three partial dots that are reduced over the wave
+// once per channel; a workgroup's four wave sums meet in LDS and leave as ONE partial per (channel, output):
+// part[(c * nwg + wg) * 3 + o]; rgb_wsum_kernel adds the workgroups' partials in a fixed order (deterministic).
+// Grid (pixel groups, channel groups): at the low resolutions (4096 pixels x 258 channels) the pixels alone are a handful
+// of workgroups, so the channel range is split too (blockIdx.y; the bias pseudo-channel rides with the last group).
+constexpr int RGBF_IT = 4;
+static long rgbf_workgroups(long pixels_total) { return (pixels_total / 4 + 256 * RGBF_IT - 1) / (256 * RGBF_IT); }
+static int rgbf_channel_groups(long nwg, int C) {          // ~1024 workgroups in all, at least 8 channels each
+    long g = (1024 + nwg - 1) / nwg;
+    if (g > C / 8) g = C / 8;
+    return g < 1 ? 1 : (int)g;
+}
+
+__global__ __launch_bounds__(256) void rgb_bwd_fused_kernel(const float* __restrict__ drgb, const float* __restrict__ net, int C,
+                                                            long P, int batch, const float* __restrict__ w,
+                                                            float* __restrict__ dnet, int accumulate, int masked,
+                                                            float* __restrict__ part) {
+    extern __shared__ float wsum[];                              // [4 waves][3][C + 1]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long quads = (long)batch * P / 4;
+    f32x4 g[RGBF_IT][3];
+    long base[RGBF_IT];
+    bool ok[RGBF_IT];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const long o = b * C * P + (long)(c0 + u) * P + p;
-            dv[u] = (accumulate && c0 + u < C) ? dnet[o] : 0.0f;
-            av[u] = (act && c0 + u < C) ? act[o] : 1.0f;
+    for (int it = 0; it < RGBF_IT; ++it) {
+        const long q = ((long)blockIdx.x * RGBF_IT + it) * 256 + tid;
+        ok[it] = q < quads;
+        const long p4 = ok[it] ? 4 * q : 0;
+        const long b = p4 / P, p = p4 - b * P;
+        base[it] = b * C * P + p;
+        const float* gp = drgb + b * 3 * P + p;
+#pragma unroll
+        for (int o = 0; o < 3; ++o) g[it][o] = ok[it] ? *(const f32x4*)(gp + o * P) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    auto wave_sum = [](float v) {
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) v += __shfl_xor(v, sft);
+        return v;
+    };
+    const int cper = (C + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int cbeg = (int)blockIdx.y * cper;
+    const int cend = cbeg + cper < C ? cbeg + cper : C;
+    const bool with_bias = blockIdx.y + 1 == gridDim.y;
+    const int cnt = cend > cbeg ? cend - cbeg : 0;
+    for (int j = 0; j < cnt + (with_bias ? 1 : 0); ++j) {
+        const int c = j < cnt ? cbeg + j : C;
+        float a[3] = {0.0f, 0.0f, 0.0f};
+        if (c < C) {
+            const float w0 = w[c], w1 = w[C + c], w2 = w[2 * C + c];
+            f32x4 nv[RGBF_IT], xv[RGBF_IT];
+#pragma unroll
+            for (int it = 0; it < RGBF_IT; ++it) {
+                nv[it] = ok[it] ? *(const f32x4*)(net + base[it] + (long)c * P) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                xv[it] = (accumulate && dnet && ok[it]) ? *(const f32x4*)(dnet + base[it] + (long)c * P) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+#pragma unroll
+            for (int it = 0; it < RGBF_IT; ++it) {
+                f32x4 v = w0 * g[it][0] + w1 * g[it][1] + w2 * g[it][2];
+                if (accumulate) v += xv[it];
+                if (masked) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= nv[it][e] > 0.0f ? 1.0f : LEAK;
+                }
+                if (dnet && ok[it]) *(f32x4*)(dnet + base[it] + (long)c * P) = v;
+#pragma unroll
+                for (int o = 0; o < 3; ++o)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[o] = fmaf(g[it][o][e], nv[it][e], a[o]);
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < RGBF_IT; ++it)
+#pragma unroll
+                for (int o = 0; o < 3; ++o) a[o] += (g[it][o].x + g[it][o].y) + (g[it][o].z + g[it][o].w);
         }
+        if (part) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int c = c0 + u;
-            if (c < C) {
-                float v = w[c] * g0 + w[C + c] * g1 + w[2 * C + c] * g2;
-                if (accumulate) v += dv[u];
-                if (act) v *= av[u] > 0.0f ? 1.0f : LEAK;
-                dnet[b * C * P + (long)c * P + p] = v;
+            for (int o = 0; o < 3; ++o) {
+                const float t = wave_sum(a[o]);
+                if (lane == 0) wsum[(wave * 3 + o) * (C + 1) + c] = t;
             }
         }
     }
-}
-
-// dW[o][c] = sum_{b,p} drgb(b,o,p) net(b,c,p);  db[o] = sum drgb(b,o,p)  (channel c == C stands for the bias).
-// Grid (C+1, RGBW_SPLITS): each block reduces a contiguous slice of the (b,p) range; rgb_wsum_kernel adds the
-// slices in a fixed order (deterministic).
-constexpr int RGBW_SPLITS = 32;
-
-__global__ __launch_bounds__(256) void rgb_conv_bwd_weight_kernel(const float* __restrict__ drgb, const float* __restrict__ net,
-                                                                  int C, long P, int batch, float* __restrict__ part) {
-    __shared__ float red[3][256];
-    const int c = blockIdx.x, sp = blockIdx.y, tid = threadIdx.x;
-    const long total = (long)batch * P, per = (total + RGBW_SPLITS - 1) / RGBW_SPLITS;
-    const long i0 = (long)sp * per, i1 = i0 + per < total ? i0 + per : total;
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-    for (long i = i0 + tid; i < i1; i += 256) {
-        const long b = i / P, p = i - b * P;
-        const float v = c < C ? net[b * C * P + (long)c * P + p] : 1.0f;
-        const float* gp = drgb + b * 3 * P + p;
-        a0 = fmaf(gp[0], v, a0); a1 = fmaf(gp[P], v, a1); a2 = fmaf(gp[2 * P], v, a2);
-    }
-    red[0][tid] = a0; red[1][tid] = a1; red[2][tid] = a2;
+    if (!part) return;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) { red[0][tid] += red[0][tid + s]; red[1][tid] += red[1][tid + s]; red[2][tid] += red[2][tid + s]; }
-        __syncthreads();
+    for (int i = tid; i < 3 * (C + 1); i += 256) {
+        const int o = i / (C + 1), c = i - o * (C + 1);
+        if (!((c >= cbeg && c < cend) || (with_bias && c == C))) continue;
+        const float t = (wsum[(0 * 3 + o) * (C + 1) + c] + wsum[(1 * 3 + o) * (C + 1) + c]) +
+                        (wsum[(2 * 3 + o) * (C + 1) + c] + wsum[(3 * 3 + o) * (C + 1) + c]);
+        part[((long)c * gridDim.x + blockIdx.x) * 3 + o] = t;
     }
-    if (tid < 3) part[((long)c * RGBW_SPLITS + sp) * 3 + tid] = red[tid][0];
 }
 
-__global__ void rgb_wsum_kernel(const float* __restrict__ part, int C, float* __restrict__ dw, float* __restrict__ db) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (c, o)
-    if (i >= (C + 1) * 3) return;
+// one wave per (channel, output): lane l adds the partials l, l + 64, ... in order, then the 64 lane sums are added in a
+// fixed tree
+__global__ __launch_bounds__(64) void rgb_wsum_kernel(const float* __restrict__ part, int C, int nwg, float* __restrict__ dw,
+                                                      float* __restrict__ db) {
+    const int i = blockIdx.x, lane = threadIdx.x;                 // (c, o)
     const int c = i / 3, o = i - 3 * c;
     float a = 0.0f;
-    for (int sp = 0; sp < RGBW_SPLITS; ++sp) a += part[((long)c * RGBW_SPLITS + sp) * 3 + o];
-    if (c < C) { if (dw) dw[o * C + c] = a; }
-    else if (db) db[o] = a;
+    for (int sp = lane; sp < nwg; sp += 64) a += part[((long)c * nwg + sp) * 3 + o];
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) a += __shfl_xor(a, sft);
+    if (lane == 0) {
+        if (c < C) { if (dw) dw[o * C + c] = a; }
+        else if (db) db[o] = a;
+    }
 }
 
 // d(rgb) = d(img) * img * (1 - img)
@@ -452,7 +499,11 @@ static size_t up_carve_bwd(const GnrUpsampleProblem* p, const UpDims& d, char* b
     z.drgb_a = (float*)take(B * 3 * Pn * 4);
     z.drgb_b = (float*)take(B * 3 * Pn * 4);
     size_t cs_floats = B * (size_t)(mmax + 128);
-    if (cs_floats < (size_t)(mmax + 1) * RGBW_SPLITS * 3) cs_floats = (size_t)(mmax + 1) * RGBW_SPLITS * 3;
+    for (int i = 0; i <= d.n_blocks; ++i) {           // rgb_bwd_fused_kernel's partials: (channels + 1) x workgroups x 3
+        const size_t px = B * (size_t)d.side[i] * d.side[i];
+        const size_t need = (size_t)(d.ch[i] + 1) * (size_t)rgbf_workgroups((long)px) * 3;
+        if (cs_floats < need) cs_floats = need;
+    }
     z.colsum = (float*)take(cs_floats * 4);
     z.wg = (float*)take(wgrad_scratch_floats() * 4);
     if (s) *s = z;
@@ -613,15 +664,17 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
             hipLaunchKernelGGL(bilinear2x_adj_kernel, dim3(blocks_for((long)B * 3 * P4)), dim3(256), 0, st, drgb_tmp, drgb, (long)B * 3,
                                2 * S, 2 * S);
         }
-        // conv_rgb(i+1): weight/bias gradients, then dhid = (dnet' + Wr^T drgb) * lrelu'(net')
-        if (G.rgb_w[i + 1] || G.rgb_b[i + 1]) {
-            hipLaunchKernelGGL(rgb_conv_bwd_weight_kernel, dim3(Cn + 1, RGBW_SPLITS), dim3(256), 0, st, drgb, s.net[i], Cn, P4, B, t.colsum);
-            hipLaunchKernelGGL(rgb_wsum_kernel, dim3((3 * (Cn + 1) + 63) / 64), dim3(64), 0, st, t.colsum, Cn, G.rgb_w[i + 1], G.rgb_b[i + 1]);
-        }
+        // conv_rgb(i+1): weight / bias gradients and dhid = (dnet' + Wr^T drgb) * lrelu'(net'), one pass over net'
         float* X = dnet_next ? dnet_next : t.g0;       // dhid, later du, later dpre1
         float* Y = X == t.g0 ? t.g1 : t.g0;            // g, later dpre2
-        hipLaunchKernelGGL(rgb_conv_bwd_data_kernel, dim3(blocks_for((long)B * P4)), dim3(256), 0, st, drgb, Cn, P4, B, w->rgb_w[i + 1],
-                           X, dnet_next ? 1 : 0, s.net[i]);
+        {
+            const bool want_w = G.rgb_w[i + 1] || G.rgb_b[i + 1];
+            const unsigned nwg = (unsigned)rgbf_workgroups((long)B * P4);
+            hipLaunchKernelGGL(rgb_bwd_fused_kernel, dim3(nwg, rgbf_channel_groups(nwg, Cn)), dim3(256), (size_t)12 * (Cn + 1) * sizeof(float), st, drgb, s.net[i], Cn,
+                               P4, B, w->rgb_w[i + 1], X, dnet_next ? 1 : 0, 1, want_w ? t.colsum : (float*)nullptr);
+            if (want_w)
+                hipLaunchKernelGGL(rgb_wsum_kernel, dim3(3 * (Cn + 1)), dim3(64), 0, st, t.colsum, Cn, (int)nwg, G.rgb_w[i + 1], G.rgb_b[i + 1]);
+        }
         // g = blur^T dhid
         hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * Cn * P)), dim3(256), 0, st, X, Y, (long)B * Cn, 2 * S, 2 * S, 1);
         // feat_layers[i]: dWf = g u^T, dbf; du = Wf^T g
@@ -658,13 +711,14 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
         const long P = (long)S * S;
         hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * 3 * P)), dim3(256), 0, st, drgb, drgb_tmp, (long)B * 3, 2 * S, 2 * S, 1);
         hipLaunchKernelGGL(bilinear2x_adj_kernel, dim3(blocks_for((long)B * 3 * P)), dim3(256), 0, st, drgb_tmp, drgb, (long)B * 3, S, S);
-        if (G.rgb_w[0] || G.rgb_b[0]) {
-            hipLaunchKernelGGL(rgb_conv_bwd_weight_kernel, dim3(d.ch[0] + 1, RGBW_SPLITS), dim3(256), 0, st, drgb, p->x, d.ch[0], P, B, t.colsum);
-            hipLaunchKernelGGL(rgb_wsum_kernel, dim3((3 * (d.ch[0] + 1) + 63) / 64), dim3(64), 0, st, t.colsum, d.ch[0], G.rgb_w[0], G.rgb_b[0]);
+        const bool want_w = G.rgb_w[0] || G.rgb_b[0];
+        if (want_w || d_x) {
+            const unsigned nwg = (unsigned)rgbf_workgroups((long)B * P);
+            hipLaunchKernelGGL(rgb_bwd_fused_kernel, dim3(nwg, rgbf_channel_groups(nwg, d.ch[0])), dim3(256), (size_t)12 * (d.ch[0] + 1) * sizeof(float), st, drgb, p->x,
+                               d.ch[0], P, B, w->rgb_w[0], d_x ? dnet_next : (float*)nullptr, 1, 0, want_w ? t.colsum : (float*)nullptr);
+            if (want_w)
+                hipLaunchKernelGGL(rgb_wsum_kernel, dim3(3 * (d.ch[0] + 1)), dim3(64), 0, st, t.colsum, d.ch[0], (int)nwg, G.rgb_w[0], G.rgb_b[0]);
         }
-        if (d_x)
-            hipLaunchKernelGGL(rgb_conv_bwd_data_kernel, dim3(blocks_for((long)B * P)), dim3(256), 0, st, drgb, d.ch[0], P, B, w->rgb_w[0],
-                               dnet_next, 1, (const float*)nullptr);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("gnr_upsample_bwd: launch failed: %s", hipGetErrorString(e));
