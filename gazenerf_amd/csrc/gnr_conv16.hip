@@ -353,6 +353,9 @@ Conv16Plan conv16_plan(int M, int K, long pixels_total, int blur_w) {
         const double waves = (double)slices * (double)(pixels_total / (16 * v.NT));
         // two waves share a SIMD's matrix pipe: below 1024 waves the chip is not full and a wave's length is the time
         double cost = (waves > 1024.0 ? waves / 1024.0 : 1.0) * v.MT * v.NT * (v.NT == 2 ? 1.06 : 1.0);
+        // every row slice repeats the stencil's loads (three rows + edges) and its ~30 VALU per operand register: the
+        // fewest slices win (measured, 7 images: M = 64 as 1 x (4,4) 185 us, as 2 x (2,4) 249 us; M = 129 as (9,2) 160 us)
+        if (blur_w) cost *= 1.0 + 0.5 * (slices - 1);
         if (best.MT == 0 || cost < best_cost - 1e-9) {
             best.MT = v.MT; best.NT = v.NT; best.slices = slices;
             best_cost = cost;

@@ -344,6 +344,46 @@ __global__ __launch_bounds__(256) void unshuffle_bwd_kernel(const float* __restr
     }
 }
 
+// The same for C % 4 == 0 (the 64-channel block at 256 x 256, the largest of the three): in-channel c' + q C is element
+// c' % 4 of the 2x2 block of out-channel c'/4 + q C/4, so ONE thread that walks the four out-channels cb + q C/4 of four
+// consecutive pixels has every term of dres(4 cb + e) in registers -- du is read once instead of twice, all accesses are
+// 16-byte vectors.  Same summation order as above.
+__global__ __launch_bounds__(256) void unshuffle_bwd4_kernel(const float* __restrict__ du, const unsigned char* __restrict__ sign,
+                                                             int C, int H, int W, int batch, float* __restrict__ dpre2,
+                                                             float* __restrict__ dres) {
+    const long P = (long)H * W, nq = P / 4;
+    const int Cq = C / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)batch * Cq * nq) return;
+    const long b = idx / ((long)Cq * nq), rem = idx - b * (long)Cq * nq;
+    const int cb = (int)(rem / nq);
+    const long p = 4 * (rem - (long)cb * nq);
+    const int y = (int)(p / W), x = (int)(p - (long)y * W);
+    f32x4 G[4][4];                                   // [q][e] over the 4 pixels
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = cb + q * Cq;
+        const float* src = du + (b * C + c) * 4 * P + (long)(2 * y) * (2 * W) + 2 * x;
+        const f32x4 t0 = *(const f32x4*)src, t1 = *(const f32x4*)(src + 4);
+        const f32x4 b0 = *(const f32x4*)(src + 2 * W), b1 = *(const f32x4*)(src + 2 * W + 4);
+        G[q][0] = f32x4{t0.x, t0.z, t1.x, t1.z};
+        G[q][1] = f32x4{t0.y, t0.w, t1.y, t1.w};
+        G[q][2] = f32x4{b0.x, b0.z, b1.x, b1.z};
+        G[q][3] = f32x4{b0.y, b0.w, b1.y, b1.w};
+        const unsigned nib4 = *(const unsigned*)(sign + (b * C + c) * P + p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f32x4 v;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = G[q][e][t] * (((nib4 >> (8 * t + e)) & 1u) ? 1.0f : LEAK);
+            *(f32x4*)(dpre2 + (b * 4 * C + 4 * c + e) * P + p) = v;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        *(f32x4*)(dres + (b * C + 4 * cb + e) * P + p) = (G[0][e] + G[1][e]) + (G[2][e] + G[3][e]);
+}
+
 // out[n] = sum_b in[b][n]
 __global__ void sum_batch_kernel(const float* __restrict__ in, int batch, int n, int ld, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -687,8 +727,12 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
         // un-shuffle: dpre2 (-> Y) and the residual part of d(net_in): into u[i]'s buffer, which nothing reads any more
         // (block 0: straight into the caller's d_x)
         float* dnet = (i == 0 && d_x) ? d_x : s.u[i];
-        hipLaunchKernelGGL(unshuffle_bwd_kernel, dim3(blocks_for((long)B * 2 * C * P)), dim3(256), 0, st, X, s.sign2[i], C, S, S, B, Y,
-                           dnet);
+        if (C % 4 == 0)
+            hipLaunchKernelGGL(unshuffle_bwd4_kernel, dim3(blocks_for((long)B * (C / 4) * (P / 4))), dim3(256), 0, st, X, s.sign2[i], C, S, S,
+                               B, Y, dnet);
+        else
+            hipLaunchKernelGGL(unshuffle_bwd_kernel, dim3(blocks_for((long)B * 2 * C * P)), dim3(256), 0, st, X, s.sign2[i], C, S, S, B, Y,
+                               dnet);
         // layer_2: dW2 = dpre2 a1^T, db2; dpre1 = (W2^T dpre2) * lrelu'(a1)  (-> X)
         launch_wgrad_img(Y, 4 * C, 4 * C, s.a1[i], 2 * C, 2 * C, B, P, G.up2_w[i], 2 * C, t.colsum, 4 * C + 128, t.wg, st);
         if (G.up2_b[i]) hipLaunchKernelGGL(sum_batch_kernel, dim3((4 * C + 63) / 64), dim3(64), 0, st, t.colsum, B, 4 * C, 4 * C + 128, G.up2_b[i]);

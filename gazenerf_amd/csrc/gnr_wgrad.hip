@@ -1286,13 +1286,17 @@ size_t wgrad_scratch_floats() {
 
 // fp32 tile configurations: {rows, cols, relative cost per MFMA slot (LDS reads per MFMA, 3-wave workgroups)}
 struct TileCfg { int tn, tk; float cost; };
-static const TileCfg kTileCfgs[4] = {{128, 128, 1.00f}, {192, 64, 1.04f}, {64, 192, 1.04f}, {96, 96, 1.08f}};
+// (the last three: the upsampler's narrow high-resolution layers -- 32 x 64 and 128 x 64 channels over 1.8 M / 0.46 M pixels --
+// are HBM-bound; a tile no larger than the product stages no duplicate rows)
+constexpr int N_TILE_CFGS = 7;
+static const TileCfg kTileCfgs[N_TILE_CFGS] = {{128, 128, 1.00f}, {192, 64, 1.04f}, {64, 192, 1.04f}, {96, 96, 1.08f},
+                                               {128, 64, 1.10f}, {64, 64, 1.15f}, {32, 64, 1.20f}};
 
 static int choose_tile(int n_valid, int k_valid, bool vec) {
     if (vec) return 0;                                  // the rider variant exists for the 128 x 128 tile only
     int best = 0;
     float best_cost = 0.0f;
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < N_TILE_CFGS; ++i) {
         const TileCfg& c = kTileCfgs[i];
         const float cost = (float)((n_valid + c.tn - 1) / c.tn) * (float)((k_valid + c.tk - 1) / c.tk) * c.tn * c.tk * c.cost;
         if (i == 0 || cost < best_cost) { best = i; best_cost = cost; }
@@ -1363,7 +1367,8 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
     // workgroups and fill whole rounds, otherwise the launch waits for one XCD's straggler round (113 splits instead
     // of 112 cost 40 %): splits = 8 * floor(slots / tiles), made divisible by the batch: ONE round of workgroups.
     // (Two rounds ran the GEMM no faster and doubled the partial tiles the reduce kernel has to sum.)
-    long splits_total = 8L * ((pipe_xk ? 32 : 64) / tiles);
+    // (the 128-thread 32 x 64 tile: four workgroups per CU)
+    long splits_total = 8L * ((pipe_xk ? 32 : (cfg == 6 ? 128 : 64)) / tiles);
     if (splits_total < 8) splits_total = 8;
     long spi = splits_total / batch;
     if (img2w) {
@@ -1408,7 +1413,10 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
             case 0: hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2, false>), dim3(blocks), dim3(256), 0, stream, wp); break;
             case 1: hipLaunchKernelGGL((wgrad_kernel<2, 2, 3, 1, false>), dim3(blocks), dim3(256), 0, stream, wp); break;
             case 2: hipLaunchKernelGGL((wgrad_kernel<2, 2, 1, 3, false>), dim3(blocks), dim3(256), 0, stream, wp); break;
-            default: hipLaunchKernelGGL((wgrad_kernel<3, 1, 1, 3, false>), dim3(blocks), dim3(192), 0, stream, wp); break;
+            case 3: hipLaunchKernelGGL((wgrad_kernel<3, 1, 1, 3, false>), dim3(blocks), dim3(192), 0, stream, wp); break;
+            case 4: hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 1, false>), dim3(blocks), dim3(256), 0, stream, wp); break;
+            case 5: hipLaunchKernelGGL((wgrad_kernel<2, 2, 1, 1, false>), dim3(blocks), dim3(256), 0, stream, wp); break;
+            default: hipLaunchKernelGGL((wgrad_kernel<1, 2, 1, 1, false>), dim3(blocks), dim3(128), 0, stream, wp); break;
         }
     }
     WgradReduceParams rp{};
