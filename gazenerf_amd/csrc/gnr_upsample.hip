@@ -384,15 +384,6 @@ __global__ __launch_bounds__(256) void unshuffle_bwd4_kernel(const float* __rest
         *(f32x4*)(dres + (b * C + 4 * cb + e) * P + p) = (G[0][e] + G[1][e]) + (G[2][e] + G[3][e]);
 }
 
-// out[n] = sum_b in[b][n]
-__global__ void sum_batch_kernel(const float* __restrict__ in, int batch, int n, int ld, float* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float a = 0.0f;
-    for (int b = 0; b < batch; ++b) a += in[(long)b * ld + i];
-    out[i] = a;
-}
-
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -718,8 +709,7 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
         // g = blur^T dhid
         hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * Cn * P)), dim3(256), 0, st, X, Y, (long)B * Cn, 2 * S, 2 * S, 1);
         // feat_layers[i]: dWf = g u^T, dbf; du = Wf^T g
-        launch_wgrad_img(Y, Cn, Cn, s.u[i], C, C, B, P4, G.feat_w[i], C, t.colsum, Cn + 128, t.wg, st);
-        if (G.feat_b[i]) hipLaunchKernelGGL(sum_batch_kernel, dim3((Cn + 63) / 64), dim3(64), 0, st, t.colsum, B, Cn, Cn + 128, G.feat_b[i]);
+        launch_wgrad_img(Y, Cn, Cn, s.u[i], C, C, B, P4, G.feat_w[i], C, G.feat_b[i], 0, t.wg, st);
         Conv16Params g{};
         g.plan = bp[i].c3; g.At = s.pack + bp[i].o3; g.B = Y; g.b_batch = (long)Cn * P4; g.C = X; g.c_batch = (long)C * P4;
         g.M = C; g.K = Cn; g.P = (int)P4; g.batch = B;
@@ -734,15 +724,13 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
             hipLaunchKernelGGL(unshuffle_bwd_kernel, dim3(blocks_for((long)B * 2 * C * P)), dim3(256), 0, st, X, s.sign2[i], C, S, S, B, Y,
                                dnet);
         // layer_2: dW2 = dpre2 a1^T, db2; dpre1 = (W2^T dpre2) * lrelu'(a1)  (-> X)
-        launch_wgrad_img(Y, 4 * C, 4 * C, s.a1[i], 2 * C, 2 * C, B, P, G.up2_w[i], 2 * C, t.colsum, 4 * C + 128, t.wg, st);
-        if (G.up2_b[i]) hipLaunchKernelGGL(sum_batch_kernel, dim3((4 * C + 63) / 64), dim3(64), 0, st, t.colsum, B, 4 * C, 4 * C + 128, G.up2_b[i]);
+        launch_wgrad_img(Y, 4 * C, 4 * C, s.a1[i], 2 * C, 2 * C, B, P, G.up2_w[i], 2 * C, G.up2_b[i], 0, t.wg, st);
         g = Conv16Params{};
         g.plan = bp[i].c2; g.At = s.pack + bp[i].o2; g.B = Y; g.b_batch = 4L * C * P; g.C = X; g.c_batch = 2L * C * P;
         g.M = 2 * C; g.K = 4 * C; g.P = (int)P; g.batch = B; g.mask_ref = s.a1[i]; g.mask_batch = 2L * C * P;
         launch_conv16(g, st);
         // layer_1: dW1 = dpre1 net_in^T, db1; dnet += W1^T dpre1
-        launch_wgrad_img(X, 2 * C, 2 * C, net_in, C, C, B, P, G.up1_w[i], C, t.colsum, 2 * C + 128, t.wg, st);
-        if (G.up1_b[i]) hipLaunchKernelGGL(sum_batch_kernel, dim3((2 * C + 63) / 64), dim3(64), 0, st, t.colsum, B, 2 * C, 2 * C + 128, G.up1_b[i]);
+        launch_wgrad_img(X, 2 * C, 2 * C, net_in, C, C, B, P, G.up1_w[i], C, G.up1_b[i], 0, t.wg, st);
         g = Conv16Params{};
         g.plan = bp[i].c1; g.At = s.pack + bp[i].o1; g.B = X; g.b_batch = 2L * C * P; g.C = dnet; g.c_batch = (long)C * P;
         g.M = C; g.K = 2 * C; g.P = (int)P; g.batch = B; g.accumulate = 1;

@@ -1264,7 +1264,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReducePara
         for (; sp < count; ++sp) acc += src[(long)sp * stride];
         return acc;
     };
-    if (rp.colsum_out)
+    if (rp.colsum_out && rp.colsum_ld == 0) {       // one sum over every image's shares (the splits of image b follow those of b-1)
+        for (long e = gid; e < rp.n_valid; e += gsz)
+            rp.colsum_out[e] = ordered_sum(rp.colsum_part + e, (long)rp.tiles_n * rp.tn_rows, rp.batch * rp.spi * rp.cs_q);
+    } else if (rp.colsum_out)
         for (long e = gid; e < (long)rp.batch * rp.n_valid; e += gsz) {
             const int b = (int)(e / rp.n_valid), n = (int)(e % rp.n_valid);
             const long stride = (long)rp.tiles_n * rp.tn_rows;
@@ -1445,7 +1448,8 @@ void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb,
 }
 
 // dW[n_valid x k_valid] = sum over images and pixels of A[b][n][p] * B[b][k][p] for channels-first fp32 images
-// ([B][lda][P] and [B][ldb][P], P % 32 == 0); colsum_out[b][n] = sum_p A[b][n][p].  Exact fp32 MFMA.
+// ([B][lda][P] and [B][ldb][P], P % 32 == 0); colsum_out[b * colsum_ld + n] = sum_p A[b][n][p], or with colsum_ld == 0
+// colsum_out[n] = the sum over the images too.  Exact fp32 MFMA.
 void launch_wgrad_img(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, int batch,
                       long pixels_per_image, float* dW, int ldw, float* colsum_out, int colsum_ld, float* scratch,
                       hipStream_t stream) {
