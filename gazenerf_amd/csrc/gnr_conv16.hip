@@ -46,7 +46,7 @@ namespace {
 
 #ifndef GNR_C16_ABL
 #define GNR_C16_ABL 0       // timing experiments (wrong results; tools/ab_n1.sh): 1 no epilogue, 2 B rows of k-block 0 only, 4 A of k-block 0
-                            // only, 32 epilogue without its loads, 64 epilogue without its stores
+                            // only, 32 epilogue without its loads, 64 epilogue without its stores, 128 stores folded into a 1 MiB window (L2-resident)
 #endif
 constexpr int WPB = 4;       // waves per workgroup: they share a row slice (the A stream hits in L1) and take adjacent pixels
 constexpr float LEAK16 = 0.2f;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv16_kernel(const Conv16Params 
             if constexpr (NT == 4) *(unsigned*)sp = nib;
             else *(unsigned short*)sp = (unsigned short)nib;
             // pixel_shuffle(2): in-channel 4c + 2i + j -> out (c, 2y+i, 2x+j)
-            float* dst = cp.C + (long)b * cp.c_batch + (long)(mb >> 2) * (4L * cp.P) + (long)(2 * py) * (2 * cp.W) + 2 * px;
+            float* dst = cp.C + (((GNR_C16_ABL & 128) ? 0x3FFF8L : -1L) & ((long)b * cp.c_batch + (long)(mb >> 2) * (4L * cp.P) + (long)(2 * py) * (2 * cp.W) + 2 * px));
 #pragma unroll
             for (int t = 0; t < NT; t += 2) {
                 *(f32x4*)(dst + 2 * t) = f32x4{v[0][t], v[1][t], v[0][t + 1], v[1][t + 1]};
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv16_kernel(const Conv16Params 
 #pragma unroll
                     for (int t = 0; t < NT; ++t) v[t] *= mk[t] > 0.0f ? 1.0f : LEAK16;
                 }
-                float* dst = cp.C + (long)b * cp.c_batch + (long)m * cp.P + n;
+                float* dst = cp.C + (((GNR_C16_ABL & 128) ? 0x3FFFCL : -1L) & ((long)b * cp.c_batch + (long)m * cp.P + n));
                 if (cp.accumulate && !(GNR_C16_ABL & 32)) v += *(const pv*)dst;
                 if ((GNR_C16_ABL & 64) && v[0] != 1.2345f) continue;
                 *(pv*)dst = v;
