@@ -412,6 +412,13 @@ static int up_dims(const GnrUpsampleProblem* p, UpDims* d) {
         d->ch[i] = c > p->min_feat ? c : p->min_feat;       // max(feat_nc // 2^i, min_feat), neural_renderer.py:60-97
         d->side[i] = p->featmap_size << i;
     }
+    // limits of the kernels: rgb_bwd_fused_kernel keeps 12 (C + 1) floats in LDS; the GEMMs address an image's operand
+    // (up to 4 C channels x P pixels, or C x 4 P) through one 32-bit buffer descriptor
+    if (p->feat_nc > 1024) return fail("gnr_upsample: feat_nc = %d exceeds the kernels' limit of 1024 channels", p->feat_nc);
+    for (int i = 0; i < p->n_blocks; ++i)
+        if (16L * d->ch[i] * d->side[i] * d->side[i] >= (1L << 31))
+            return fail("gnr_upsample: block %d (%d channels at %d x %d) exceeds the 2 GiB per-image operand limit of the GEMM "
+                        "kernels", i, d->ch[i], d->side[i], d->side[i]);
     return 0;
 }
 

@@ -284,7 +284,9 @@ int gnr_merge_bwd(const GnrMergeProblem* p, const float* g_merge_face, const flo
  * Channel schedule ch[i] = max(feat_nc >> i, min_feat) (neural_renderer.py:57-98).  Weights are the
  * reference's Conv2d tensors ([out,in,1,1] == row-major [out,in]) under their state-dict names:
  *   up1_* = feat_upsample_list.i.layer_1 [2c,c], up2_* = ...layer_2 [4c,2c], feat_* = feat_layers.i [c',c],
- *   rgb_* = feat_2_rgb_list.i [3,c_i], i = 0..n.  bg_featmap is not an input of forward(). */
+ *   rgb_* = feat_2_rgb_list.i [3,c_i], i = 0..n.  bg_featmap is not an input of forward().
+ * Limits (rejected with an error, gnr_last_error()): feat_nc <= 1024; 16 * ch[i] * side[i]^2 < 2^31 for every block (the
+ * reference's 258 channels at 64 x 64 -> 512 x 512 use 1.7 % of that). */
 #define GNR_UPSAMPLE_MAX_BLOCKS 4
 enum { GNR_UP_WS_FWD = 0, GNR_UP_WS_BWD = 1 };
 

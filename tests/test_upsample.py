@@ -81,6 +81,19 @@ def test_blur_matches_its_definition():
             assert abs(acc / 16.0 - float(got[y, xx])) < 1e-9
 
 
+def test_blur_matches_an_independent_reflect_convolution():
+    """A second, independent implementation of 'reflect'-bordered correlation: scipy.ndimage.correlate(mode='mirror')
+    (mirror = reflection about the edge PIXEL, the convention of torch / kornia 'reflect').  kornia itself is absent
+    (Blur parity stays labelled unpinned); this at least rules out a private reading of the border rule."""
+    from scipy import ndimage
+    g = np.random.default_rng(3)
+    x = g.standard_normal((2, 3, 9, 14))
+    k = np.outer([1.0, 2.0, 1.0], [1.0, 2.0, 1.0]) / 16.0
+    want = np.stack([np.stack([ndimage.correlate(x[b, c], k, mode="mirror") for c in range(3)]) for b in range(2)])
+    got = O.blur(torch.from_numpy(x)).numpy()
+    assert float(np.abs(got - want).max()) <= 1e-14
+
+
 # ----------------------------------------------------------------------------- GPU
 def _dev():
     assert torch.cuda.is_available(), "these tests need the MI355X"
