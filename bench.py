@@ -639,6 +639,28 @@ def run_cfg4(ctx):
     if rank != 0:
         return None
     ms = dt / args.steps * 1e3
+
+    # Outside the timed region: the upsampler alone on the 3B+1 stacked feature maps it sees in this
+    # step -- the largest part of the step that is not the hot path.
+    def time_upsampler():
+        xs = torch.randn(3 * B + 1, 258, S, S, device=dev, requires_grad=True)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        tf, tb = [], []
+        for it in range(7):
+            ev[0].record()
+            y = net.neural_render(xs)
+            ev[1].record()
+            y.backward(torch.ones_like(y))
+            ev[2].record()
+            torch.cuda.synchronize(dev)
+            if it >= 2:
+                tf.append(ev[0].elapsed_time(ev[1]))
+                tb.append(ev[0].elapsed_time(ev[2]))
+        opt.zero_grad(set_to_none=True)
+        return {"images": 3 * B + 1, "fwd_ms": sorted(tf)[len(tf) // 2], "fwdbwd_ms": sorted(tb)[len(tb) // 2],
+                "kernels": "gnr::conv16_kernel<MT,NT,..> + gnr::wgrad2w_kernel / wgrad_kernel (image layout) + stencil / RGB kernels",
+                "timing": "median of 5 calls of GazeNeRFNetAMD.neural_render on a random [3B+1,258,64,64] map, HIP events, outside the timed steps"}
+    upsampler = time_upsampler()
     x3 = args.precision == "bf16x3"
     peak = PEAK_BF16X3_TFLOPS if x3 else PEAK_FP32_MFMA_TFLOPS
     m = B * n_rays * n_p
@@ -675,6 +697,8 @@ def run_cfg4(ctx):
                      "step_frac": hot_flop / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                      "step_frac_basis": "hot-path FLOPs only (3 x forward) over the whole step's wall time, fp32 MFMA peak"},
         "stages": stages,
+        "upsampler": upsampler,
+        "outside_hot_path_ms": ms - sum(st["avg_ms"] * mult for st, mult in zip(stages, (1, 2, 2))),
     }
     ar = dist_info(ctx, reducer, clock)
     if ar:

@@ -90,6 +90,8 @@ def test_cfg4_whole_network_step_reduces_every_gradient():
     assert ar["floats"] == 5015714 and ar["buckets"] == 3 and ar["world_size_formed"] == 2
     assert abs(d["value"] - 2 * 2 * 4096 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     assert {s["stage"] for s in d["stages"]} == {"fwd_mlp", "dgrad", "wgrad"}
+    up = d["upsampler"]                       # N1 alone on the step's 3B+1 stacked maps, timed outside the steps
+    assert up["images"] == 7 and 0 < up["fwd_ms"] < up["fwdbwd_ms"] and 0 < d["outside_hot_path_ms"] < d["ms_per_step"]
 
 
 @pytest.mark.parametrize("mode", ["fwd", "fwdbwd"])
