@@ -8,9 +8,11 @@
 // fp32-MFMA peak on these shapes: M is one channel past a multiple of 128 (129, 258, 516, 1032: 10-33 % padded rows),
 // K is 64-516 (4-33 k-tiles: prologue, epilogue and barriers are a large share), and at B = 1 most layers launch fewer
 // workgroups than the chip has slots.  This kernel applies what round 3 measured for the MLP chain (DESIGN.md section 5,
-// tools/ubench/mfma_2w.hip): two INDEPENDENT waves per SIMD -- no LDS, no barrier -- each feeding
-// v_mfma_f32_16x16x4_f32 straight from registers reach 97 % of the matrix pipe, because one wave's loads, waits and
-// epilogue issue beside the other's MFMAs.
+// tools/ubench/mfma_2w.hip): two or more INDEPENDENT waves per SIMD -- no LDS, no barrier -- each feeding
+// v_mfma_f32_16x16x4_f32 straight from registers reach 97 % of the matrix pipe, because one wave's loads and waits issue
+// beside the other's MFMAs.  Measured here (profiles/r3_n1_conv16_experiments.txt): the main loops run at 0.85-0.90 of
+// the peak; the epilogue's stores do NOT hide under the other waves' MFMAs -- they add their duration -- whatever the tile
+// shape, the workgroup size or the phase relation of the waves, which is what is left of the distance to the roof.
 //
 // A wave owns MT row tiles (16 channels) x NT pixel tiles (16 pixels) over the WHOLE contraction:
 //   * A (weights, <= 2 MB, re-laid out once per call by conv16_pack_kernel as [slice][k-block][row tile][lane][4]):
@@ -23,8 +25,9 @@
 //   * both operand sets of block kb+1 are requested before the MFMAs of block kb (register double buffer): a whole
 //     block of MFMAs (MT*NT*4 x 32 cycles) covers the latency.  vmcnt is in-order, so A cannot run a shorter prefetch
 //     distance than B without forcing B's loads home early -- hence 2 x MT x 4 A registers.
-//   * MT x NT per layer from a small cost model (padded work x fill of the 1024 SIMDs): 1032 rows = 5 x 13 tiles
-//     exactly, 516 = 3 x 11, 258 -> 2 x 9, 129 -> 9; at B = 1 smaller slices when the chip would be under-filled.
+//   * MT x NT per layer from a small cost model (padded work x fill of the 1024 SIMDs; conv16_plan): measured, the
+//     smallest tile (2 x 4: 84 VGPRs, five waves per SIMD) is at or near the best for every plain GEMM and wins the ties;
+//     1032 rows = 5 x 13 tiles exactly and 516 = 3 x 11 are kept for shapes where padding decides.
 //   * workgroup id -> (XCD, slot): an XCD takes a contiguous range of (pixel tile, row slice) items, row slice fastest,
 //     so the slices of one pixel tile re-read its B rows from the same L2.
 // BLUR instances (forward feat_layers): the B operand is blur(u), computed on the fly from three rows of u (reflect
