@@ -1,6 +1,8 @@
 """Per-dispatch counters of the GEMM launches of the last iteration of tools/n1_trace.py (rocprofv3 --pmc CSVs of
 tools/n1_pmc.sh: sq/, fetch/, write/).  MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs);
-FETCH_SIZE / WRITE_SIZE in KiB-units of 1 KB -> MB as MI355X_MICROARCH.md prescribes (x 1024 bytes... reported raw too)."""
+FETCH_SIZE / WRITE_SIZE are KB: bytes = counter x 1024 (MI355X_MICROARCH.md, HBM section); FETCH_SIZE is printed as
+counted -- on gfx950 it tallies the 128-byte requests of 16-byte-per-lane streaming reads at 64 bytes (double it for
+those), and Infinity-Cache hits are included."""
 import collections
 import csv
 import glob
@@ -42,4 +44,4 @@ for d, f, w in zip(rows, fr, wrr):
     print("%-34s grid %-9s waves %-6d us@2.4GHz %-7.1f mfma_busy %.3f  wait_any %.3f  wait_inst %.3f  fetch %8.1f MB  write %8.1f MB" % (
         n[:34], d["grid"], d.get("SQ_WAVES", 0), gui / 8 / 2400.0, d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(gui * 128.0, 1),
         d.get("SQ_WAIT_ANY", 0) / max(wc, 1), d.get("SQ_WAIT_INST_ANY", 0) / max(wc, 1),
-        (f or {}).get("FETCH_SIZE", 0) * 1024 / 1e6 / 32 * 32, (w or {}).get("WRITE_SIZE", 0) * 1024 / 1e6))
+        (f or {}).get("FETCH_SIZE", 0) * 1024 / 1e6, (w or {}).get("WRITE_SIZE", 0) * 1024 / 1e6))
