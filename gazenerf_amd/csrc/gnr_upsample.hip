@@ -9,15 +9,19 @@
 //             net = lrelu(Wf v + bf);  rgb = rgb + conv_rgb(i+1)(net);  if not last: rgb = up(rgb)
 //   img = sigmoid(rgb);   up = blur o bilinear-x2 (align_corners=False);  blur = reflect-padded [1,2,1]^2/16
 //
-// All tensors are the reference's channels-first fp32 images [B][C][H*W].  The 1x1 convolutions are GEMMs
-// over pixels (C[M][N] = A[M][K] B[K][N], N = pixels contiguous): conv_gemm_kernel, fp32 MFMA
-// (v_mfma_f32_32x32x2_f32, exact fp32), 128x128 tile per 256-thread workgroup through a k-major LDS image
-// (every operand read is a conflict-free ds_read_b32), epilogues fused: bias + LeakyReLU, the
-// residual-repeat + pixel_shuffle store of the PixelShuffleUpsample tail (with the sign byte the backward
-// needs), LeakyReLU-derivative masks and accumulation for the dgrad GEMMs (A = W^T by strides).
-// Weight gradients re-use wgrad_kernel (gnr_wgrad.hip) on the image layout; the 3-channel RGB branch and the
-// stencils (blur, bilinear, their adjoints) are one-thread-per-pixel HBM-bound kernels.
-// Work per 64x64 -> 512x512 image: 19.6 GFLOP forward (9.8 GMAC), ~0.6 GB of activation traffic.
+// All tensors are the reference's channels-first fp32 images [B][C][H*W].  The 1x1 convolutions are GEMMs over pixels
+// (C[M][N] = A[M][K] B[K][N], N = pixels contiguous): conv16_kernel (gnr_conv16.hip), exact fp32 MFMA fed from registers
+// by several independent waves per SIMD, epilogues fused: bias + LeakyReLU, the residual-repeat + pixel_shuffle store of
+// the PixelShuffleUpsample tail (with the sign nibble the backward needs), LeakyReLU-derivative masks and accumulation
+// for the dgrad GEMMs (A = W^T by strides).  Round 3:
+//   * blur(u) is never written: the feat_layers GEMM reads its operand through the stencil; the backward applies the
+//     adjoint stencil to the half-width gradient instead (blur and the 1x1 convolution commute), so u is what is saved;
+//   * weight gradients: wgrad2w_kernel / wgrad_kernel (gnr_wgrad.hip) on the image layout, bias gradients as their column
+//     sums over all images;
+//   * the 3-channel RGB branch: forward one thread per pixel, backward ONE pass over the activations for the weight and
+//     the data gradient (rgb_bwd_fused_kernel);
+//   * stencils (blur adjoint, bilinear and its adjoint, un-shuffle) are HBM-bound gather kernels with 16-byte accesses.
+// Work per 64x64 -> 512x512 image: 19.6 GFLOP forward (9.8 GMAC), ~0.77 GB of activation traffic.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
