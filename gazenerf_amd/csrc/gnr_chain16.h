@@ -123,7 +123,11 @@ __device__ __forceinline__ void wbatch16(WStream16& w, f32x4 (&g)[WB16]) {
 #ifdef GNR_VOFF_STREAM      // A/B switch: the running offset in the VGPR (one v_add per batch)
 __device__ __forceinline__ void wadvance16(WStream16& w) { w.voff += WB16 * 1024u; }
 #else
+#ifdef GNR_W_HOT       /* timing experiment (wrong results): the weight stream wraps inside a 1 MiB window -> L2-resident */
+__device__ __forceinline__ void wadvance16(WStream16& w) { w.soff = (w.soff + WB16 * 1024u) & 0xFFFFFu; }
+#else
 __device__ __forceinline__ void wadvance16(WStream16& w) { w.soff += WB16 * 1024u; }
+#endif
 #endif
 __device__ __forceinline__ void wstream16_init(WStream16& w, const float* packed, int lane) {
     w.rs = __builtin_amdgcn_make_buffer_rsrc((void*)packed, 0, 0x7ffffff0, 0x00020000);
