@@ -184,31 +184,34 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv16_kernel(const Conv16Params 
             for (int e = 0; e < NT; ++e) blur_taps16(x + e, W, wl[e], wc, wr[e]);
         }
         const int y0 = y >= 1 ? y - 1 : y, y2 = y + 1 < H ? y + 1 : y;
-        const int xm = x >= 1 ? x - 1 : x, xp = x + NT < W ? x + NT : x + NT - 1;
-        unsigned vc[3], vl[3], vr[3];
+        // The two neighbours outside a lane's NT pixels belong to the lanes next to it: a DPP row shift (a row = the 16
+        // lanes of one k-group) supplies them, except at the two ends of the wave's pixel run.  Those 2 x 16 rows x 3 image
+        // rows = 96 values per k-block are fetched by TWO dword loads (lane l: k-step l / 16, k-group (l / 4) % 4, image
+        // row l % 4) and handed to the end lanes by ds_bpermute.  (Round-3 measurement: one dword load per neighbour per
+        // lane -- 24 per k-block, each touching as many cache lines as a 16-byte load -- cost more than the MFMAs:
+        // feat_layers 161 / 196 / 343 us with them, 121 / 125 / 197 without.)
+        const int x0w = p0 - y * W;                                // first column of the wave's run (wave-uniform)
+        unsigned vc[3], ve_l, ve_r;
         {
             const int ys[3] = {y0, y, y2};
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const unsigned base = (unsigned)g * (unsigned)cp.P + (unsigned)(ys[q] * W);
-                vc[q] = (base + (unsigned)x) * 4u;
-                vl[q] = (base + (unsigned)xm) * 4u;
-                vr[q] = (base + (unsigned)xp) * 4u;
-            }
+            for (int q = 0; q < 3; ++q) vc[q] = ((unsigned)g * (unsigned)cp.P + (unsigned)(ys[q] * W) + (unsigned)x) * 4u;
+            const int es = lane >> 4, eg = (lane >> 2) & 3, eq = (lane & 3) < 3 ? (lane & 3) : 2;
+            const unsigned ebase = (unsigned)(4 * es + eg) * (unsigned)cp.P + (unsigned)(ys[eq] * W);
+            ve_l = (ebase + (unsigned)(x0w >= 1 ? x0w - 1 : 0)) * 4u;                       // weight 0 when outside (reflect folds inward)
+            ve_r = (ebase + (unsigned)(x0w + 16 * NT < W ? x0w + 16 * NT : W - 1)) * 4u;
         }
+        const int perm_base = 16 * g;                              // ds_bpermute byte address of source lane 4 g (+ 16 s + q)
         pv rc[4][3];
-        float rl[4][3], rr[4][3];
+        float edge_l, edge_r;
         auto load_raw = [&](int kb) {
             const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((GNR_C16_ABL & 2) ? 0 : kb) * 16u * rowB));
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const unsigned so = sb + (unsigned)s * 4u * rowB;
-                    rc[s][q] = Pix<NT>::load(rsB, vc[q], so);
-                    rl[s][q] = load1(rsB, vl[q], so);
-                    rr[s][q] = load1(rsB, vr[q], so);
-                }
+                for (int q = 0; q < 3; ++q) rc[s][q] = Pix<NT>::load(rsB, vc[q], sb + (unsigned)s * 4u * rowB);
+            edge_l = load1(rsB, ve_l, sb);
+            edge_r = load1(rsB, ve_r, sb);
         };
         // The raw rows of block kb+1 are requested before the MFMAs of block kb and folded into its B operand right after
         // them: only the 4 NT operand registers are carried from one iteration to the next (with the raw rows carried
@@ -219,13 +222,21 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv16_kernel(const Conv16Params 
             for (int s = 0; s < 4; ++s) {
                 float row[3][NT];
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
+                for (int q = 0; q < 3; ++q) {
+                    // neighbours across the lane boundary: row_shr:1 / row_shl:1 of the adjacent lane's end pixel; the end
+                    // lanes of the row (no source lane) keep `old` = the value fetched for the wave's ends
+                    const int src = perm_base + (16 * s + q) * 4;
+                    const int el = __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, edge_l));
+                    const int er = __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, edge_r));
+                    const float nl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(el, __builtin_bit_cast(int, (float)rc[s][q][NT - 1]), 0x111, 0xf, 0xf, false));
+                    const float nr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(er, __builtin_bit_cast(int, (float)rc[s][q][0]), 0x101, 0xf, 0xf, false));
 #pragma unroll
                     for (int e = 0; e < NT; ++e) {
-                        const float left = e == 0 ? rl[s][q] : rc[s][q][e - 1];
-                        const float right = e == NT - 1 ? rr[s][q] : rc[s][q][e + 1];
+                        const float left = e == 0 ? nl : rc[s][q][e - 1];
+                        const float right = e == NT - 1 ? nr : rc[s][q][e + 1];
                         row[q][e] = wl[e] * left + 0.5f * rc[s][q][e] + wr[e] * right;
                     }
+                }
 #pragma unroll
                 for (int e = 0; e < NT; ++e) Bo[s][e] = yl * row[0][e] + yc * row[1][e] + yr * row[2][e];
             }
