@@ -75,10 +75,17 @@ __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in,
 #pragma unroll
     for (int e = 0; e < 4; ++e) blur_taps(x + e, W, adjoint, wl[e], wc[e], wr[e]);
     const int xm = x >= 1 ? x - 1 : x, xp = x + 4 < W ? x + 4 : x + 3;
+    // The two neighbours outside the thread's four pixels are the end pixels of the adjacent lanes' quads (a strided dword
+    // load per neighbour touches as many cache lines as the 16-byte load itself): lane shuffles, and a real load only in
+    // the first / last lane of the wave.  At the image's left / right edge the neighbour's weight is 0 resp. the reflected
+    // pixel is the thread's own.
+    const int lane = threadIdx.x & 63;
     auto row = [&](int yy) {
         const float* r = p + (long)yy * W;
         const f32x4 c = *(const f32x4*)(r + x);
-        const float l = r[xm], rr = r[xp];
+        float l = __shfl_up(c.w, 1), rr = __shfl_down(c.x, 1);
+        if (lane == 0 || x == 0) l = r[xm];
+        if (lane == 63 || x + 4 >= W) rr = r[xp];
         return f32x4{wl[0] * l + wc[0] * c.x + wr[0] * c.y, wl[1] * c.x + wc[1] * c.y + wr[1] * c.z,
                      wl[2] * c.y + wc[2] * c.z + wr[2] * c.w, wl[3] * c.z + wc[3] * c.w + wr[3] * rr};
     };
