@@ -187,7 +187,9 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv16_kernel(const Conv16Params 
         // The two neighbours outside a lane's NT pixels belong to the lanes next to it: a DPP row shift (a row = the 16
         // lanes of one k-group) supplies them, except at the two ends of the wave's pixel run.  Those 2 x 16 rows x 3 image
         // rows = 96 values per k-block are fetched by TWO dword loads (lane l: k-step l / 16, k-group (l / 4) % 4, image
-        // row l % 4) and handed to the end lanes by ds_bpermute.  (Round-3 measurement: one dword load per neighbour per
+        // row l % 4), reduced over the three image rows inside their lane quads and handed to the end lanes by ds_bpermute.
+        // The stencil is applied rows-first (its taps along the row do not depend on the row): NT + 2 column sums, then
+        // three taps -- 30 VALU per operand quad, not 48; blur_kernel's order differs by rounding only.  (Round-3 measurement: one dword load per neighbour per
         // lane -- 24 per k-block, each touching as many cache lines as a 16-byte load -- cost more than the MFMAs:
         // feat_layers 161 / 196 / 343 us with them, 121 / 125 / 197 without.)
         const int x0w = p0 - y * W;                                // first column of the wave's run (wave-uniform)
@@ -218,27 +220,30 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv16_kernel(const Conv16Params 
         // instead, hipcc copies all 18 NT of them at the loop head and spills).
         pv Bv[2][4];
         auto combine = [&](pv (&Bo)[4]) {
+            // the three image rows of an end column sit in three adjacent lanes of the edge load (l % 4 = row): their
+            // weighted sum by quad broadcasts, once per k-block
+            auto quad_rows = [&](float v) {
+                const int iv = __builtin_bit_cast(int, v);
+                const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(iv, 0x00, 0xf, 0xf, true));     // quad_perm [0,0,0,0]
+                const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(iv, 0x55, 0xf, 0xf, true));     // [1,1,1,1]
+                const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(iv, 0xAA, 0xf, 0xf, true));     // [2,2,2,2]
+                return yl * r0 + yc * r1 + yr * r2;
+            };
+            const float comb_l = quad_rows(edge_l), comb_r = quad_rows(edge_r);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                float row[3][NT];
+                // rows first (the taps along the row do not depend on the row): NT + 2 columns, then the three taps
+                float col[NT + 2];
+                {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    // neighbours across the lane boundary: row_shr:1 / row_shl:1 of the adjacent lane's end pixel; the end
-                    // lanes of the row (no source lane) keep `old` = the value fetched for the wave's ends
-                    const int src = perm_base + (16 * s + q) * 4;
-                    const int el = __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, edge_l));
-                    const int er = __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, edge_r));
-                    const float nl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(el, __builtin_bit_cast(int, (float)rc[s][q][NT - 1]), 0x111, 0xf, 0xf, false));
-                    const float nr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(er, __builtin_bit_cast(int, (float)rc[s][q][0]), 0x101, 0xf, 0xf, false));
-#pragma unroll
-                    for (int e = 0; e < NT; ++e) {
-                        const float left = e == 0 ? nl : rc[s][q][e - 1];
-                        const float right = e == NT - 1 ? nr : rc[s][q][e + 1];
-                        row[q][e] = wl[e] * left + 0.5f * rc[s][q][e] + wr[e] * right;
-                    }
+                    for (int e = 0; e < NT; ++e) col[e + 1] = yl * rc[s][0][e] + yc * rc[s][1][e] + yr * rc[s][2][e];
+                    const float el = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm_base + 64 * s, __builtin_bit_cast(int, comb_l)));
+                    const float er = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm_base + 64 * s, __builtin_bit_cast(int, comb_r)));
+                    col[0] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, el), __builtin_bit_cast(int, col[NT]), 0x111, 0xf, 0xf, false));
+                    col[NT + 1] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, er), __builtin_bit_cast(int, col[1]), 0x101, 0xf, 0xf, false));
                 }
 #pragma unroll
-                for (int e = 0; e < NT; ++e) Bo[s][e] = yl * row[0][e] + yc * row[1][e] + yr * row[2][e];
+                for (int e = 0; e < NT; ++e) Bo[s][e] = wl[e] * col[e] + 0.5f * col[e + 1] + wr[e] * col[e + 2];
             }
         };
         load_raw(0);
