@@ -1264,9 +1264,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReducePara
         for (; sp < count; ++sp) acc += src[(long)sp * stride];
         return acc;
     };
-    if (rp.colsum_out && rp.colsum_ld == 0) {       // one sum over every image's shares (the splits of image b follow those of b-1)
-        for (long e = gid; e < rp.n_valid; e += gsz)
-            rp.colsum_out[e] = ordered_sum(rp.colsum_part + e, (long)rp.tiles_n * rp.tn_rows, rp.batch * rp.spi * rp.cs_q);
+    if (rp.colsum_out && rp.colsum_ld == 0) {
+        // one sum over every image's shares (the splits of image b follow those of b-1): up to ~1000 per output, so a WAVE
+        // per output -- lane l adds shares l, l + 64, ... in order, then the 64 lane sums meet in a fixed tree
+        const long stride = (long)rp.tiles_n * rp.tn_rows;
+        const int count = rp.batch * rp.spi * rp.cs_q, lane = threadIdx.x & 63;
+        for (long n = gid >> 6; n < rp.n_valid; n += gsz >> 6) {
+            float a = 0.0f;
+            for (int sp = lane; sp < count; sp += 64) a += rp.colsum_part[(long)sp * stride + n];
+#pragma unroll
+            for (int sft = 32; sft > 0; sft >>= 1) a += __shfl_xor(a, sft);
+            if (lane == 0) rp.colsum_out[n] = a;
+        }
     } else if (rp.colsum_out)
         for (long e = gid; e < (long)rp.batch * rp.n_valid; e += gsz) {
             const int b = (int)(e / rp.n_valid), n = (int)(e % rp.n_valid);
