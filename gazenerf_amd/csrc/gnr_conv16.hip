@@ -31,7 +31,7 @@
 //   * workgroup id -> (XCD, slot): an XCD takes a contiguous range of (pixel tile, row slice) items, row slice fastest,
 //     so the slices of one pixel tile re-read its B rows from the same L2.
 // BLUR instances (forward feat_layers): the B operand is blur(u), computed on the fly from three rows of u (reflect
-// padding == kornia filter2d border_type='reflect', same taps and order as blur_kernel) -- the blurred map is never
+// padding == kornia filter2d border_type='reflect', blur_kernel's taps applied rows-first) -- the blurred map is never
 // written; the backward uses blur's adjoint on the (half as wide) gradient instead (gnr_upsample.hip).
 #include "gnr_conv16.h"
 
