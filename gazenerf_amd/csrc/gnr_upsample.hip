@@ -292,6 +292,122 @@ __global__ __launch_bounds__(256) void rgb_bwd_fused_kernel(const float* __restr
     }
 }
 
+// The same pass with the NEXT step folded in: block i's backward needs g = blur^T(dhid), not dhid.  A workgroup owns a tile
+// of 16 rows x 64 columns (thread: row tid / 16, four columns 4 (tid % 16) ..); per channel it computes dhid for the tile and
+// its one-pixel halo (threads 0 .. 163 take one halo pixel each), parks it in LDS (two buffers: one barrier per channel) and
+// applies the adjoint stencil from there with blur_kernel's weights and order -- dhid never goes to memory (saves one write
+// and one read of the C/2-channel gradient per block).  Weight-gradient partials as above (centre pixels only).
+constexpr int RB_TH = 16, RB_TW = 64, RB_LD = 72, RB_TILE = (RB_TH + 2) * RB_LD;      // LDS row: 3 pad + 66 used + 3
+
+__global__ __launch_bounds__(256) void rgb_bwd_blur_kernel(const float* __restrict__ drgb, const float* __restrict__ net, int C,
+                                                           int H, int W, int batch, const float* __restrict__ w,
+                                                           const float* __restrict__ dnet_in, float* __restrict__ gout,
+                                                           float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int wsum_floats = (12 * (C + 1) + 3) & ~3;
+    float* wsum = sm;                                            // [4 waves][3][C + 1]
+    float* tile = sm + wsum_floats;                              // [2][18][RB_LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long P = (long)H * W;
+    const int tiles_x = W / RB_TW, tiles_y = H / RB_TH;
+    const int b = (int)(blockIdx.x / (unsigned)(tiles_x * tiles_y)), trem = (int)(blockIdx.x - (unsigned)b * (tiles_x * tiles_y));
+    const int y00 = (trem / tiles_x) * RB_TH, x00 = (trem % tiles_x) * RB_TW;
+    const int r = tid >> 4, q = tid & 15, y = y00 + r, x = x00 + 4 * q;
+    const long base = (long)b * C * P + (long)y * W + x;
+    f32x4 g[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) g[o] = *(const f32x4*)(drgb + ((long)b * 3 + o) * P + (long)y * W + x);
+    // halo pixel of this thread (if any): top row, bottom row, left column, right column of the 18 x 66 patch
+    int hy = 0, hx = 0;
+    bool halo = tid < 2 * (RB_TW + 2) + 2 * RB_TH;
+    if (tid < RB_TW + 2) { hy = -1; hx = tid - 1; }
+    else if (tid < 2 * (RB_TW + 2)) { hy = RB_TH; hx = tid - (RB_TW + 2) - 1; }
+    else if (tid < 2 * (RB_TW + 2) + RB_TH) { hy = tid - 2 * (RB_TW + 2); hx = -1; }
+    else { hy = tid - 2 * (RB_TW + 2) - RB_TH; hx = RB_TW; }
+    const int gy = y00 + hy, gx = x00 + hx;
+    const bool hin = halo && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const long hbase = hin ? (long)b * C * P + (long)gy * W + gx : 0;
+    float hg[3] = {0.0f, 0.0f, 0.0f};
+    if (hin) {
+#pragma unroll
+        for (int o = 0; o < 3; ++o) hg[o] = drgb[((long)b * 3 + o) * P + (long)gy * W + gx];
+    }
+    const int hpos = (hy + 1) * RB_LD + 3 + (hx + 1);
+    const int cpos = (r + 1) * RB_LD + 4 + 4 * q;                // the thread's four pixels inside the patch (16-byte aligned)
+    // adjoint taps of this thread's outputs (as blur_kernel, adjoint = 1)
+    float yl, yc, yr, wl[4], wc[4], wr[4];
+    blur_taps(y, H, true, yl, yc, yr);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) blur_taps(x + e, W, true, wl[e], wc[e], wr[e]);
+    auto wave_sum = [](float v) {
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) v += __shfl_xor(v, sft);
+        return v;
+    };
+    const int cper = (C + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int cbeg = (int)blockIdx.y * cper;
+    const int cend = cbeg + cper < C ? cbeg + cper : C;
+    const bool with_bias = blockIdx.y + 1 == gridDim.y;
+    for (int c = cbeg, j = 0; c < cend; ++c, ++j) {
+        float* tb = tile + (j & 1) * RB_TILE;
+        const float w0 = w[c], w1 = w[C + c], w2 = w[2 * C + c];
+        const f32x4 nv = *(const f32x4*)(net + base + (long)c * P);
+        f32x4 v = w0 * g[0] + w1 * g[1] + w2 * g[2];
+        if (dnet_in) v += *(const f32x4*)(dnet_in + base + (long)c * P);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= nv[e] > 0.0f ? 1.0f : LEAK;
+        *(f32x4*)(tb + cpos) = v;
+        if (halo) {
+            float hv = 0.0f;
+            if (hin) {
+                hv = w0 * hg[0] + w1 * hg[1] + w2 * hg[2];
+                if (dnet_in) hv += dnet_in[hbase + (long)c * P];
+                hv *= net[hbase + (long)c * P] > 0.0f ? 1.0f : LEAK;
+            }
+            tb[hpos] = hv;
+        }
+        if (part) {
+            float a[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int o = 0; o < 3; ++o)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[o] = fmaf(g[o][e], nv[e], a[o]);
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                const float t = wave_sum(a[o]);
+                if (lane == 0) wsum[(wave * 3 + o) * (C + 1) + c] = t;
+            }
+        }
+        __syncthreads();
+        f32x4 rows[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float* rp = tb + (r + k) * RB_LD + 4 + 4 * q;
+            const f32x4 cc = *(const f32x4*)rp;
+            const float l = rp[-1], rr = rp[4];
+            rows[k] = f32x4{wl[0] * l + wc[0] * cc.x + wr[0] * cc.y, wl[1] * cc.x + wc[1] * cc.y + wr[1] * cc.z,
+                            wl[2] * cc.y + wc[2] * cc.z + wr[2] * cc.w, wl[3] * cc.z + wc[3] * cc.w + wr[3] * rr};
+        }
+        *(f32x4*)(gout + base + (long)c * P) = yl * rows[0] + yc * rows[1] + yr * rows[2];
+    }
+    if (!part) return;
+    if (with_bias) {
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const float t = wave_sum((g[o].x + g[o].y) + (g[o].z + g[o].w));
+            if (lane == 0) wsum[(wave * 3 + o) * (C + 1) + C] = t;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 3 * (C + 1); i += 256) {
+        const int o = i / (C + 1), c = i - o * (C + 1);
+        if (!((c >= cbeg && c < cend) || (with_bias && c == C))) continue;
+        const float t = (wsum[(0 * 3 + o) * (C + 1) + c] + wsum[(1 * 3 + o) * (C + 1) + c]) +
+                        (wsum[(2 * 3 + o) * (C + 1) + c] + wsum[(3 * 3 + o) * (C + 1) + c]);
+        part[((long)c * gridDim.x + blockIdx.x) * 3 + o] = t;
+    }
+}
+
 // one wave per (channel, output): lane l adds the partials l, l + 64, ... in order, then the 64 lane sums are added in a
 // fixed tree
 __global__ __launch_bounds__(64) void rgb_wsum_kernel(const float* __restrict__ part, int C, int nwg, float* __restrict__ dw,
@@ -550,7 +666,9 @@ static size_t up_carve_bwd(const GnrUpsampleProblem* p, const UpDims& d, char* b
     size_t cs_floats = B * (size_t)(mmax + 128);
     for (int i = 0; i <= d.n_blocks; ++i) {           // rgb_bwd_fused_kernel's partials: (channels + 1) x workgroups x 3
         const size_t px = B * (size_t)d.side[i] * d.side[i];
-        const size_t need = (size_t)(d.ch[i] + 1) * (size_t)rgbf_workgroups((long)px) * 3;
+        size_t wgs = (size_t)rgbf_workgroups((long)px);
+        if (px / (RB_TH * RB_TW) > wgs) wgs = px / (RB_TH * RB_TW);       // rgb_bwd_blur_kernel: one workgroup per 16 x 64 tile
+        const size_t need = (size_t)(d.ch[i] + 1) * wgs * 3;
         if (cs_floats < need) cs_floats = need;
     }
     z.colsum = (float*)take(cs_floats * 4);
@@ -718,14 +836,25 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
         float* Y = X == t.g0 ? t.g1 : t.g0;            // g, later dpre2
         {
             const bool want_w = G.rgb_w[i + 1] || G.rgb_b[i + 1];
-            const unsigned nwg = (unsigned)rgbf_workgroups((long)B * P4);
-            hipLaunchKernelGGL(rgb_bwd_fused_kernel, dim3(nwg, rgbf_channel_groups(nwg, Cn)), dim3(256), (size_t)12 * (Cn + 1) * sizeof(float), st, drgb, s.net[i], Cn,
-                               P4, B, w->rgb_w[i + 1], X, dnet_next ? 1 : 0, 1, want_w ? t.colsum : (float*)nullptr);
-            if (want_w)
-                hipLaunchKernelGGL(rgb_wsum_kernel, dim3(3 * (Cn + 1)), dim3(64), 0, st, t.colsum, Cn, (int)nwg, G.rgb_w[i + 1], G.rgb_b[i + 1]);
+            if ((2 * S) % RB_TW == 0 && (2 * S) % RB_TH == 0) {
+                // ... and g = blur^T dhid in the same pass (dhid stays in LDS)
+                const unsigned nwg = (unsigned)(B * (2 * S / RB_TH) * (2 * S / RB_TW));
+                const size_t lds = ((size_t)((12 * (Cn + 1) + 3) & ~3) + 2 * RB_TILE) * sizeof(float);
+                hipLaunchKernelGGL(rgb_bwd_blur_kernel, dim3(nwg, rgbf_channel_groups(nwg, Cn)), dim3(256), lds, st, drgb, s.net[i], Cn,
+                                   2 * S, 2 * S, B, w->rgb_w[i + 1], dnet_next ? X : (const float*)nullptr, Y,
+                                   want_w ? t.colsum : (float*)nullptr);
+                if (want_w)
+                    hipLaunchKernelGGL(rgb_wsum_kernel, dim3(3 * (Cn + 1)), dim3(64), 0, st, t.colsum, Cn, (int)nwg, G.rgb_w[i + 1], G.rgb_b[i + 1]);
+            } else {
+                const unsigned nwg = (unsigned)rgbf_workgroups((long)B * P4);
+                hipLaunchKernelGGL(rgb_bwd_fused_kernel, dim3(nwg, rgbf_channel_groups(nwg, Cn)), dim3(256), (size_t)12 * (Cn + 1) * sizeof(float), st, drgb, s.net[i], Cn,
+                                   P4, B, w->rgb_w[i + 1], X, dnet_next ? 1 : 0, 1, want_w ? t.colsum : (float*)nullptr);
+                if (want_w)
+                    hipLaunchKernelGGL(rgb_wsum_kernel, dim3(3 * (Cn + 1)), dim3(64), 0, st, t.colsum, Cn, (int)nwg, G.rgb_w[i + 1], G.rgb_b[i + 1]);
+                // g = blur^T dhid
+                hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * Cn * P)), dim3(256), 0, st, X, Y, (long)B * Cn, 2 * S, 2 * S, 1);
+            }
         }
-        // g = blur^T dhid
-        hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * Cn * P)), dim3(256), 0, st, X, Y, (long)B * Cn, 2 * S, 2 * S, 1);
         // feat_layers[i]: dWf = g u^T, dbf; du = Wf^T g
         launch_wgrad_img(Y, Cn, Cn, s.u[i], C, C, B, P4, G.feat_w[i], C, G.feat_b[i], 0, t.wg, st);
         Conv16Params g{};
