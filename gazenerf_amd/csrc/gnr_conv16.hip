@@ -278,6 +278,15 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv16_kernel(const Conv16Params 
         // pre-activation signs per pixel go into one nibble, the lane's pixels into one 8 NT-bit store.
         const int Cq = cp.M / 4;
         const int py = n / cp.W, px = n - py * cp.W;
+        // x.repeat(1,4,1,1): in-channel m reads x channel m % (M/4).  ONE division per lane; the channels of the lane's
+        // tiles follow by adding 16 mt + e and wrapping (a runtime modulo per channel was ~35 VALU, eight times per wave)
+        const int rbase = (m0 + 4 * g) % Cq;
+        auto res_row = [&](int add) {
+            int rr = rbase + add;
+            if (Cq >= 16 * MT + 4) { if (rr >= Cq) rr -= Cq; }       // add < 16 MT + 4 <= Cq: at most one wrap
+            else rr %= Cq;
+            return rr;
+        };
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int mb = m0 + 16 * mt + 4 * g;                  // multiple of 4
@@ -291,7 +300,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv16_kernel(const Conv16Params 
                 // x.repeat(1,4,1,1): in-channel m reads x channel m % (M/4)
                 pv res;
                 if (GNR_C16_ABL & 32) res = pv(0.25f);
-                else res = *(const pv*)(cp.res + (long)b * cp.res_batch + (long)(m % Cq) * cp.P + n);
+                else res = *(const pv*)(cp.res + (long)b * cp.res_batch + (long)res_row(16 * mt + e) * cp.P + n);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     float u = acc[mt][t][e] + bias;
