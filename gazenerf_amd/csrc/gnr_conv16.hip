@@ -35,6 +35,7 @@
 // written; the backward uses blur's adjoint on the (half as wide) gradient instead (gnr_upsample.hip).
 #include "gnr_conv16.h"
 
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -380,7 +381,11 @@ Conv16Plan conv16_plan(int M, int K, long pixels_total, int blur_w) {
         const int slices = (tiles + v.MT - 1) / v.MT;
         const double waves = (double)slices * (double)(pixels_total / (16 * v.NT));
         // two waves share a SIMD's matrix pipe: below 1024 waves the chip is not full and a wave's length is the time
-        double cost = (waves > 1024.0 ? waves / 1024.0 : 1.0) * v.MT * v.NT * (v.NT == 2 ? 1.06 : 1.0);
+        // rounds of 1024 waves; a few rounds are whole rounds (single-image sweep: 1088 waves of a (4,4) tile take as long as
+        // 2048 -- 75 us against 56 for the 2112 waves of (2,4) and 48 for 1024 waves of (9,2))
+        double rounds = waves / 1024.0;
+        if (rounds <= 4.0) rounds = std::ceil(rounds);
+        double cost = rounds * v.MT * v.NT * (v.NT == 2 ? 1.06 : 1.0);
         // every row slice repeats the stencil's loads (three rows + edges) and its ~30 VALU per operand register: the
         // fewest slices win (measured, 7 images: M = 64 as 1 x (4,4) 185 us, as 2 x (2,4) 249 us; M = 129 as (9,2) 160 us)
         if (blur_w) cost *= 1.0 + 0.5 * (slices - 1);
