@@ -15,13 +15,13 @@ N_RGB = 3
 WS_FWD, WS_FWD_SAVE, WS_BWD = 0, 1, 2
 STAGE_FWD_MLP, STAGE_DGRAD, STAGE_COMP_BWD, STAGE_WGRAD = 0, 1, 2, 3
 N_STAGES = 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _p = C.c_void_p
 
 
 class _Sized(C.Structure):
-    """Descriptor structs of ABI 3 start with ``struct_size`` = the caller's sizeof (include/gnr.h): stamped on
+    """Descriptor structs (since ABI 3) start with ``struct_size`` = the caller's sizeof (include/gnr.h): stamped on
     construction, checked by every entry point that takes the struct."""
 
     def __init__(self, *args, **kw):
@@ -85,7 +85,7 @@ class GnrInputGrads(C.Structure):
     _fields_ = [("R", _p), ("T", _p), ("shape_code", _p), ("gaze", _p), ("appea_code", _p), ("ray_bias", _p * 2)]
 
 
-EXPORTS = ("gnr_abi_version", "gnr_sizeof", "gnr_workspace_bytes", "gnr_fwd", "gnr_fwd_bf16x3", "gnr_bwd", "gnr_bwd_bf16x3", "gnr_resample",
+EXPORTS = ("gnr_abi_version", "gnr_build_info", "gnr_set_conv16_tile", "gnr_sizeof", "gnr_workspace_bytes", "gnr_fwd", "gnr_fwd_bf16x3", "gnr_bwd", "gnr_bwd_bf16x3", "gnr_resample",
            "gnr_sample_zvals", "gnr_set_kernel_timing", "gnr_set_aux_timing", "gnr_set_stage_timing", "gnr_set_clock_probe", "gnr_merge_scratch_bytes",
            "gnr_merge_fwd", "gnr_merge_bwd", "gnr_upsample_workspace_bytes", "gnr_upsample_fwd", "gnr_upsample_bwd",
            "gnr_last_error")
@@ -101,6 +101,42 @@ class GnrError(RuntimeError):
     """Raised when a libgnr entry point returns non-zero (message from gnr_last_error)."""
 
 
+def parse_build_info(info: str) -> dict:
+    """gnr_build_info() -> {"src": ..., "flags": ..., "experimental": ...} (include/gnr.h)."""
+    out = {"src": "unknown", "flags": "", "experimental": "0"}
+    for part in info.split(";"):
+        k, _, v = part.partition("=")
+        if k in out:
+            out[k] = v
+    return out
+
+
+def check_build_info(info: str, path: str):
+    """A library built from other sources than the tree's, or with timing-experiment switches, must not run silently: the
+    binaries are git-ignored and travel prebuilt.  `GNR_ALLOW_EXPERIMENTAL_LIB=1` admits an
+    experimental build (the A/B scripts under tools/ set it); nothing admits a stale one -- rebuild."""
+    import sys
+
+    from ._srchash import source_hash
+    bi = parse_build_info(info)
+    want = source_hash()
+    if want is not None and bi["src"] != want:
+        raise RuntimeError(
+            "gazenerf_amd: %s was built from other sources than this tree (library src=%s, tree src=%s): rebuild with "
+            "`python -m gazenerf_amd.build`" % (path, bi["src"], want))
+    if bi["experimental"] != "0" or bi["flags"]:
+        if os.environ.get("GNR_ALLOW_EXPERIMENTAL_LIB", "") != "1":
+            raise RuntimeError(
+                "gazenerf_amd: %s is a timing-experiment build (%s): results may be wrong.  Rebuild without "
+                "GNR_EXTRA_HIPCC_FLAGS, or set GNR_ALLOW_EXPERIMENTAL_LIB=1 for an A/B timing run" % (path, info))
+        print("gazenerf_amd: WARNING: running an EXPERIMENTAL libgnr.so (%s)" % info, file=sys.stderr, flush=True)
+
+
+def build_info() -> str:
+    """gnr_build_info() of the loaded library (bench.py prints it in its result line)."""
+    return load().gnr_build_info().decode("utf-8", "replace")
+
+
 def load():
     """dlopen libgnr.so (once).  Raises if it has not been built: there is no fallback path."""
     global _lib
@@ -112,6 +148,13 @@ def load():
             "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for the render op." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     lib.gnr_abi_version.restype = C.c_int
+    if lib.gnr_abi_version() != ABI_VERSION:
+        raise RuntimeError("libgnr.so ABI %d != binding ABI %d; rebuild with `python -m gazenerf_amd.build`" % (
+            lib.gnr_abi_version(), ABI_VERSION))
+    lib.gnr_build_info.restype = C.c_char_p
+    check_build_info(lib.gnr_build_info().decode("utf-8", "replace"), LIB_PATH)
+    lib.gnr_set_conv16_tile.restype = C.c_int
+    lib.gnr_set_conv16_tile.argtypes = [C.c_int, C.c_int]
     lib.gnr_last_error.restype = C.c_char_p
     lib.gnr_workspace_bytes.restype = C.c_size_t
     lib.gnr_workspace_bytes.argtypes = [C.POINTER(GnrProblem), C.c_int, C.c_int]
@@ -152,8 +195,6 @@ def load():
     lib.gnr_set_clock_probe.argtypes = [_p]
     lib.gnr_set_aux_timing.restype = C.c_int
     lib.gnr_set_aux_timing.argtypes = [_p, _p]
-    if lib.gnr_abi_version() != ABI_VERSION:
-        raise RuntimeError("libgnr.so ABI %d != binding ABI %d; rebuild" % (lib.gnr_abi_version(), ABI_VERSION))
     lib.gnr_sizeof.restype = C.c_size_t
     lib.gnr_sizeof.argtypes = [C.c_int]
     for which, cls in enumerate(STRUCTS):

@@ -28,6 +28,10 @@ def load(required: bool = False):
             if mod.abi_version() != _lib.ABI_VERSION:
                 raise RuntimeError("_gnr_torch.so was built against ABI %d, libgnr.so is ABI %d; rebuild" % (
                     mod.abi_version(), _lib.ABI_VERSION))
+            from ._srchash import source_hash
+            if source_hash() is not None and mod.source_hash() != source_hash():
+                raise RuntimeError("_gnr_torch.so was built from other sources than this tree (%s vs %s); rebuild with "
+                                   "`python -m gazenerf_amd.build`" % (mod.source_hash(), source_hash()))
             _mod = mod
     if _mod is None and required:
         raise RuntimeError("gazenerf_amd: %s is missing. Build it with `python -m gazenerf_amd.build`." % PATH)

@@ -17,6 +17,7 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
             const GnrInputGrads* din, const GnrWeightGrads* const* dw, void* saved, size_t saved_bytes,
             void* scratch, size_t scratch_bytes, hipStream_t stream, bool bf16x3);
 size_t bwd_scratch_bytes(const GnrProblem* p, int n_streams);
+int conv16_set_tile(int mt, int nt);        // gnr_conv16.hip
 
 static thread_local std::string g_err;
 // measurement hooks: process-wide on purpose (see include/gnr.h)
@@ -43,17 +44,9 @@ int fail(const char* fmt, ...) {
 
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
-bool chain16_enabled() {
-    static const bool on = [] {
-        const char* e = getenv("GNR_CHAIN32");
-        return !(e && e[0] == '1');
-    }();
-    return on;
-}
-
 int check_problem(const GnrProblem* p, int n_streams) {
     if (!p) return fail("gnr: problem is NULL");
-    // ABI 3 size handshake: a caller built against another header must not have its fields read at our offsets
+    // size handshake (since ABI 3): a caller built against another header must not have its fields read at our offsets
     if (p->struct_size != sizeof(GnrProblem))
         return fail("gnr: GnrProblem.struct_size is %u but this libgnr.so (ABI %d) has sizeof(GnrProblem) = %zu: the caller "
                     "was built against a different include/gnr.h (or did not set struct_size)", p->struct_size,
@@ -73,6 +66,8 @@ int check_problem(const GnrProblem* p, int n_streams) {
     // The view-direction columns are skipped by the chain kernels and come back as a per-ray bias (include/gnr.h): either
     // the caller supplies it for EVERY weight set, or for none -- then the library computes the embedding and the fold
     // itself (gnr_vd.hip).  One set with and one without would silently drop the columns of the latter.
+    for (int s = n_streams; s < 2; ++s)      // a stale pointer there would switch the device-side fold off for set 0 as well
+        if (p->ray_bias[s]) return fail("gnr: ray_bias[%d] is set but the call has %d weight set(s)", s, n_streams);
     if (p->vd_dims > 0) {
         int given = 0;
         for (int s = 0; s < n_streams; ++s) given += p->ray_bias[s] ? 1 : 0;
@@ -157,6 +152,13 @@ extern "C" {
 
 int gnr_abi_version(void) { return GNR_ABI_VERSION; }
 
+#ifndef GNR_BUILD_INFO          /* gazenerf_amd/build.py passes it; a hand-made build says so */
+#define GNR_BUILD_INFO "src=unknown;flags=;experimental=0"
+#endif
+const char* gnr_build_info(void) { return GNR_BUILD_INFO; }
+
+int gnr_set_conv16_tile(int row_tiles, int pixel_tiles) { return conv16_set_tile(row_tiles, pixel_tiles); }
+
 const char* gnr_last_error(void) { return g_err.c_str(); }
 
 size_t gnr_sizeof(int which) {
@@ -230,20 +232,18 @@ static int fwd_impl(const GnrProblem* p, const GnrWeights* face, const GnrWeight
     }
     // weights_packed: the caller vouches that the packed streams in this workspace are current (inference only)
     const bool reuse = p->weights_packed != 0 && !save;
-    const bool c16 = !bf16x3 && chain16_enabled();
-    launch_prep(*p, n_streams, ws_in, fp.ws, st, !bf16x3 && !reuse, c16);  // (the code-folded biases are always rebuilt)
+    launch_prep(*p, n_streams, ws_in, fp.ws, st, !bf16x3 && !reuse);  // (the code-folded biases are always rebuilt)
     if (bf16x3 && !reuse) launch_prep3(*p, n_streams, ws_in, fp.ws, st);
     stage_mark(GNR_STAGE_FWD_MLP, 0, st);
     if (bf16x3) launch_fwd3(fp, st);
-    else if (c16) launch_fwd16(fp, st);
-    else launch_fwd(fp, st);
+    else launch_fwd16(fp, st);
     stage_mark(GNR_STAGE_FWD_MLP, 1, st);
 
     CombineParams cp{};
     cp.prob = *p;
     cp.n_streams = n_streams;
-    cp.chunks_per_ray = c16 ? 2 * fp.chunks_per_ray : fp.chunks_per_ray;
-    cp.chunk_len = c16 ? 16 : CHUNK;
+    cp.chunks_per_ray = bf16x3 ? fp.chunks_per_ray : 2 * fp.chunks_per_ray;      // fp32: one partial per 16-sample sub-chunk
+    cp.chunk_len = bf16x3 ? CHUNK : 16;
     for (int s = 0; s < n_streams; ++s) {
         cp.part_feat[s] = fp.ws[s].part_feat;
         cp.part_sc[s] = fp.ws[s].part_sc;

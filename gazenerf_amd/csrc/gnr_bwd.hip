@@ -4,10 +4,10 @@
 //   1. gt_kernel          upstream d(feat_out) [B,C,N_r] -> row-major [ray][288]
 //   2. comp_bwd_kernel    CalcRayColor backward (utils/model_utils.py:498-534) per ray:
 //                         s_i = g . feat_i, w_i, dL/dsigma_raw_i, sum_i dL/ddelta_i * delta_i
-//   3. packT_kernel       W^T as MFMA A-fragments in the chain's k-order
-//   4. bwd_chain_kernel   register-chained dgrad through RGB2..L0 (same structure and FLOPs as the
-//                         forward kernel), ReLU masks from the saved activations, every layer's dY
-//                         dumped row-major for the weight gradients, d(encoding) -> d(pts) partials
+//   3. packT16_kernel     W^T as MFMA A-fragments in the chain's k-order            (gnr_bwd16.hip; bf16x3: gnr_bwd3.hip)
+//   4. bwd16_chain_kernel register-chained dgrad through RGB2..L0 (same structure and FLOPs as the
+//                         forward kernel), ReLU masks from the saved sign bits, every layer's dY
+//                         dumped chunk-channel-major for the weight gradients, d(encoding) -> d(pts) partials
 //   5. launch_wgrad x12   dW = dY^T X  (gnr_wgrad.hip), colsum for the biases
 //   6. latent_kernel      per-image bias sums -> d(shape,gaze,appea) and the latent columns of dW
 // Once per call: geo_kernel  d(pts), dL/dl partials -> dR, dT (GenSamplePoints backward).
@@ -32,36 +32,6 @@ void launch_vd_bwd(const GnrProblem& p, int n_streams, const GnrWeights* const* 
                    const float* embed, const VdBwdScratch& sc, bool want_dR, hipStream_t st);
 void launch_packT16(const PackTParams& pt, hipStream_t stream);
 void launch_bwd16_chain(const BwdParams& bp, hipStream_t stream);
-
-__global__ void packT_kernel(const PackTParams pp) {
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < PACKEDT_FLOATS;
-         e += (size_t)gridDim.x * blockDim.x) {
-        int l = 0;
-        size_t off = 0;
-        while (l + 1 < N_BL && e >= off + bl_floats(l)) { off += bl_floats(l); ++l; }
-        const size_t loc = e - off;
-        const int kt_n = bl_out_tiles(l);
-        const int sg = (int)(loc / ((size_t)kt_n * 256));
-        const int rem = (int)(loc % ((size_t)kt_n * 256));
-        const int kt = rem / 256, lane = (rem % 256) / 4, jj = rem % 4;
-        const int step = 4 * sg + jj, h = lane >> 5;
-        const int n = dlayout_channel(step, h);              // contraction index: forward output channel
-        const int krow = 32 * kt + (lane & 31);              // output row of this backward layer
-        int col = -1;
-        if (pp.enc[l]) {
-            // output rows follow the C/D layout of an encoding register file: row i' of tile t'
-            // belongs to lane-half h' = (i'>>2)&1, register r = (i'&3) + 4 (i'>>3)
-            const int tq = krow >> 5, iq = krow & 31;
-            const int hq = (iq >> 2) & 1, r = (iq & 3) + 4 * (iq >> 3);
-            col = enc_channel(16 * tq + r, hq);
-        } else if (krow < pp.k_valid[l]) {
-            col = pp.col0[l] + krow;
-        }
-        float v = 0.0f;
-        if (n < pp.n_valid[l] && col >= 0) v = pp.w[l][(size_t)n * pp.ld[l] + col];
-        pp.packed[e] = v;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // upstream gradient transpose: g[b][n][ray] -> gT[ray_g][288] (zero padded / zero when NULL)
@@ -215,110 +185,6 @@ __global__ __launch_bounds__(256) void comp_bwd_kernel(const CompBwdParams cp) {
         cp.csum[ray] = cp.accumulate ? cp.csum[ray] + cs : cs;
         cp.dsig_ray[ray] = dsum;
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// dgrad chain
-// ---------------------------------------------------------------------------------------------
-template <int NT>
-__device__ __forceinline__ void zero_tiles(f32x16 (&acc)[NT_H]) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-}
-
-__global__ __launch_bounds__(256, 1) void bwd_chain_kernel(const BwdParams bp) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, h = lane >> 5;
-    const long chunk = (long)blockIdx.x * WAVES_PER_WG + wave;
-    if (chunk >= bp.n_chunks) return;
-    const ClkProbe clk0 = clk_begin();
-    const long ray_g = chunk / bp.chunks_per_ray;
-    const long row = chunk * CHUNK + j;
-    const long M = bp.M;
-    WStream w;
-    wstream_init(w, bp.packedT, lane);
-    const float* enc_row = bp.enc + chunk * (CHUNK * ENC_PAD) + j;     // CCM: slot stride 32
-    f32x16 A[NT_H], Bv[NT_H];
-    float gx = 0.0f, gy = 0.0f, gz = 0.0f;
-
-    // d(feat_i) = w_i * g  (9 tiles) -> A
-    {
-        const float w = bp.wglob[row];
-        const float* gr = bp.gT + ray_g * FEAT_PAD + 4 * h;
-#pragma unroll
-        for (int t = 0; t < NT_F; ++t)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const f32x4 g4 = *(const f32x4*)(gr + 32 * t + 8 * rq);
-                A[t][4 * rq + 0] = w * g4.x; A[t][4 * rq + 1] = w * g4.y;
-                A[t][4 * rq + 2] = w * g4.z; A[t][4 * rq + 3] = w * g4.w;
-            }
-    }
-    unsigned mk[RELU_WORDS];
-    auto bits = [&](int layer) { return bp.relu_bits + relu_bits_offset(layer, bp.n_chunks, chunk); };
-    auto dyh = [&](int l) { return dump_ptr(bp.dY_h + l * M * H, H, chunk, j, h); };
-    // Each mm_h dumps ITS INPUT (the dY of the layer above) while its MFMAs run; accumulators start
-    // from an inline-zero C operand; the ReLU mask of each output tile is applied in the loop tail.
-#define GNR_MASK(X) [&](int t) { apply_relu_bits_tile(X[t], mk[t >> 1], t); }
-    // RGB2^T: A(9) -> Bv(6), mask y1 > 0            (dumps dfeat)
-    load_relu_bits<NT_H2>(mk, bits(8), lane);
-    mm_h<NT_F, NT_H2, true, true>(A, Bv, w, dump_ptr(bp.dfeat, FEAT_PAD, chunk, j, h), GNR_MASK(Bv));
-    // RGB1^T: Bv(6) -> A(12), no activation on y0   (dumps dY_r1)
-    mm_h<NT_H2, NT_H, true, true>(Bv, A, w, dump_ptr(bp.dY_r1, H2, chunk, j, h));
-    // RGB0^T: A -> Bv, + density head, mask h7      (dumps dY_r0)
-    load_relu_bits<NT_H>(mk, bits(7), lane);
-    {
-        const float ds = bp.dsig[row];
-        const float* wsg = bp.wsig + 4 * h;
-        mm_h<NT_H, NT_H, true, true>(A, Bv, w, dump_ptr(bp.dY_r0, H, chunk, j, h), [&](int t) {
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const f32x4 w4 = *(const f32x4*)(wsg + 32 * t + 8 * rq);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) Bv[t][4 * rq + e] = fmaf(w4[e], ds, Bv[t][4 * rq + e]);
-            }
-            apply_relu_bits_tile(Bv[t], mk[t >> 1], t);
-        });
-    }
-    // L7^T: Bv -> A mask h6 (dumps dY_7); L6^T: A -> Bv mask h5 (dumps dY_6)
-    load_relu_bits<NT_H>(mk, bits(6), lane);
-    mm_h<NT_H, NT_H, true, true>(Bv, A, w, dyh(7), GNR_MASK(A));
-    load_relu_bits<NT_H>(mk, bits(5), lane);
-    mm_h<NT_H, NT_H, true, true>(A, Bv, w, dyh(6), GNR_MASK(Bv));
-    // L5: encoding columns first (2 tiles, A is dead here; dumps dY_5), then the hidden columns -> A mask h4
-    mm_h<NT_H, 2, true, true>(Bv, A, w, dyh(5));
-    enc_backward(A, enc_row, h, gx, gy, gz);
-    load_relu_bits<NT_H>(mk, bits(4), lane);
-    mm_h<NT_H, NT_H, true, false>(Bv, A, w, nullptr, GNR_MASK(A));
-    // L4^T..L1^T (dump dY_4 .. dY_1)
-#pragma unroll 1
-    for (int rep = 0; rep < 2; ++rep) {
-        const int la = 3 - 2 * rep, lb = 2 - 2 * rep;      // outputs dY_3, dY_2 then dY_1, dY_0
-        load_relu_bits<NT_H>(mk, bits(la), lane);
-        mm_h<NT_H, NT_H, true, true>(A, Bv, w, dyh(la + 1), GNR_MASK(Bv));
-        load_relu_bits<NT_H>(mk, bits(lb), lane);
-        mm_h<NT_H, NT_H, true, true>(Bv, A, w, dyh(lb + 1), GNR_MASK(A));
-    }
-#undef GNR_MASK
-    // L0: encoding columns from dY_0 (in A; dumps dY_0)
-    mm_h<NT_H, 2, true, true>(A, Bv, w, dyh(0));
-    enc_backward(Bv, enc_row, h, gx, gy, gz);
-
-    // chunk partials for the geometry gradient: sum dpts, sum z * dpts
-    const float z = bp.zval[row];
-    const float sx = half_sum32(gx), sy = half_sum32(gy), sz = half_sum32(gz);
-    const float zx = half_sum32(gx * z), zy = half_sum32(gy * z), zz = half_sum32(gz * z);
-    if (lane == 0) {
-        float* gc = bp.geo_chunk + chunk * 8;
-        if (bp.accumulate_geo) {
-            gc[0] += sx; gc[1] += sy; gc[2] += sz; gc[3] += zx; gc[4] += zy; gc[5] += zz;
-        } else {
-            gc[0] = sx; gc[1] = sy; gc[2] = sz; gc[3] = zx; gc[4] = zy; gc[5] = zz; gc[6] = 0.0f; gc[7] = 0.0f;
-        }
-    }
-    clk_end(clk0, bp.clk);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -649,10 +515,8 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         setl(10, W.fea_w[1], Hh, Hh, 0, Hh, 0);
         setl(11, W.fea_w[0], vp, Hh, 0, ENC_PAD, 1);
         pt.packed = sc.packedT;
-        const bool c16 = !bf16x3 && chain16_enabled();
         if (bf16x3) launch_packT3(pt, st);
-        else if (c16) launch_packT16(pt, st);
-        else hipLaunchKernelGGL(packT_kernel, dim3(1024), dim3(256), 0, st, pt);
+        else launch_packT16(pt, st);
         // 4. dgrad chain
         BwdParams bp{};
         bp.prob = *p; bp.chunks_per_ray = cpr; bp.n_chunks = fp.n_chunks; bp.M = M;
@@ -664,11 +528,8 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         if (s == 0) stage_mark(GNR_STAGE_DGRAD, 0, st);
         if (bf16x3)
             launch_bwd3_chain(bp, st);
-        else if (c16)
-            launch_bwd16_chain(bp, st);
         else
-            hipLaunchKernelGGL(bwd_chain_kernel, dim3((unsigned)((fp.n_chunks + WAVES_PER_WG - 1) / WAVES_PER_WG)),
-                               dim3(256), 0, st, bp);
+            launch_bwd16_chain(bp, st);
         if (s == 0) stage_mark(GNR_STAGE_DGRAD, 1, st);
 
         // 5. weight gradients dW = dY^T X; the same kernels emit the per-image column sums of dY
@@ -723,7 +584,7 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
     // geometry: dR, dT
     if (dinz.R || dinz.T) {
         GeoParams gp{};
-        gp.prob = *p; gp.chunks_per_ray = (!bf16x3 && chain16_enabled()) ? 2 * cpr : cpr; gp.geo_chunk = sc.geo_chunk; gp.csum = sc.csum;
+        gp.prob = *p; gp.chunks_per_ray = bf16x3 ? cpr : 2 * cpr;   /* fp32 kernels: one partial per 16-sample sub-chunk */ gp.geo_chunk = sc.geo_chunk; gp.csum = sc.csum;
         gp.part = sc.geo_part; gp.blocks_per_image = sc.geo_blocks;
         hipLaunchKernelGGL(geo_kernel, dim3(sc.geo_blocks, p->batch), dim3(256), 0, st, gp);
         hipLaunchKernelGGL(geo_final_kernel, dim3(p->batch), dim3(64), 0, st, sc.geo_part, sc.geo_blocks, dinz.R, dinz.T,

@@ -50,6 +50,7 @@ struct Conv16Params {
     unsigned char* sign_out; long sign_batch;      // shuffle: bit e of byte (b, m/4, n) = (acc + bias > 0) of channel 4(m/4)+e
     int blur, H;                                   // B operand = blur(B) with reflect padding, image H x W (W above)
 };
-void launch_conv16(const Conv16Params& cp, hipStream_t st);
+int launch_conv16(const Conv16Params& cp, hipStream_t st);       // non-zero (+ gnr_last_error) when the plan names no instance
+int conv16_set_tile(int mt, int nt);                             // gnr_set_conv16_tile
 
 }  // namespace gnr

@@ -35,6 +35,7 @@
 // written; the backward uses blur's adjoint on the (half as wide) gradient instead (gnr_upsample.hip).
 #include "gnr_conv16.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -350,6 +351,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv16_kernel(const Conv16Params 
     }
 }
 
+std::atomic<int> g_forced_tile{0};          // 100 MT + NT, 0 = cost model (gnr_set_conv16_tile)
 struct Variant { int MT, NT; bool blur; };
 // (row tiles, pixel tiles) instances; blur: the instance that reads B through the stencil exists (register budget)
 // (ties in the cost model go to the earlier entry: the smaller tiles, which measured equal or better -- DESIGN.md 3.5)
@@ -368,16 +370,25 @@ void launch_variant_blur(const Conv16Params& cp, unsigned blocks, hipStream_t st
 
 }  // namespace
 
+int conv16_set_tile(int mt, int nt) {
+    if (mt == 0 && nt == 0) { g_forced_tile = 0; return 0; }
+    for (const Variant& v : kVariants)
+        if (v.MT == mt && v.NT == nt) { g_forced_tile = 100 * mt + nt; return 0; }
+    return fail("gnr_set_conv16_tile: no GEMM instance with %d row tiles x %d pixel tiles (have 2x4, 4x4, 8x4, 9x2, 11x2, 13x2; "
+                "0, 0 restores the cost model)", mt, nt);
+}
+
 Conv16Plan conv16_plan(int M, int K, long pixels_total, int blur_w) {
     const int tiles = (M + 15) / 16;
     Conv16Plan best{};
     double best_cost = 0.0;
-    static const char* force = getenv("GNR_CONV16_FORCE");      // tuning: "MT,NT" for every GEMM that has the instance
-    int fmt = 0, fnt = 0;
-    if (force) sscanf(force, "%d,%d", &fmt, &fnt);
+    // tuning / test hook (gnr_set_conv16_tile): one (MT, NT) pair for every GEMM; blur-fused GEMMs whose forced pair has
+    // no stencil instance fall back to the separate stencil (MT == 0 on return), exactly as without the hook
+    const int forced = g_forced_tile.load();
+    const int fmt = forced / 100, fnt = forced % 100;
     for (const Variant& v : kVariants) {
         if (blur_w && (!v.blur || blur_w % (16 * v.NT))) continue;      // a wave's pixels must lie in one image row
-        if (fmt && (v.MT != fmt || v.NT != fnt) && !(blur_w && fmt > 9)) continue;
+        if (fmt && (v.MT != fmt || v.NT != fnt)) continue;
         const int slices = (tiles + v.MT - 1) / v.MT;
         const double waves = (double)slices * (double)(pixels_total / (16 * v.NT));
         // two waves share a SIMD's matrix pipe: below 1024 waves the chip is not full and a wave's length is the time
@@ -416,7 +427,7 @@ void launch_conv16_pack(const Conv16PackJobs& jobs, hipStream_t st) {
     hipLaunchKernelGGL(conv16_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, jobs);
 }
 
-void launch_conv16(const Conv16Params& cp, hipStream_t st) {
+int launch_conv16(const Conv16Params& cp, hipStream_t st) {
     const long items = (long)cp.batch * cp.P / (16 * WPB * cp.plan.NT) * cp.plan.slices;
     const unsigned blocks = (unsigned)(8 * ((items + 7) / 8));
     const int key = cp.plan.MT * 10 + cp.plan.NT;
@@ -427,8 +438,9 @@ void launch_conv16(const Conv16Params& cp, hipStream_t st) {
         case 84: launch_variant<8, 4>(cp, blocks, st); break;
         case 44: launch_variant_blur<4, 4>(cp, blocks, st); break;
         case 24: launch_variant_blur<2, 4>(cp, blocks, st); break;
-        default: fail("conv16: no instance for MT = %d, NT = %d", cp.plan.MT, cp.plan.NT);
+        default: return fail("conv16: no instance for MT = %d, NT = %d", cp.plan.MT, cp.plan.NT);
     }
+    return 0;
 }
 
 }  // namespace gnr

@@ -11,6 +11,17 @@
 //   * weights are pre-packed per layer into that k-order as MFMA A-fragments
 //     P[step/4][n_tile][lane][4] so that a wave's load is one contiguous 1 KiB float4 row.
 #pragma once
+// Timing-experiment switches (tools/ab_*.sh, tools/ablate_fwd3.sh): several of them give WRONG or incomplete results.  They
+// only compile in a build that declares itself experimental -- gazenerf_amd/build.py adds -DGNR_EXPERIMENTAL_BUILD whenever
+// extra flags are given, gnr_build_info() then reports them, and the Python binding refuses such a library unless asked.
+#if !defined(GNR_EXPERIMENTAL_BUILD) &&                                                                                     \
+    (defined(GNR_W_HOT) || defined(GNR_WG_HOT) || defined(GNR_NODUMP_TIMING) || defined(GNR_TEMPORAL_DUMP_TIMING) ||        \
+     defined(GNR_ABL16) || defined(GNR_C16_ABL) || defined(GNR_PIPE_ABL) || defined(GNR_TR_ABL) || defined(GNR_ABLATE) ||   \
+     defined(GNR_FWD16_BOTH_STREAMS) || defined(GNR_VOFF_STREAM) || defined(GNR_NO_DEPHASE) || defined(GNR_DUMP_BURST) ||   \
+     defined(GNR_WG_RIDERS) || defined(GNR_WG_NOPIPE) || defined(GNR_WG_NOIMG2W) || defined(GNR_WG_NO2W) ||                 \
+     defined(GNR_DUMP_BRANCH) || defined(GNR_DUMP_QUAD))
+#error "GNR_* timing switches need -DGNR_EXPERIMENTAL_BUILD (python -m gazenerf_amd.build adds it when GNR_EXTRA_HIPCC_FLAGS is set)"
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -52,11 +63,6 @@ __host__ __device__ constexpr size_t packed_offset(int l) {
 }
 constexpr size_t PACKED_FLOATS = packed_offset(N_CHAIN);   // 1 357 824 per stream
 
-// k-order of activations held in the C/D layout: step s = 16 t + r, lane-half h.
-__host__ __device__ inline int dlayout_channel(int step, int h) {
-    const int t = step >> 4, r = step & 15;
-    return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-}
 // k-order of the positional encoding (our choice; the packer matches it).  Returns the
 // reference channel (utils/model_utils.py:272-280 order) or -1 for the zero pad.
 //   step 0: h0 -> x, h1 -> y;  step 1: h0 -> z, h1 -> pad;
@@ -135,7 +141,7 @@ struct CombineParams {
 
 // host-side launchers (defined in the .hip translation units)
 void launch_prep(const GnrProblem& p, int n_streams, const GnrWeights* const* w, StreamWs* ws,
-                 hipStream_t stream, bool pack_fp32 = true, bool chain16 = true);
+                 hipStream_t stream, bool pack_fp32 = true);
 void launch_fwd16(const FwdParams& fp, hipStream_t stream);
 // gnr_vd.hip: the view-direction option computed by the library (vd_dims > 0, no caller-supplied ray_bias)
 bool vd_on_device(const GnrProblem* p);
@@ -143,12 +149,9 @@ int vd_check(const GnrProblem* p);
 size_t vd_fwd_floats(const GnrProblem* p, int n_streams);
 void vd_carve_fwd(const GnrProblem* p, int n_streams, float* base, float** embed, float** rb);
 void launch_vd_fwd(const GnrProblem& p, int n_streams, const GnrWeights* const* w, float* embed, float* const* rb, hipStream_t st);
-bool chain16_enabled();        // gnr_api.hip: the fp32 chain runs on 16x16x4 tiles, two waves per SIMD (default) -- or,
-                               // with GNR_CHAIN32=1 in the environment, on round 2's 32x32x2 kernels (A/B timing)
 void launch_prep3(const GnrProblem& p, int n_streams, const GnrWeights* const* w, StreamWs* ws,
                   hipStream_t stream);
 void launch_fwd3(const FwdParams& fp, hipStream_t stream);
-void launch_fwd(const FwdParams& fp, hipStream_t stream);
 void launch_combine(const CombineParams& cp, hipStream_t stream);
 
 }  // namespace gnr

@@ -1,5 +1,5 @@
 // gnr_prep.hip -- small memory-bound kernels around the fused MLP kernel (gfx950):
-//   pack_kernel      weights [out,in] -> MFMA A-fragment stream in the chain's k-order
+//   pack16_kernel    weights [out,in] -> MFMA A-fragment stream in the chain's k-order
 //   bias_kernel      per-image biases with the latent codes folded in (models/gaze_nerf.py:136-143:
 //                    181 of layer-0/5 inputs and 127 of RGB_layer_1 inputs are per-image constants)
 //   combine_kernel   chunk partials -> CalcRayColor outputs (utils/model_utils.py:516-534),
@@ -19,34 +19,8 @@ struct PackParams {
     float* packed;
 };
 
-__global__ void pack_kernel(const PackParams pp) {
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < PACKED_FLOATS;
-         e += (size_t)gridDim.x * blockDim.x) {
-        int l = 0;
-        size_t off = 0;
-        while (l + 1 < N_CHAIN && e >= off + layer_packed_floats(l)) { off += layer_packed_floats(l); ++l; }
-        const size_t loc = e - off;
-        const int nt_n = layer_nt(l);
-        const int sg = (int)(loc / ((size_t)nt_n * 256));
-        const int rem = (int)(loc % ((size_t)nt_n * 256));
-        const int nt = rem / 256, lane = (rem % 256) / 4, jj = rem % 4;
-        const int step = 4 * sg + jj, h = lane >> 5, n = 32 * nt + (lane & 31);
-        const int es = layer_enc_steps(l);
-        int col = -1;
-        if (step < es) {
-            col = enc_channel(step, h);                       // encoding occupies source columns 0..62
-        } else {
-            const int k = dlayout_channel(step - es, h);
-            if (k < pp.kh[l]) col = pp.hcol[l] + k;
-        }
-        float v = 0.0f;
-        if (n < pp.n_out[l] && col >= 0) v = pp.w[l][(size_t)n * pp.ld[l] + col];
-        pp.packed[e] = v;
-    }
-}
-
-// The same stream for the 16x16x4 chain (gnr_chain16.h): rows (k-group of 16 input channels, n-tile of 16 outputs),
-// lane l = (output row l&15, k = l>>4), component e = k-step.  Same number of floats per layer.
+// The weight stream of the 16x16x4 chain (gnr_chain16.h): rows (k-group of 16 input channels, n-tile of 16 outputs),
+// lane l = (output row l&15, k = l>>4), component e = k-step.
 __global__ void pack16_kernel(const PackParams pp) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < PACKED_FLOATS;
          e += (size_t)gridDim.x * blockDim.x) {
@@ -132,7 +106,7 @@ __global__ void bias_kernel(const BiasParams bp) {
 }
 
 void launch_prep(const GnrProblem& p, int n_streams, const GnrWeights* const* w, StreamWs* ws,
-                 hipStream_t stream, bool pack_fp32, bool chain16) {
+                 hipStream_t stream, bool pack_fp32) {
     const int vp = ENC_CH + p.shape_dims + p.gaze_dims;
     const int Hh = p.hidden, Hh2 = Hh / 2;      // the network's own width; rows / columns beyond it are packed as zeros
     for (int s = 0; s < n_streams; ++s) {
@@ -153,8 +127,7 @@ void launch_prep(const GnrProblem& p, int n_streams, const GnrWeights* const* w,
             }
         }
         pp.packed = ws[s].packed;
-        if (pack_fp32 && chain16) hipLaunchKernelGGL(pack16_kernel, dim3(1024), dim3(256), 0, stream, pp);
-        else if (pack_fp32) hipLaunchKernelGGL(pack_kernel, dim3(1024), dim3(256), 0, stream, pp);
+        if (pack_fp32) hipLaunchKernelGGL(pack16_kernel, dim3(1024), dim3(256), 0, stream, pp);
         BiasParams bp;
         bp.prob = p; bp.w = *w[s]; bp.bias = ws[s].bias; bp.wsig = ws[s].wsig;
         hipLaunchKernelGGL(bias_kernel, dim3(N_CHAIN, p.batch), dim3(H), 0, stream, bp);

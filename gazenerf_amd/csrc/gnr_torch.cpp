@@ -30,7 +30,7 @@ void check_f32(const Tensor& t, const char* name, const c10::Device& dev) {
 }
 
 struct Problem {
-    GnrProblem c = GNR_INIT_PROBLEM;   // zeroed + struct_size stamped (ABI 3 size handshake)
+    GnrProblem c = GNR_INIT_PROBLEM;   // zeroed + struct_size stamped (size handshake)
     std::vector<Tensor> keep;          // contiguous versions the pointers refer to
     int64_t B = 0, n_r = 0, n_p = 0;
     c10::Device dev{c10::kCPU};
@@ -263,6 +263,11 @@ int64_t saved_workspace_bytes(int64_t batch, int64_t n_rays, int64_t n_samples, 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "PyTorch-ROCm C++ binding of libgnr.so (GazeNeRF volumetric hot path on MI355X)";
     m.def("abi_version", []() { return gnr_abi_version(); });
+#ifndef GNR_SOURCE_HASH
+#define GNR_SOURCE_HASH "unknown"
+#endif
+    m.def("source_hash", []() { return std::string(GNR_SOURCE_HASH); }, "hash of csrc/ + include/gnr.h this binding was built from");
+    m.def("build_info", []() { return std::string(gnr_build_info()); }, "gnr_build_info() of the libgnr.so it is linked to");
     m.def("render_fwd", &render_fwd, "gnr_fwd / gnr_fwd_bf16x3 on the current HIP stream");
     m.def("render_bwd", &render_bwd, "gnr_bwd / gnr_bwd_bf16x3 on the current HIP stream");
     m.def("saved_workspace_bytes", &saved_workspace_bytes, "bytes of saved activations for a training forward of this size");

@@ -606,7 +606,7 @@ struct UpSaved {                        // kept for the backward
     float* a1[UP_MAX];                  // [B][2C][P]
     unsigned char* sign2[UP_MAX];       // [B][C][P]    four pre-activation sign bits per (out-channel quad, pixel)
     float* pack;                        // packed A operands of every GEMM of the call in flight (forward, then backward)
-    float* u[UP_MAX];                   // [B][C][4P]   shuffled map (pre-blur); the backward re-uses it as d(net) once consumed
+    float* u[UP_MAX];                   // [B][C][4P]   shuffled map (pre-blur): read by the backward's dWf GEMM, never written by it
     float* net[UP_MAX];                 // [B][C'][4P]  block output
     float* img;                         // [B][3][Pn]
     float* vtmp;                        // [B][C][4P]   blurred map, only for blocks whose feat GEMM cannot blur on the fly
@@ -641,6 +641,8 @@ static size_t up_carve(const GnrUpsampleProblem* p, const UpDims& d, char* base,
 
 struct UpScratch {                      // backward temporaries
     float* g0; float* g1;               // two buffers of the largest activation size
+    float* g2;                          // same size: d(net) alternates between g2 and g1, so the
+                                        // saved forward state stays intact and a second backward (retain_graph) is valid
     float* drgb_a; float* drgb_b;       // [B][3][Pn]
     float* colsum;                      // [B][max M]
     float* wg;                          // wgrad partial tiles
@@ -661,6 +663,7 @@ static size_t up_carve_bwd(const GnrUpsampleProblem* p, const UpDims& d, char* b
     UpScratch z{};
     z.g0 = (float*)take(big);
     z.g1 = (float*)take(big);
+    z.g2 = (float*)take(big);        // d(net) of block i+1 becomes block i's X (dhid, du, dpre1: up to 4 C P floats)
     z.drgb_a = (float*)take(B * 3 * Pn * 4);
     z.drgb_b = (float*)take(B * 3 * Pn * 4);
     size_t cs_floats = B * (size_t)(mmax + 128);
@@ -747,13 +750,13 @@ int gnr_upsample_fwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, f
         // a1 = lrelu(W1 net + b1)
         g.plan = bp[i].c1; g.At = s.pack + bp[i].o1; g.B = net; g.b_batch = (long)C * P; g.C = s.a1[i]; g.c_batch = 2L * C * P;
         g.M = 2 * C; g.K = C; g.P = (int)P; g.batch = B; g.bias = w->up1_b[i]; g.leaky = 1;
-        launch_conv16(g, st);
+        if (launch_conv16(g, st)) return 1;
         // u = pixel_shuffle(lrelu(W2 a1 + b2) + repeat(net))
         g = Conv16Params{};
         g.plan = bp[i].c2; g.At = s.pack + bp[i].o2; g.B = s.a1[i]; g.b_batch = 2L * C * P; g.C = s.u[i]; g.c_batch = 4L * C * P;
         g.M = 4 * C; g.K = 2 * C; g.P = (int)P; g.batch = B; g.bias = w->up2_b[i]; g.leaky = 1; g.shuffle = 1; g.W = S;
         g.res = net; g.res_batch = (long)C * P; g.sign_out = s.sign2[i]; g.sign_batch = (long)C * P;
-        launch_conv16(g, st);
+        if (launch_conv16(g, st)) return 1;
         // net' = lrelu(Wf blur(u) + bf): the stencil inside the GEMM's operand load, or as its own kernel
         g = Conv16Params{};
         g.plan = bp[i].c3; g.At = s.pack + bp[i].o3; g.B = s.u[i]; g.b_batch = 4L * C * P; g.C = s.net[i]; g.c_batch = 4L * Cn * P;
@@ -765,7 +768,7 @@ int gnr_upsample_fwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, f
                                2 * S, 0);
             g.B = s.vtmp;
         }
-        launch_conv16(g, st);
+        if (launch_conv16(g, st)) return 1;
         // rgb += conv_rgb(i+1)(net');  last block: img = sigmoid(rgb) (or rgb itself), also straight into the caller's image
         const bool last = i == d.n_blocks - 1;
         hipLaunchKernelGGL(rgb_conv_kernel, dim3(blocks_for((long)B * 4 * P)), dim3(256), 0, st, s.net[i], Cn, 4 * P, B,
@@ -860,10 +863,12 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
         Conv16Params g{};
         g.plan = bp[i].c3; g.At = s.pack + bp[i].o3; g.B = Y; g.b_batch = (long)Cn * P4; g.C = X; g.c_batch = (long)C * P4;
         g.M = C; g.K = Cn; g.P = (int)P4; g.batch = B;
-        launch_conv16(g, st);                                                    // X = du
-        // un-shuffle: dpre2 (-> Y) and the residual part of d(net_in): into u[i]'s buffer, which nothing reads any more
-        // (block 0: straight into the caller's d_x)
-        float* dnet = (i == 0 && d_x) ? d_x : s.u[i];
+        if (launch_conv16(g, st)) return 1;                                      // X = du
+        // un-shuffle: dpre2 (-> Y) and the residual part of d(net_in) into backward scratch (block 0: straight into the
+        // caller's d_x).  X is g0 (last block) or the previous d(net), Y the other of g0 / g1: d(net) takes g2, g1, g2, ...
+        // -- never a buffer of the saved forward workspace (round 3 wrote it over u[i], which made a second backward over
+        // the same saved state wrong).
+        float* dnet = (i == 0 && d_x) ? d_x : (((nb - 1 - i) & 1) ? t.g1 : t.g2);
         if (C % 4 == 0)
             hipLaunchKernelGGL(unshuffle_bwd4_kernel, dim3(blocks_for((long)B * (C / 4) * (P / 4))), dim3(256), 0, st, X, s.sign2[i], C, S, S,
                                B, Y, dnet);
@@ -875,13 +880,13 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
         g = Conv16Params{};
         g.plan = bp[i].c2; g.At = s.pack + bp[i].o2; g.B = Y; g.b_batch = 4L * C * P; g.C = X; g.c_batch = 2L * C * P;
         g.M = 2 * C; g.K = 4 * C; g.P = (int)P; g.batch = B; g.mask_ref = s.a1[i]; g.mask_batch = 2L * C * P;
-        launch_conv16(g, st);
+        if (launch_conv16(g, st)) return 1;
         // layer_1: dW1 = dpre1 net_in^T, db1; dnet += W1^T dpre1
         launch_wgrad_img(X, 2 * C, 2 * C, net_in, C, C, B, P, G.up1_w[i], C, G.up1_b[i], 0, t.wg, st);
         g = Conv16Params{};
         g.plan = bp[i].c1; g.At = s.pack + bp[i].o1; g.B = X; g.b_batch = 2L * C * P; g.C = dnet; g.c_batch = (long)C * P;
         g.M = C; g.K = 2 * C; g.P = (int)P; g.batch = B; g.accumulate = 1;
-        launch_conv16(g, st);
+        if (launch_conv16(g, st)) return 1;
         dnet_next = dnet;             // block i-1's dhid accumulates into it (its Cn x 4P' is this C x P)
     }
     // rgb_0 = up(conv_rgb0(x)): adjoint of up at side S0 -> 2 S0, then the conv

@@ -20,7 +20,10 @@
  *   - every pointer is a DEVICE pointer to fp32 unless stated; tensors are contiguous, row-major,
  *     in the reference's own layouts (channels-first outputs [B, C, N_r]);
  *   - the caller owns every buffer, including the workspace; the library allocates nothing and
- *     keeps no state between calls (safe for several modules / devices per process);
+ *     keeps no state between calls (safe for several modules / devices per process).  Which kernels run depends on the
+ *     arguments alone: the library reads NO environment variable (until round 3 GNR_CHAIN32 / GNR_CONV16_FORCE selected
+ *     kernels behind the caller's back; the first is gone with the kernels it selected, the second is the explicit
+ *     gnr_set_conv16_tile below).  The only process-wide state are the hooks declared next to gnr_set_kernel_timing;
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no host synchronisation;
  *   - every function returns 0 on success, non-zero on error; gnr_last_error() then describes it
  *     (thread-local).  Bindings turn that into an exception so the reference's
@@ -43,7 +46,7 @@
 extern "C" {
 #endif
 
-#define GNR_ABI_VERSION 3
+#define GNR_ABI_VERSION 4
 #define GNR_N_TRUNK 8          /* FeaExt_module_0..7   (models/mlp_nerf.py:29-58)  */
 #define GNR_N_RGB 3            /* RGB_layer_0..2       (models/mlp_nerf.py:68-93)  */
 
@@ -230,7 +233,8 @@ int gnr_sample_zvals(const GnrProblem* p, float* zvals_out, void* stream);
  * hipEvent_t (passed as void*) on their stream immediately before / after the dominant kernel of
  * the call (the fused MLP kernel in gnr_fwd; the dgrad-chain kernel of the first weight set in
  * gnr_bwd), so a harness can time that kernel alone.  Pass NULLs to switch it off (the default).
- * This is the only process-wide state in the library; it never affects results. */
+ * The hooks of this family (and gnr_set_conv16_tile) are the only process-wide state in the library; the timing hooks never
+ * affect results. */
 int gnr_set_kernel_timing(void* ev_start, void* ev_stop);
 
 /* The same hook per stage (ABI 2): records the event pair around
@@ -322,6 +326,21 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
                      size_t scratch_bytes, void* stream);
 
 const char* gnr_last_error(void);
+
+/* ABI 4.  What this binary was built from: "src=<16 hex digits: sha256 over gazenerf_amd/csrc/{*.hip,*.h,*.cpp} and this
+ * header, in name order>;flags=<extra -D switches of a timing-experiment build, with the files they applied to>;
+ * experimental=<0|1>".  The binaries are not under version control (they travel to the GPU box prebuilt): a binding
+ * recomputes the hash from the tree it runs in and refuses a library built from other sources, or an experimental build
+ * (gazenerf_amd/_lib.py does both).  Timing switches that change results only compile with -DGNR_EXPERIMENTAL_BUILD
+ * (gazenerf_amd/csrc/gnr_internal.h), which `python -m gazenerf_amd.build` adds -- and reports here -- whenever extra flags
+ * are given. */
+const char* gnr_build_info(void);
+
+/* ABI 4.  Tuning / test hook (process-wide like the timing hooks; results are the same to rounding for every choice): pin the
+ * (row tiles, pixel tiles) instance of the upsampler's 1x1-convolution GEMMs -- 2x4, 4x4, 8x4, 9x2, 11x2, 13x2 -- instead of
+ * the cost model's choice per GEMM; (0, 0) restores the cost model.  A pair without an instance is an error.  The blur-fused
+ * feat_layers GEMM exists for 2x4, 4x4, 9x2; with another pair pinned the stencil runs as its own kernel. */
+int gnr_set_conv16_tile(int row_tiles, int pixel_tiles);
 
 #ifdef __cplusplus
 }

@@ -38,8 +38,59 @@ def test_binding_matches_header(lib_built):
     assert ctypes.sizeof(_lib.GnrMergeProblem) == 16 + 6 * 8        # struct_size + 3 ints + 6 pointers
 
 
+def test_build_info_ties_the_binary_to_the_tree(lib_built, monkeypatch):
+    """VERDICT round 3 (items 3, 11): the binaries are git-ignored and travel prebuilt, so the library says what it was
+    built from and the binding refuses (a) a library built from other sources than the tree's, (b) a timing-experiment
+    build -- unless GNR_ALLOW_EXPERIMENTAL_LIB=1, which only the A/B scripts under tools/ set."""
+    import pytest
+    from gazenerf_amd import _lib, _srchash
+    lib = _lib.load()
+    info = lib.gnr_build_info().decode()
+    bi = _lib.parse_build_info(info)
+    assert bi["src"] == _srchash.source_hash() and len(bi["src"]) == 16
+    assert bi["experimental"] == "0" and bi["flags"] == ""
+    assert _lib.build_info() == info
+    _lib.check_build_info(info, "libgnr.so")                                   # the real one passes
+    with pytest.raises(RuntimeError, match="built from other sources"):
+        _lib.check_build_info("src=0123456789abcdef;flags=;experimental=0", "libgnr.so")
+    with pytest.raises(RuntimeError, match="built from other sources"):
+        _lib.check_build_info("src=unknown;flags=;experimental=0", "libgnr.so")     # a hand-made build
+    exp = "src=%s;flags=-DGNR_W_HOT=1@gnr_fwd16.hip;experimental=1" % bi["src"]
+    monkeypatch.delenv("GNR_ALLOW_EXPERIMENTAL_LIB", raising=False)
+    with pytest.raises(RuntimeError, match="timing-experiment build"):
+        _lib.check_build_info(exp, "libgnr.so")
+    monkeypatch.setenv("GNR_ALLOW_EXPERIMENTAL_LIB", "1")
+    _lib.check_build_info(exp, "libgnr.so")                                    # admitted, with a warning on stderr
+    # every source file is in the hash: touching one byte of any of them changes it
+    files = _srchash.source_files()
+    assert any(f.endswith("gnr_fwd16.hip") for f in files) and any(f.endswith("gnr.h") for f in files)
+    assert any(f.endswith("gnr_torch.cpp") for f in files)
+
+
+def test_timing_switches_do_not_compile_without_the_experimental_macro(tmp_path):
+    """csrc/gnr_internal.h: a wrong-results switch (here GNR_W_HOT) is a compile error unless the build declares itself
+    experimental -- which build.py does, and reports in gnr_build_info(), whenever extra flags are given."""
+    import subprocess
+    src = os.path.join(ROOT, "gazenerf_amd", "csrc", "gnr_prep.hip")
+    base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-DGNR_W_HOT=1"]
+    r = subprocess.run(base + [src], capture_output=True, text=True)
+    assert r.returncode != 0 and "GNR_EXPERIMENTAL_BUILD" in r.stderr
+    r = subprocess.run(base + ["-DGNR_EXPERIMENTAL_BUILD=1", src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_the_library_reads_no_environment_variable(lib_built):
+    """include/gnr.h: which kernels run depends on the arguments alone (GNR_CHAIN32 / GNR_CONV16_FORCE are gone)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--undefined-only", lib_built], capture_output=True, text=True).stdout
+    assert "getenv" not in out
+    for name in os.listdir(os.path.join(ROOT, "gazenerf_amd", "csrc")):
+        if name.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(ROOT, "gazenerf_amd", "csrc", name)).read(), name
+
+
 def test_struct_size_handshake(lib_built):
-    """ABI 3: every entry point that takes a descriptor struct refuses one whose struct_size is not the library's
+    """Since ABI 3: every entry point that takes a descriptor struct refuses one whose struct_size is not the library's
     sizeof -- a binder compiled against another header gets an error, never fields read at the wrong offsets."""
     from gazenerf_amd import _lib
     lib = _lib.load()

@@ -141,51 +141,67 @@ def test_hip_vs_oracle_live(feat_nc, side, img, min_feat, batch):
         assert _rel_l2(dp[k].cpu(), pg[k].grad) <= 1e-3, k
 
 
-_FORCE_SCRIPT = r"""
-import sys, numpy as np, torch
-sys.path.insert(0, sys.argv[1])
-from gazenerf_amd import neural_render, synth
-dev = torch.device("cuda:0")
-out = {}
-for tag, (feat_nc, side, nb, mf, batch) in {"a": (258, 64, 1, 32, 1), "b": (64, 32, 2, 16, 2)}.items():
-    params = synth.hash_renderer_params(seed=5, feat_nc=feat_nc, n_blocks=nb, min_feat=mf, weight_scale=2.0)
-    x = synth.synth_featmap(batch, feat_nc, side, seed=2).to(dev).requires_grad_(True)
-    pg = {k: v.to(dev).clone().requires_grad_(True) for k, v in params.items()}
-    img = neural_render(x, pg, n_blocks=nb, min_feat=mf)
-    w = torch.linspace(0.5, 1.5, img.numel(), device=dev).reshape(img.shape)
-    (img * w).sum().backward()
-    out[tag + "_img"] = img.detach().cpu().numpy(); out[tag + "_dx"] = x.grad.cpu().numpy()
-    for k, v in pg.items():
-        out[tag + "_" + k] = v.grad.cpu().numpy()
-np.savez(sys.argv[2], **out)
-"""
+def _variant_run(dev):
+    out = {}
+    for tag, (feat_nc, side, nb, mf, batch) in {"a": (258, 64, 1, 32, 1), "b": (64, 32, 2, 16, 2)}.items():
+        params = synth.hash_renderer_params(seed=5, feat_nc=feat_nc, n_blocks=nb, min_feat=mf, weight_scale=2.0)
+        x = synth.synth_featmap(batch, feat_nc, side, seed=2).to(dev).requires_grad_(True)
+        pg = {k: v.to(dev).clone().requires_grad_(True) for k, v in params.items()}
+        from gazenerf_amd import neural_render
+        img = neural_render(x, pg, n_blocks=nb, min_feat=mf)
+        w = torch.linspace(0.5, 1.5, img.numel(), device=dev).reshape(img.shape)
+        (img * w).sum().backward()
+        out[tag + "_img"] = img.detach().cpu().numpy(); out[tag + "_dx"] = x.grad.cpu().numpy()
+        for k, v in pg.items():
+            out[tag + "_" + k] = v.grad.cpu().numpy()
+    return out
 
 
 @pytest.mark.gpu
-def test_every_gemm_tile_variant_gives_the_same_result(tmp_path):
-    """conv16_plan picks one of six (row tiles, pixel tiles) instances per GEMM; GNR_CONV16_FORCE pins one for every GEMM
-    that has it (the library reads the variable once per process, hence the subprocesses).  (8,4), (11,2), (13,2) have no
-    blur instance: forcing them also runs the separate-stencil fallback of feat_layers.  All must agree with the cost
-    model's choice to rounding (different tiles sum the contraction in the same k order: identical up to the blur path)."""
-    import os, subprocess, sys
-    from conftest import ROOT
+def test_every_gemm_tile_variant_gives_the_same_result():
+    """conv16_plan picks one of six (row tiles, pixel tiles) instances per GEMM; gnr_set_conv16_tile (an explicit hook of the
+    C ABI -- until round 3 an environment variable the library read behind the caller's back) pins one for every GEMM.
+    (8,4), (11,2), (13,2) have no blur instance: pinning them also runs the separate-stencil fallback of feat_layers.  All
+    must agree with the cost model's choice to rounding (different tiles sum the contraction in the same k order:
+    identical up to the blur path); a pair without an instance is rejected."""
+    from gazenerf_amd import _lib
+    lib = _lib.load()
+    dev = _dev()
     res = {}
-    for force in ("", "13,2", "11,2", "9,2", "8,4", "4,4", "2,4"):
-        env = dict(os.environ)
-        env.pop("GNR_CONV16_FORCE", None)
-        if force:
-            env["GNR_CONV16_FORCE"] = force
-        path = str(tmp_path / ("v_%s.npz" % force.replace(",", "_")))
-        r = subprocess.run([sys.executable, "-c", _FORCE_SCRIPT, ROOT, path], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        res[force] = dict(np.load(path))
-    base = res[""]
+    try:
+        for force in ((0, 0), (13, 2), (11, 2), (9, 2), (8, 4), (4, 4), (2, 4)):
+            _lib.check(lib.gnr_set_conv16_tile(*force))
+            res[force] = _variant_run(dev)
+        assert lib.gnr_set_conv16_tile(3, 3) != 0 and b"no GEMM instance" in lib.gnr_last_error()
+    finally:
+        lib.gnr_set_conv16_tile(0, 0)
+    base = res[(0, 0)]
     for force, got in res.items():
         for k, v in base.items():
             if k.endswith("_img"):
                 assert float(np.abs(got[k] - v).max()) <= 2e-6, (force, k)
             else:
                 assert float(np.linalg.norm(got[k] - v)) <= 2e-5 * float(np.linalg.norm(v)) + 1e-12, (force, k)
+
+
+@pytest.mark.gpu
+def test_second_backward_over_the_same_saved_state_is_identical():
+    """gnr_upsample_bwd used to write d(net) over the saved pre-blur map u[i] (which its own dWf GEMM
+    reads), so `backward(retain_graph=True)` followed by a second backward silently gave wrong feat_layers gradients.  d(net)
+    now lives in backward scratch: two backwards over one forward are bit-identical."""
+    from gazenerf_amd import neural_render
+    dev = _dev()
+    params = synth.hash_renderer_params(seed=7, feat_nc=64, n_blocks=2, min_feat=16, weight_scale=2.0)
+    x = synth.synth_featmap(2, 64, 32, seed=3).to(dev).requires_grad_(True)
+    pg = {k: v.to(dev).clone().requires_grad_(True) for k, v in params.items()}
+    img = neural_render(x, pg, n_blocks=2, min_feat=16)
+    w = torch.linspace(0.5, 1.5, img.numel(), device=dev).reshape(img.shape)
+    loss = (img * w).sum()
+    leaves = [x] + list(pg.values())
+    g1 = torch.autograd.grad(loss, leaves, retain_graph=True)
+    g2 = torch.autograd.grad(loss, leaves)
+    for name, a, b in zip(["x"] + list(pg.keys()), g1, g2):
+        assert torch.equal(a, b), name
 
 
 @pytest.mark.gpu

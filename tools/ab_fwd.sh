@@ -1,6 +1,7 @@
 #!/bin/bash
 # like ab_variants.sh but prints only the forward stage; usage: tools/ab_fwd.sh <tag> "<flags>"
 set -u
+export GNR_ALLOW_EXPERIMENTAL_LIB=1      # _lib.load() refuses a library built with timing switches otherwise
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=$1; FLAGSX=$2
 mkdir -p $R/gpurun_out/ab

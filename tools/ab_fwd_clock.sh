@@ -1,6 +1,7 @@
 #!/bin/bash
 # like ab_fwd.sh, 10 steps, prints stage times WITH the in-kernel clock probe; usage: tools/ab_fwd_clock.sh <tag> "<flags>"
 set -u
+export GNR_ALLOW_EXPERIMENTAL_LIB=1      # _lib.load() refuses a library built with timing switches otherwise
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=$1; FLAGSX=$2
 mkdir -p $R/gpurun_out/ab

@@ -3,6 +3,7 @@
 # the upsampler forward at B = 7 under the kernel trace, keep the conv16 launch times.
 # usage: tools/ab_n1.sh <tag> "<flags>" [n1_trace.py args]
 set -u
+export GNR_ALLOW_EXPERIMENTAL_LIB=1      # _lib.load() refuses a library built with timing switches otherwise
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=$1; FLAGSX=$2; shift 2
 mkdir -p $R/gpurun_out/ab

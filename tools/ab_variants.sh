@@ -2,6 +2,7 @@
 # Timing experiments on the GPU box: rebuild the named kernels with extra -D switches, run the bench once, keep its line.
 # usage: tools/ab_variants.sh <tag> "<files,comma>" "<flags>" [bench args]      (results may be WRONG with timing switches)
 set -u
+export GNR_ALLOW_EXPERIMENTAL_LIB=1      # _lib.load() refuses a library built with timing switches otherwise
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=$1; FILES=$2; FLAGSX=$3; shift 3
 mkdir -p $R/gpurun_out/ab

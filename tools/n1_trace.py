@@ -23,6 +23,10 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
+    tile = os.environ.get("N1_CONV16_TILE")                     # tools/n1_sweep.sh: pin one GEMM instance ("MT,NT")
+    if tile:
+        from gazenerf_amd import _lib
+        _lib.check(_lib.load().gnr_set_conv16_tile(*[int(v) for v in tile.split(",")]))
     net = NeuralRendererAMD().to(dev)
     x = torch.randn(a.batch, 258, 64, 64, device=dev, requires_grad=not a.fwd_only)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
