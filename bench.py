@@ -47,6 +47,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3                 # MI355X_MICROARCH.md chip-level p
 # bf16x3: three bf16 MFMAs per fp32-equivalent product -> a third of the 16x fp32 rate (dense bf16 peak / 3)
 PEAK_BF16X3_TFLOPS = 16.0 * PEAK_FP32_MFMA_TFLOPS / 3.0
 HBM_PEAK_GBS = 8000.0
+HBM_STREAM_GBS = 6290.0                       # measured float4 copy on MI355X (same table): what a streaming kernel can reach
 PEAK_CLOCK_MHZ = 2400.0                       # the clock both MFMA peaks are quoted at
 # the weight-gradient stage: its main kernel instance first (the 384^2 layers), then what else runs inside the bracket
 WGRAD_KERNEL = {False: "gnr::wgrad2w_kernel<false, false> + its other instances + gnr::wgrad_pipe_kernel<3, 1, false, 2> + gnr::wgrad_reduce_kernel",
@@ -74,6 +75,9 @@ def parse():
     ap.add_argument("--gather", action="store_true", help="strong scaling, fwd: all_gather the feature maps to every rank inside the step")
     ap.add_argument("--no-one-call", action="store_true", help="skip the extra timing of the one-call (in-op tiled) training path")
     ap.add_argument("--pg-timeout", type=float, default=180.0, help="seconds before a stuck rendezvous / collective aborts")
+    ap.add_argument("--force-dist", action="store_true", default=os.environ.get("GNR_BENCH_FORCE_DIST", "") == "1",
+                    help="--gpus 1: form a ONE-rank RCCL process group anyway and run the gradient exchange through it "
+                         "(loads librccl, creates a communicator, exercises the stream hand-off on a single GPU)")
     return ap.parse_args()
 
 
@@ -208,10 +212,8 @@ def mean(xs):
 
 def chain_suffix(x3):
     """Kernel-name infix of the dense-chain kernels: bf16x3 -> "3"; fp32 -> "16" (v_mfma_f32_16x16x4_f32, two waves per
-    SIMD: gnr_chain16.h) unless GNR_CHAIN32=1 selects round 2's 32x32x2 kernels."""
-    if x3:
-        return "3"
-    return "" if os.environ.get("GNR_CHAIN32", "")[:1] == "1" else "16"
+    SIMD: gnr_chain16.h)."""
+    return "3" if x3 else "16"
 
 
 def main():
@@ -240,11 +242,15 @@ def main():
     dist = None
     backend = None
     try:
-        if world > 1:
+        if world > 1 or args.force_dist:
             import datetime
 
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if world == 1 and "MASTER_PORT" not in os.environ:      # --force-dist without a launcher: a one-rank rendezvous
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC only on this driver (RCCL needs it)
             # backend "nccl" is RCCL on ROCm; GNR_BENCH_BACKEND=gloo is a test-only override (two ranks on
             # one GPU cannot form an RCCL communicator)
@@ -263,10 +269,13 @@ def main():
         ctx = dict(args=args, rank=rank, world=world, dev=dev, dist=dist, backend=backend, torch=torch)
         res = run_cfg4(ctx) if args.config == "cfg4" else run_cfg2b(ctx)
         if rank == 0:
-            if world > 1:
+            from gazenerf_amd import _lib
+            res["build"] = _lib.build_info()          # gnr_build_info(): source hash (checked against the tree at load), flags
+            if dist:
                 res["distributed"] = {"backend": backend, "world_size_formed": dist.get_world_size(),
                                       "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None,
-                                      "devices_visible": n_dev}
+                                      "devices_visible": n_dev, "forced_at_world_size_1": bool(world == 1),
+                                      "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
             if world == 1 and not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(args.mode if args.config == "cfg2b" else "fwdbwd", 64 if args.config == "cfg4" else args.samples,
                                                    args.cpu_budget)
@@ -371,12 +380,10 @@ def run_cfg2b(ctx):
     plist = [face[k] for k in render.PARAM_ORDER] + [eyes[k] for k in render.PARAM_ORDER]
     leaves = [p[k] for k in ("R", "T", "shape_code", "gaze", "appea_code")]
     micro = min(args.micro, n_local)
-    t_rand = synth.synth_jitter(1, micro, n_p, seed=7).to(dev) if fwdbwd else None
-    reducer = GradAllReducer([plist[:24], plist[24:]], world) if fwdbwd else None
+    t_rand = synth.synth_jitter(1, n_local, n_p, seed=7).to(dev) if fwdbwd else None      # [1, n_local, n_p + 1]
+    reducer = GradAllReducer([plist[:24], plist[24:]], world, force_collective=bool(dist)) if fwdbwd else None
     clock = AllReduceClock(torch)
     timers = {k: StageTimer(k, pool=128) for k in (("fwd_mlp", "dgrad", "comp_bwd", "wgrad") if fwdbwd else ("fwd_mlp",))}
-    if fwdbwd:
-        xy_tiles = [p["xy"][:, :, r0:r0 + micro].contiguous() for r0 in range(0, n_local, micro)]
 
     def reset(keep):
         for t in timers.values():
@@ -397,15 +404,25 @@ def run_cfg2b(ctx):
         for t in plist + leaves:
             t.requires_grad_(True)
             t.grad = None
-        for xy in xy_tiles:
-            for t in timers.values():
-                t.arm()
-            out = render.render_two_stream(xy, p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"],
-                                           p["appea_code"], face, eyes, n_samples=n_p,
-                                           t_rand=t_rand[:, :xy.shape[2]], precision=precision)
-            loss = sum((out["feat_" + t] ** 2).mean() + out["bg_alpha_" + t].mean() for t in ("face", "eyes"))
-            loss.backward()
-        if world > 1:
+        # the library's tiled training entry point (round 4): per ray tile forward-with-save -> the caller's per-ray
+        # loss -> backward, 3/3 of the FLOPs; the stage timers are re-armed for every tile from inside the loss closure
+        for t in timers.values():
+            t.arm()
+
+        def tile_loss(out, sl):
+            # called between a tile's forward and its backward: hand the library fresh event pairs for this tile's
+            # backward stages (tile 0's were armed above) and for the next tile's forward
+            if sl.start > 0:
+                for k in ("dgrad", "comp_bwd", "wgrad"):
+                    timers[k].arm()
+            if sl.stop < n_local:
+                timers["fwd_mlp"].arm()
+            return sum((out["feat_" + t] ** 2).mean() + out["bg_alpha_" + t].mean() for t in ("face", "eyes"))
+
+        render.render_two_stream_tiled(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"], p["appea_code"],
+                                       face, eyes, loss_fn=tile_loss, n_samples=n_p, ray_tile=micro,
+                                       t_rand=t_rand, precision=precision)
+        if dist:
             clock(reducer.all_reduce)
 
     def leg(precision):
@@ -427,7 +444,6 @@ def run_cfg2b(ctx):
         # saved activations (540 GB) exceed the workspace budget, so the op tiles the rays itself: an inference forward
         # of the whole image, then per tile forward-with-save + backward = 4/3 of the FLOPs of the micro-batched
         # loop above (which keeps each micro-batch's activations until its own backward).  Timed, never the headline.
-        t_full = synth.synth_jitter(1, n_local, n_p, seed=7).to(dev)
         import ctypes
 
         from gazenerf_amd import _lib
@@ -442,7 +458,7 @@ def run_cfg2b(ctx):
                 t.requires_grad_(True)
                 t.grad = None
             out = render.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"], p["appea_code"],
-                                           face, eyes, n_samples=n_p, t_rand=t_full, precision=args.precision)
+                                           face, eyes, n_samples=n_p, t_rand=t_rand, precision=args.precision)
             sum((out["feat_" + t] ** 2).mean() + out["bg_alpha_" + t].mean() for t in ("face", "eyes")).backward()
 
         call()
@@ -453,6 +469,9 @@ def run_cfg2b(ctx):
         torch.cuda.synchronize()
         oc = (time.perf_counter() - t0) / 2
         one_call = {"ms_per_step": oc * 1e3, "value": n_local / oc, "unit": "rays/s", "calls_timed": 2,
+                    "ms_per_step_tiled_entry": dt / args.steps * 1e3,
+                    "tiled_entry": "render_two_stream_tiled(loss_fn=...) -- the timed step of this bench IS that entry point: per "
+                                   "ray tile forward-with-save, the caller's per-ray loss, backward; 3/3 of the FLOPs",
                     "tiled_in_op": bool(tiled), "saved_activation_bytes_untiled": int(saved),
                     "workspace_budget_bytes": int(render.DEFAULT_WS_BUDGET),
                     "flop_factor_vs_step": 4.0 / 3.0 if tiled else 1.0,
@@ -460,7 +479,6 @@ def run_cfg2b(ctx):
                     "note": "one render_two_stream call + backward for the whole %dx%d-ray image; when the saved activations exceed "
                             "the workspace budget the op tiles the rays itself (inference forward once, then forward-with-save + "
                             "backward per tile = 4/3 of the step's FLOPs)" % (side, side)}
-        del t_full
     alt = None
     if args.precision == "fp32" and not args.no_alt:
         alt = leg("bf16x3")            # second, separately timed leg on the bf16x3 kernels (never the headline)
@@ -506,7 +524,11 @@ def run_cfg2b(ctx):
             tr, src = pmc_traffic("gnr::comp_bwd_kernel", rays_per_launch, n_p)
             stages.append({"stage": "comp_bwd", "what": "compositing backward (timed on the first stream; once per stream)",
                            "kernel": "gnr::comp_bwd_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "avg_ms": a, "launches_timed": len(stage_ms["comp_bwd"]),
+                           "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "peak_measured_stream": HBM_STREAM_GBS,
+                           "frac_of_measured_stream": gbs / HBM_STREAM_GBS,
+                           "peak_basis": "frac: the 8.0 TB/s HBM3E spec; frac_of_measured_stream: the 6.29 TB/s a float4 copy "
+                                         "achieves on this chip (MI355X_MICROARCH.md chip-level table)",
+                           "avg_ms": a, "launches_timed": len(stage_ms["comp_bwd"]),
                            "bytes_per_launch": nbytes, "traffic": tr, "traffic_source": src,
                            "share_of_step": a * 2 * launches_per_step / ms})
         step_flop = (3 if fwdbwd else 1) * n_local * n_p * 2 * FLOP_PER_SAMPLE_STREAM      # this rank's share
@@ -611,7 +633,7 @@ def run_cfg4(ctx):
     assert len(nr) + len(face) + len(eyes) == len(params)
     # buckets in the order the backward produces them: NeuralRenderer first (its all-reduce flies during the hot
     # path's backward), then the two MLPs
-    reducer = GradAllReducer([nr, face, eyes], world)
+    reducer = GradAllReducer([nr, face, eyes], world, force_collective=bool(dist))
     reducer.arm_overlap()
     opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.999), fused=True)
     clock = AllReduceClock(torch)
@@ -624,13 +646,14 @@ def run_cfg4(ctx):
 
     def step():
         opt.zero_grad(set_to_none=True)
+        reducer.begin_step()              # nothing in flight, nothing half counted (an aborted step would leave both)
         for t in timers.values():
             t.arm()
         pred = net("train", p["xy"], None, None, p["shape_code"], p["appea_code"], p["gaze"], p["R"], p["T"], p["Kinv"],
                    t_rand=t_rand)["coarse_dict"]
         loss = losses.total_loss(pred, gt, face_mask, full_eye, left_eye, right_eye, opt_codes)["total_loss"]
         loss.backward()
-        if world > 1:
+        if dist:
             clock(reducer.all_reduce)
         opt.step()
 

@@ -1,7 +1,8 @@
 """gazenerf_amd -- MI355X-native volumetric renderer for GazeNeRF's hot path.
 
 Public surface:
-    render_two_stream, importance_resample, sample_zvals,  (gazenerf_amd.render)
+    render_two_stream, render_two_stream_tiled,            (gazenerf_amd.render; the second: a training step over ray
+    importance_resample, sample_zvals,                      tiles with the caller's per-ray loss, 3/3 of the FLOPs)
     PackedWeightCache
     merge_featmaps                                         (gazenerf_amd.merge)
     neural_render, NeuralRendererAMD                       (gazenerf_amd.upsample)
@@ -15,7 +16,7 @@ Public surface:
     build.build()                                          compile libgnr.so for gfx950
 """
 from . import data, losses, synth  # noqa: F401
-from .render import PackedWeightCache, importance_resample, render_two_stream, sample_zvals  # noqa: F401
+from .render import PackedWeightCache, importance_resample, render_two_stream, render_two_stream_tiled, sample_zvals  # noqa: F401
 from .merge import merge_featmaps  # noqa: F401
 from .upsample import NeuralRendererAMD, neural_render  # noqa: F401
 from .module import GazeNeRFNetAMD, HotPathRenderer, MLPParams  # noqa: F401

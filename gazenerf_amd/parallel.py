@@ -61,11 +61,26 @@ class GradAllReducer:
     working on the layers before it (in the whole network: the NeuralRenderer bucket flies during the hot path's
     backward).  The two MLP buckets come out of ONE gnr_bwd call together, so they start back to back at its end:
     there is nothing left to overlap them with.  ``all_reduce()`` launches whatever has not been launched, waits,
-    and writes the averaged gradients back.  ``bytes_per_step`` / ``n_buckets`` describe the exchange."""
+    and writes the averaged gradients back.  ``bytes_per_step`` / ``n_buckets`` describe the exchange.
 
-    def __init__(self, params, world_size: int, bucket_numel: int = 1518979, average: bool = True):
+    Assumptions (asserted where they can be): every rank owns the same parameters in the same buckets and EVERY parameter
+    of a bucket receives a gradient in every backward -- a rank whose data-dependent control flow skips a parameter
+    would launch a different sequence of collectives than its peers and hang them (the reference network has no such
+    parameter: every tensor of the two MLPs and of the NeuralRenderer is used by every step;
+    ``all_reduce(check_complete=True)`` verifies that no bucket was left half counted).  Gradient accumulation over several
+    backward passes: wrap all but the last one in ``no_sync()`` (hooks then launch nothing), or call ``begin_step()``
+    where the loop zeroes the gradients.  Without either, a bucket whose exchange is already in flight when its hooks
+    fire again is collected and re-launched -- correct, but it blocks the autograd thread on a stale collective.
+
+    ``force_collective``: run the exchange even at world size 1 (``bench.py`` with GNR_BENCH_FORCE_DIST=1: a one-rank RCCL
+    communicator exercises library load, communicator creation and the stream hand-off on a single GPU)."""
+
+    def __init__(self, params, world_size: int, bucket_numel: int = 1518979, average: bool = True,
+                 force_collective: bool = False):
         self.world = world_size
         self.average = average
+        self.active = world_size > 1 or force_collective
+        self._sync = True
         self.buckets: List[List[torch.Tensor]] = []
         params = list(params)
         if params and isinstance(params[0], (list, tuple)):
@@ -91,7 +106,7 @@ class GradAllReducer:
     # -- overlap -------------------------------------------------------------------------------------------
     def arm_overlap(self):
         """Launch a bucket's all-reduce from autograd hooks as soon as its last gradient has been accumulated."""
-        if self.world == 1 or self._hooks:
+        if not self.active or self._hooks:
             return
         self._seen = [set() for _ in self.buckets]
         for bi, bucket in enumerate(self.buckets):
@@ -107,8 +122,24 @@ class GradAllReducer:
         if self._seen is not None:
             self._seen = [set() for _ in self.buckets]
 
+    def no_sync(self):
+        """Context manager for the accumulation micro-steps of a step (all backward passes but the last): the hooks count
+        nothing and launch nothing, so no collective is started on gradients that are still going to change."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            old, self._sync = self._sync, False
+            try:
+                yield self
+            finally:
+                self._sync = old
+        return ctx()
+
     def _make_hook(self, bi):
         def hook(param):
+            if not self._sync:
+                return
             seen = self._seen[bi]
             if bi in self._inflight:
                 # a second backward before all_reduce(): the flat copy in flight is stale.  Collect it (every rank
@@ -133,9 +164,14 @@ class GradAllReducer:
         self._inflight[bi] = (dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat)
 
     # -- the exchange --------------------------------------------------------------------------------------
-    def all_reduce(self):
-        if self.world == 1:
+    def all_reduce(self, check_complete: bool = False):
+        if not self.active:
             return
+        if check_complete and self._seen is not None:
+            half = [bi for bi, seen in enumerate(self._seen) if seen and bi not in self._inflight]
+            if half:
+                raise RuntimeError("GradAllReducer: bucket(s) %s received gradients for only part of their parameters in "
+                                   "this backward: a parameter without a gradient breaks the collective order" % half)
         for bi in range(self.n_buckets):
             if bi not in self._inflight:
                 self._launch(bi)

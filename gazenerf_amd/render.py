@@ -516,6 +516,66 @@ def render_two_stream(batch_xy, R, T, Kinv, shape_code, gaze, appea_code, face_p
     return res
 
 
+def render_two_stream_tiled(batch_xy, R, T, Kinv, shape_code, gaze, appea_code, face_params, eyes_params=None, *,
+                            loss_fn, n_samples: int, ray_tile: Optional[int] = None, t_rand: Optional[torch.Tensor] = None,
+                            z_edges: Optional[torch.Tensor] = None, ray_bias_face: Optional[torch.Tensor] = None,
+                            ray_bias_eyes: Optional[torch.Tensor] = None, return_outputs: bool = False, **kw):
+    """A TRAINING step over ray tiles at 3/3 of the FLOPs -- forward-with-save, loss, backward per tile, nothing recomputed.
+
+    ``render_two_stream`` cannot see the loss: when the saved activations of a call exceed the workspace budget (one
+    512 x 512-ray image: 540 GB) it has to run an inference forward first and then recompute forward-with-save per tile
+    in its backward, 4/3 of the FLOPs.  A loss that is a SUM OVER RAYS does not need the whole image before the first
+    backward -- the reference's image losses are such sums (masked L1 means over pixels, gazenerf_loss.py:438-468; the
+    caller shape being replaced: models/gaze_nerf.py:318-351 + trainer/gazenerf_trainer.py:487-528).  So:
+
+        for each tile of rays, in order:
+            out  = render_two_stream(tile)                 # saves the tile's activations
+            loss = loss_fn(out, sl)                        # sl = slice of the ray axis; out[k] is [B, C, len(sl)]
+            loss.backward()                                # frees them; .grad of every leaf accumulates in tile order
+
+    ``loss_fn(out, sl) -> scalar`` must return this tile's SHARE of the total loss (normalise by the total ray count,
+    not the tile's, if the loss is a mean); any other tensors it touches (targets, masks) are sliced with ``sl`` by the
+    caller.  Gradients accumulate into ``.grad`` of the leaf tensors exactly as ``loss.backward()`` would (fixed tile
+    order: deterministic).  Returns ``(total_loss_detached, outputs or None)``; ``return_outputs=True`` also returns the
+    detached outputs of the whole image, concatenated along the ray axis.
+
+    ``ray_tile=None``: the largest tile whose saved activations fit the workspace budget (``ws_budget_bytes`` / 96 GB).
+    Other keyword arguments are ``render_two_stream``'s."""
+    n_r = batch_xy.shape[2]
+    if ray_tile is None:
+        streams = 1 if eyes_params is None else 2
+        dummy = _Problem(batch_xy, R, T, Kinv, shape_code, gaze, appea_code, n_samples, kw.get("world_z1", 2.5),
+                         kw.get("world_z2", -3.5), None, None, kw.get("hidden", 384), kw.get("feat_nc", 258))
+        ray_tile = plan_ray_tiles(dummy, streams, kw.get("ws_budget_bytes")) or n_r
+    if ray_tile < 1:
+        raise ValueError("ray_tile must be >= 1")
+    kw = dict(kw)
+    kw.pop("ws_budget_bytes", None)
+    cut = lambda t, sl: None if t is None else t[:, sl]
+    total = None
+    pieces = {} if return_outputs else None
+    for r0 in range(0, n_r, ray_tile):
+        sl = slice(r0, min(n_r, r0 + ray_tile))
+        # ray_tile >= the tile's rays: the op itself never tiles (and never recomputes) inside a tile
+        out = render_two_stream(batch_xy[:, :, sl], R, T, Kinv, shape_code, gaze, appea_code, face_params, eyes_params,
+                                n_samples=n_samples, t_rand=cut(t_rand, sl), z_edges=cut(z_edges, sl),
+                                ray_bias_face=cut(ray_bias_face, sl), ray_bias_eyes=cut(ray_bias_eyes, sl),
+                                ray_tile=sl.stop - sl.start, **kw)
+        loss = loss_fn(out, sl)
+        if loss.dim() != 0:
+            raise ValueError("loss_fn must return a scalar (this tile's share of the total loss)")
+        loss.backward()
+        total = loss.detach() if total is None else total + loss.detach()
+        if pieces is not None:
+            for k, v in out.items():
+                pieces.setdefault(k, []).append(v.detach())
+        del out, loss
+    outs = None
+    if pieces is not None:
+        outs = {k: torch.cat(v, dim=-2 if k.startswith("w_") else -1) for k, v in pieces.items()}
+    return total, outs
+
+
 def sample_zvals(batch_xy, R, T, Kinv, *, n_samples: int, world_z1: float = 2.5, world_z2: float = -3.5,
                  t_rand=None, z_edges=None):
     """Left sample edges [B,1,N_r,N_p] -- ``fg_sample_dict["zvals"]`` (utils/model_utils.py:312-313)."""

