@@ -22,7 +22,7 @@ size_t wgrad_scratch_floats();
 void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, int batch,
                   long chunks_per_image, float* dW, int ldw, int col_off, int enc_map, float* colsum_out,
                   int colsum_ld, const float* vec, float* vec_out, float* scratch, hipStream_t stream, bool bf16x3,
-                  int n_crop = -1, int k_crop = -1);
+                  int n_crop = -1, int k_crop = -1, bool small_tiles = false);
 void launch_vecsum(const float* v, int batch, long per_image, float* out, int out_stride, hipStream_t stream);
 void stage_mark(int stage, int which, hipStream_t st);
 struct VdBwdScratch { float* d_rb[2]; float* dR_part; float* dW_part; float* dR_extra; int bpi, segs; };
@@ -367,8 +367,8 @@ __global__ void latent_weights_kernel(const LatentParams lp) {
 
 // ---------------------------------------------------------------------------------------------
 // d loss / d ray_bias[ray][c] = sum over the ray's samples of dY of RGB_layer_1 (GnrProblem.ray_bias is added to that
-// layer's bias for every sample of the ray).  One wave per ray over the saved dY_r1 dump: chunk-channel-major fp32
-// (32 contiguous samples per channel), or the bf16x3 path's QHL quads (16 bytes {hi01, hi23, lo01, lo23} per sample; the
+// layer's bias for every sample of the ray).  One wave per ray over the saved dY_r1 dump: the fp32 kernels' S16 layout
+// (16 contiguous samples per channel and sub-chunk), or the bf16x3 path's QHL quads (16 bytes {hi01, hi23, lo01, lo23} per sample; the
 // slot permutation and the half swap do not matter to a sum over all 32 slots except for which half is hi).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ray_bias_grad_kernel(const float* __restrict__ dY_r1, int chunks_per_ray, long n_rays_total,
@@ -377,12 +377,13 @@ __global__ __launch_bounds__(256) void ray_bias_grad_kernel(const float* __restr
     const long ray = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= n_rays_total) return;
     if (!qhl) {
+        // fp32 kernels: S16 layout (gnr_chain16.h) -- per 16-sample sub-chunk, channel c in the 64-byte row s16_row(c)
         for (int c = lane; c < n_out; c += 64) {
             float acc = 0.0f;
-            for (int ch = 0; ch < chunks_per_ray; ++ch) {
-                const f32x4* src = (const f32x4*)(dY_r1 + (ray * chunks_per_ray + ch) * (long)(CHUNK * H2) + c * CHUNK);
+            for (int sb = 0; sb < 2 * chunks_per_ray; ++sb) {
+                const f32x4* src = (const f32x4*)(dY_r1 + (ray * 2 * chunks_per_ray + sb) * (long)(16 * H2) + s16_row(c) * 16);
 #pragma unroll
-                for (int q = 0; q < CHUNK / 4; ++q) { const f32x4 v = src[q]; acc += (v.x + v.y) + (v.z + v.w); }
+                for (int q = 0; q < 4; ++q) { const f32x4 v = src[q]; acc += (v.x + v.y) + (v.z + v.w); }
             }
             out[ray * n_out + c] = acc;
         }
@@ -541,8 +542,19 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         const long cpi = (long)p->n_rays * cpr;                       // chunks per image
         if (s == 0) stage_mark(GNR_STAGE_WGRAD, 0, st);
         // GEMM shapes = the kernels' (H, H2); the last two arguments crop the written gradient to the network's width
-        launch_wgrad(sc.dfeat, FEAT_PAD, p->feat_nc, ws.act_y1, H2, H2, p->batch, cpi, DW.rgb_w[2], Hh2, 0, 0,
-                     dbl(LR2), H, nullptr, nullptr, sc.wg_part, st, bf16x3, p->feat_nc, Hh2);
+        if (!bf16x3 && p->feat_nc > 192 && p->feat_nc <= 288) {
+            // RGB_layer_2 (258 x 192): as ONE product its rows pad to two 192-row tiles, the second two-thirds empty
+            // (1.04 ms: 0.6 of the clock's peak).  Rows 0..191 are a full 192 x 192 tile (all 256 CUs, one round); the 66 rows
+            // beyond go to a 96-row tile of wgrad_kernel -- same dumps, the operand base moved 192 channels (S16 rows of 16 floats) into the sub-chunk.
+            launch_wgrad(sc.dfeat, FEAT_PAD, 192, ws.act_y1, H2, H2, p->batch, cpi, DW.rgb_w[2], Hh2, 0, 0,
+                         dbl(LR2), H, nullptr, nullptr, sc.wg_part, st, false, 192, Hh2);
+            launch_wgrad(sc.dfeat + 192 * 16, FEAT_PAD, p->feat_nc - 192, ws.act_y1, H2, H2, p->batch, cpi,      // S16: 16 floats per row
+                         DW.rgb_w[2] ? DW.rgb_w[2] + (size_t)192 * Hh2 : nullptr, Hh2, 0, 0, dbl(LR2) + 192, H, nullptr, nullptr,
+                         sc.wg_part, st, false, p->feat_nc - 192, Hh2, true);
+        } else {
+            launch_wgrad(sc.dfeat, FEAT_PAD, p->feat_nc, ws.act_y1, H2, H2, p->batch, cpi, DW.rgb_w[2], Hh2, 0, 0,
+                         dbl(LR2), H, nullptr, nullptr, sc.wg_part, st, bf16x3, p->feat_nc, Hh2);
+        }
         launch_wgrad(sc.dY_r1, H2, H2, ws.act_y0, H, H, p->batch, cpi, DW.rgb_w[1], Hh + p->vd_dims + p->appea_dims, 0, 0,
                      dbl(LR1), H, nullptr, nullptr, sc.wg_part, st, bf16x3, Hh2, Hh);
         launch_wgrad(sc.dY_r0, H, H, hptr(7), H, H, p->batch, cpi, DW.rgb_w[0], Hh, 0, 0, dbl(LR0), H,

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void bwd16_chain_kernel(const BwdParams bp)
         for (int q = 0; q < RELU16_WORDS; ++q)
             if (q < words) mk[q] = src[q * 64 + lane];
     };
-    const unsigned lane_off = dump_lane_off16(sub, j, g);
+    const unsigned lane_off = dump_lane_off16(j, g);
     auto dyh = [&](int l) { return dump_dst16(bp.dY_h + l * M * H, H, sub, lane_off); };
     auto none = [](int) {};
     // Each mm16_h dumps ITS INPUT (the dY of the layer above) while its MFMAs run; accumulators start from a zero

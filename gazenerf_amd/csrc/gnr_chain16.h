@@ -157,42 +157,66 @@ __device__ __forceinline__ void dephase_first_round(unsigned linear_block) {
 }
 
 // ---- dump destination: buffer stores with a wave-uniform descriptor ---------------------------------------------
-// Element (chunk c, channel n, sample jj) of a chunk-channel-major tensor lives at c*32*C + n*32 + jj.  The wave owns
-// samples 16 hh + j of chunk c and, in register e of tile t, channel 16 t + 4 g + e: with the descriptor based at the
-// chunk, every dump of the wave uses the SAME lane offset ((4 g) 32 + 16 hh + j) 4 bytes and a compile-time constant
-// (16 t + e) 128 bytes split over the 12-bit immediate and one scalar: no 64-bit address arithmetic on the VALU
-// (global_store needed a v_add_co / v_addc pair every few stores -- each VALU instruction among the MFMAs costs ~4
-// matrix-pipe cycles), and one VGPR instead of a pointer pair per destination.
+// Layer dumps (activations h0..h7, y0, y1 and every dY) use the "S16" layout (round 4): a tensor of C channels is a
+// sequence of 16-sample sub-chunks of 16 C floats; inside a sub-chunk channel n = 16 t + 4 g + e sits in the 64-byte row
+// rho(n) = 16 t + 4 e + g (e and g swapped).  The wave owns the 16 samples j of one sub-chunk and, in register e of tile
+// t, channel 16 t + 4 g + e in lane group g: ONE store instruction (fixed t, e) then writes rows 16 t + 4 e + 0..3 =
+// 256 CONTIGUOUS bytes, two whole 128-byte lines.  Rounds 1-3 used chunk-channel-major rows of 32 samples (c*32*C + n*32 +
+// j): a 16-sample wave could only write 64-byte HALF rows, four per instruction, the other half arriving from the partner
+// wave at another time.  Measured (tools/ubench/store_pattern.hip, profiles/r4_store_pattern.txt): that pattern drains at
+// 3.3 TB/s against 5.4 for whole lines and is COUNTED 1.10-1.17 x by WRITE_SIZE (which is exact, 1.001 x, on whole-line
+// patterns) -- half-line writes that miss their partner in L2 go out as two masked writes of the line; in the real kernels
+// 1.32 x (44.9 GB for 33.9 GB of dumps per launch).  The consumers (gnr_wgrad.hip) fetch 16-byte pieces = 4 consecutive
+// samples of one channel, which are contiguous in either layout: only their lane / piece offsets change.
+// With the descriptor based at the sub-chunk, every dump of the wave uses the SAME lane offset (16 g + j) 4 bytes and a
+// compile-time constant (t 1024 + e 256 bytes) split over the 12-bit immediate and one scalar: no 64-bit address
+// arithmetic on the VALU (global_store needed a v_add_co / v_addc pair every few stores -- each VALU instruction among
+// the MFMAs costs ~4 matrix-pipe cycles), and one VGPR instead of a pointer pair per destination.
+// (s16_row(n): gnr_internal.h)
 struct Dump16 {
     __amdgpu_buffer_rsrc_t rs;
     unsigned voff;
 };
-__device__ __forceinline__ unsigned dump_lane_off16(long sub, int j, int g) {
-    return (unsigned)((4 * g) * CHUNK + 16 * (int)(sub & 1) + j) * 4u;
-}
+__device__ __forceinline__ unsigned dump_lane_off16(int j, int g) { return (unsigned)(16 * g + j) * 4u; }
 __device__ __forceinline__ Dump16 dump_dst16(float* dst, int C, long sub, unsigned lane_off) {
     Dump16 d;
-    d.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(dst + (sub >> 1) * (CHUNK * (long)C)), 0, 0x7ffffff0, 0x00020000);
+    d.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(dst + sub * (SUB * (long)C)), 0, 0x7ffffff0, 0x00020000);
     d.voff = lane_off;
     return d;
 }
-// element offset (floats, compile-time) -> nontemporal dword store
+// byte offset (compile-time) -> nontemporal dword store
 template <class T>
-__device__ __forceinline__ void dump_store16(const Dump16& d, int elem, T v) {
+__device__ __forceinline__ void dump_store16_bytes(const Dump16& d, unsigned byte, T v) {
     static_assert(sizeof(T) == 4, "dword dumps");
 #ifdef GNR_NODUMP_TIMING            // timing experiment only: results are incomplete
-    (void)d; (void)elem; (void)v;
+    (void)d; (void)byte; (void)v;
 #else
-    // scalar part: whole 16-channel tiles (2 KiB); immediate: the register within the tile (e * 128 B).  With the low
-    // 12 bits as the immediate hipcc CSEs "lane offset + immediate" over all layers and keeps the 32 sums in VGPRs
-    // (every store with its own address register, none with the offset field): 32 registers the chain does not have.
-    const unsigned byte = (unsigned)elem * 4u, lo = byte & 2047u, hi = byte & ~2047u;
+    // scalar part: multiples of 1 KiB (the tile); immediate: the register within the tile (e 256 bytes; four values).  With
+    // the low 12 bits as the immediate hipcc CSEs "lane offset + immediate" over all layers and keeps the sums in VGPRs
+    // (every store with its own address register, none with the offset field): registers the chain does not have; a
+    // 2 KiB split (eight immediates) already spills 2 / 15 VGPRs in the forward / dgrad kernels.
+    const unsigned lo = byte & 1023u, hi = byte & ~1023u;
 #ifdef GNR_TEMPORAL_DUMP_TIMING
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), d.rs, d.voff + lo, (int)hi, 0);
 #else
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), d.rs, d.voff + lo, (int)hi, 2);   // aux 2 = nt
 #endif
 #endif
+}
+// register e of tile t (S16 layout)
+template <class T>
+__device__ __forceinline__ void dump_store16(const Dump16& d, int t, int e, T v) {
+    dump_store16_bytes(d, (unsigned)(t * 1024 + e * 256), v);
+}
+
+// The composited features (act_feat) keep the chunk-channel-major layout of rounds 1-3 -- element (chunk c, channel n,
+// sample jj) at c*32*C + n*32 + jj: their one reader, comp_bwd_kernel, streams a sample per lane at 0.97 of the measured
+// HBM rate on whole rows, and they are 7 % of the dumped bytes.
+__device__ __forceinline__ Dump16 dump_dst16_ccm(float* dst, int C, long sub, int j, int g) {
+    Dump16 d;
+    d.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(dst + (sub >> 1) * (CHUNK * (long)C)), 0, 0x7ffffff0, 0x00020000);
+    d.voff = (unsigned)((4 * g) * CHUNK + 16 * (int)(sub & 1) + j) * 4u;
+    return d;
 }
 
 // ---- one dense layer: acc[nt] (+)= sum over the channels held in hin[0..NT_IN) --------------------------------
@@ -238,7 +262,7 @@ __device__ __forceinline__ void mm16_h(const f32x4 (&hin)[NT16_H], f32x4 (&acc)[
             const int q0 = kb == 0 ? 0 : ((t0 + S - 1) / S) * S, q1 = ((t1 + S - 1) / S) * S;
 #pragma unroll
             for (int q = q0; q < (q1 < NREG ? q1 : NREG); ++q)
-                dump_store16(dump_dst, (16 * (q >> 2) + (q & 3)) * CHUNK, hin[q >> 2][q & 3]);
+                dump_store16(dump_dst, q >> 2, q & 3, hin[q >> 2][q & 3]);
         }
         // epilogue of the tiles completed by the previous batch
 #pragma unroll
@@ -280,12 +304,14 @@ __device__ __forceinline__ void mm16_enc(const float* enc_col, f32x4 (&acc)[NT16
     }
 }
 
+// d: dump_dst16_ccm (chunk-channel-major rows of 32 samples: channel 16 t + 4 g + e at row offset (16 t + e) 128 bytes
+// from the lane's)
 template <int NT>
-__device__ __forceinline__ void dump16(const f32x4 (&acc)[NT16_H], const Dump16& d) {
+__device__ __forceinline__ void dump16_ccm(const f32x4 (&acc)[NT16_H], const Dump16& d) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dump_store16(d, (16 * t + e) * CHUNK, acc[t][e]);
+        for (int e = 0; e < 4; ++e) dump_store16_bytes(d, (unsigned)((16 * t + e) * CHUNK * 4), acc[t][e]);
 }
 
 // ReLU sign bits: lane l keeps the signs of its own registers, tiles 8 w .. 8 w + 7 -> word w, bit 31 - (4 (t & 7) + e)

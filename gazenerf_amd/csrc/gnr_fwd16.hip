@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void fwd16_kernel(const FwdParams fp) {
         // "lane offset + immediate" for all 32 immediates into VGPRs that then live across the whole kernel (each store
         // with its own address register instead of the 12-bit offset field) -- the register pressure cost the training
         // forward 2.6 ms per launch.
-        unsigned lane_off = dump_lane_off16(sub, j, g);
+        unsigned lane_off = dump_lane_off16(j, g);
         asm volatile("" : "+v"(lane_off));
         auto dp = [&](float* dst, int C) { return dump_dst16(SAVE ? dst : nullptr, C, SAVE ? sub : 0, lane_off); };
         auto sb = [&](int layer) {           // sign-bit words [3][64 lanes] of this sub-chunk
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void fwd16_kernel(const FwdParams fp) {
                 // left-aligned here
 #pragma unroll
                 for (int q = 0; q < RELU16_WORDS; ++q)
-                    if (q < words) dump_store16(dst, q * 64, (words == 2 && q == 1) ? (mkw[q] << 16) : mkw[q]);
+                    if (q < words) dump_store16_bytes(dst, (unsigned)q * 256u, (words == 2 && q == 1) ? (mkw[q] << 16) : mkw[q]);
             }
         };
 
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void fwd16_kernel(const FwdParams fp) {
         mm16_h<NT16_H2, NT16_F, true, SAVE && !(ABL16 & 2)>(Bv, A, w, dp(ws.act_y1, H2), GNR_BIAS(LR2), noneA);
 #undef GNR_BIAS
 #undef GNR_RELU
-        if (SAVE && !(ABL16 & 4)) dump16<NT16_F>(A, dump_dst16(ws.act_feat, FEAT_PAD, sub, lane_off));
+        if (SAVE && !(ABL16 & 4)) dump16_ccm<NT16_F>(A, dump_dst16_ccm(ws.act_feat, FEAT_PAD, sub, j, g));
 
         // ---- A5: sub-chunk-local compositing (utils/model_utils.py:498-534) ----
         composite_sub(A, sig, delta, z0, ws, sub, row, lane, SAVE || fp.want_wl);

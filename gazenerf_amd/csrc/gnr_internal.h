@@ -45,6 +45,10 @@ constexpr int N_CHAIN = 11;        // L0..L7, RGB0, RGB1, RGB2
 constexpr int CHUNK = 32;          // samples per wavefront tile
 constexpr int WAVES_PER_WG = 4;
 
+// S16 dump layout of the fp32 chain kernels (gnr_chain16.h): inside a 16-sample sub-chunk of 16 C floats channel
+// n = 16 t + 4 g + e occupies the 64-byte row 16 t + 4 e + g
+__host__ __device__ constexpr int s16_row(int n) { return (n & ~15) + 4 * (n & 3) + ((n >> 2) & 3); }
+
 // chain layer ids
 enum { L0 = 0, L5 = 5, L7 = 7, LR0 = 8, LR1 = 9, LR2 = 10 };
 

@@ -72,6 +72,12 @@ struct WgradParams {
     //   channels-first images [B][C][P]: row = P, chunk = 32, img = C*P.
     long a_row, a_chunk, a_img, b_row, b_chunk, b_img;
     int linear_map;               // wgrad2w_kernel: workgroup id -> contiguous ranges of (split, tile) per XCD instead of split % 8
+    // Round 4: the fp32 chain kernels dump in the S16 layout (gnr_chain16.h): 16-sample sub-chunks of 16 ld floats, channel n
+    // in the 64-byte row s16_row(n).  A chunk of 32 samples is still one block of 32 ld floats (two sub-chunks), a 16-byte
+    // piece (4 consecutive samples of one channel) still contiguous: piece p of channel n sits at byte
+    // (p >> 2) 64 ld + s16_row(n) 64 + (p & 3) 16 of its chunk.  0: rows of 32 samples (the encoding dump, the bf16x3 path's
+    // own formats, images).
+    int a_s16, b_s16;
     unsigned long long* clk;      // shader-clock probe (gnr_internal.h) or nullptr
 };
 
@@ -82,6 +88,14 @@ __device__ __forceinline__ void wait_vm_dma() {
 
 // LDS position (in floats) of 16-byte piece `c` (0..7) of tile row `n`
 __device__ __forceinline__ int swz(int n, int c) { return n * CHUNK + ((c ^ ((n >> 1) & 7)) << 2); }
+
+// S16 source addressing of an LDS-DMA instruction (lane l fills slot l%8 of tile row 8 i + l/8 with piece p): byte offset
+// inside the chunk, relative to the tile's first row (a multiple of 16 channels) = lane part + piece part.
+//   tile row 8 i + r  ->  64-byte row 16 (i >> 1) + 4 (r & 3) + 2 (i & 1) + (r >> 2)       (s16_row, gnr_chain16.h)
+__device__ __forceinline__ unsigned s16_lane_off(int r, int p, int ld) {
+    return 256u * (unsigned)(r & 3) + 64u * (unsigned)(r >> 2) + (unsigned)(p >> 2) * (unsigned)(64 * ld) + 16u * (unsigned)(p & 3);
+}
+__device__ __forceinline__ unsigned s16_piece_off(unsigned i) { return (i >> 1) * 1024u + (i & 1u) * 128u; }
 
 template <int WN, int WK, int XN, int XK, bool VEC>
 __global__ __launch_bounds__(64 * WN * WK, 2) void wgrad_kernel(const WgradParams wp) {
@@ -126,14 +140,16 @@ __global__ __launch_bounds__(64 * WN * WK, 2) void wgrad_kernel(const WgradParam
     for (int q = 0; q < A_IT; ++q) {
         const int r = (tid + THREADS * q) >> 3;
         int n = tn * TN + r; if (n >= wp.lda) n = wp.lda - 1;
-        ga[q] = wp.A + (long)b * wp.a_img + (long)n * wp.a_row + 4 * pc - (long)b * wp.chunks_per_image * wp.a_chunk;
+        const long ea = wp.a_s16 ? (long)(pc >> 2) * (16 * wp.lda) + (long)s16_row(n) * 16 + 4 * (pc & 3) : (long)n * wp.a_row + 4 * pc;
+        ga[q] = wp.A + (long)b * wp.a_img + ea - (long)b * wp.chunks_per_image * wp.a_chunk;
         lposa[q] = swz(r, pc);
     }
 #pragma unroll
     for (int q = 0; q < B_IT; ++q) {
         const int r = (tid + THREADS * q) >> 3;
         int k = tk * TK + r; if (k >= wp.ldb) k = wp.ldb - 1;
-        gb[q] = wp.B + (long)b * wp.b_img + (long)k * wp.b_row + 4 * pc - (long)b * wp.chunks_per_image * wp.b_chunk;
+        const long eb = wp.b_s16 ? (long)(pc >> 2) * (16 * wp.ldb) + (long)s16_row(k) * 16 + 4 * (pc & 3) : (long)k * wp.b_row + 4 * pc;
+        gb[q] = wp.B + (long)b * wp.b_img + eb - (long)b * wp.chunks_per_image * wp.b_chunk;
         lposb[q] = TN * CHUNK + swz(r, pc);
     }
     const long strideA = wp.a_chunk, strideB = wp.b_chunk;
@@ -349,9 +365,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradParams wp
     // LDS-DMA: descriptor per operand with base = first chunk of this split, tile row 0; num_records = end of the
     // split, so requests for chunks past it return zeros (no tail branches).
     const unsigned chunk_a = (unsigned)(wp.lda * CHUNK * 4), chunk_b = (unsigned)(wp.ldb * CHUNK * 4);
-    auto desc = [&](const float* base, long ld, long tile_row0, unsigned chunk_bytes) {
-        const unsigned long long a = (unsigned long long)(base + c0 * (CHUNK * ld) + tile_row0 * CHUNK);
-        long bytes = (long)nchunks * chunk_bytes - tile_row0 * CHUNK * 4;
+    auto desc = [&](const float* base, long ld, long tile_row0, unsigned chunk_bytes, int s16) {
+        const long row0 = tile_row0 * (s16 ? 16 : CHUNK);          // floats from the chunk's start to the tile's first row
+        const unsigned long long a = (unsigned long long)(base + c0 * (CHUNK * ld) + row0);
+        long bytes = (long)nchunks * chunk_bytes - row0 * 4;
         if (bytes < 0) bytes = 0;
         i32x4 r;
         r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
@@ -360,29 +377,41 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradParams wp
         r.w = 0x00020000;
         return r;
     };
-    const i32x4 rsa = desc(wp.A, wp.lda, (long)tn * TN, chunk_a);
-    const i32x4 rsb = desc(wp.B, wp.ldb, (long)tk * TK, chunk_b);
-    // lane l fills slot l%8 of row 8i + l/8 with source piece (l%8) ^ ((4i + l/16) % 8)
-    const unsigned voff_even = (unsigned)(lane >> 3) * 128u + (unsigned)((lane & 7) ^ (lane >> 4)) * 16u;
-    const unsigned voff_odd = voff_even ^ 64u;
+    const i32x4 rsa = desc(wp.A, wp.lda, (long)tn * TN, chunk_a, wp.a_s16);
+    const i32x4 rsb = desc(wp.B, wp.ldb, (long)tk * TK, chunk_b, wp.b_s16);
+    // lane l fills slot l%8 of row 8i + l/8 with source piece (l%8) ^ ((4i + l/16) % 8): odd i = the piece index ^ 4
+    const int pe = (lane & 7) ^ (lane >> 4);
+    const unsigned voff_even_c = (unsigned)(lane >> 3) * 128u + (unsigned)pe * 16u, voff_odd_c = voff_even_c ^ 64u;      // rows of 32 samples
+    const unsigned voff_even_a = wp.a_s16 ? s16_lane_off(lane >> 3, pe, wp.lda) : voff_even_c;
+    const unsigned voff_odd_a = wp.a_s16 ? s16_lane_off(lane >> 3, pe ^ 4, wp.lda) : voff_odd_c;
+    const unsigned voff_even_b = wp.b_s16 ? s16_lane_off(lane >> 3, pe, wp.ldb) : voff_even_c;
+    const unsigned voff_odd_b = wp.b_s16 ? s16_lane_off(lane >> 3, pe ^ 4, wp.ldb) : voff_odd_c;
     const unsigned lds0 = (unsigned)(size_t)&lds[0];
+    // scalar source offset of this wave's piece j inside a chunk
+    unsigned poff[PA + PB];
+#pragma unroll
+    for (int j = 0; j < PA + PB; ++j) {
+        const bool isa = j < PA;
+        const unsigned i = (unsigned)(isa ? wave * PA + j : wave * PB + (j - PA));
+        poff[j] = (isa ? wp.a_s16 : wp.b_s16) ? s16_piece_off(i) : i * 1024u;
+    }
     // piece j (0 .. PA+PB-1) of this wave's share of chunk c0 + k, into ring buffer `buf`
     auto dma_piece = [&](int k, int buf, int j) {
         const bool isa = j < PA;
         const unsigned i = (unsigned)(isa ? wave * PA + j : wave * PB + (j - PA));
         const unsigned l = lds0 + (unsigned)buf * BUF_BYTES + (isa ? 0u : (unsigned)(TN * CHUNK * 4)) + i * 1024u;
 #ifdef GNR_WG_HOT      /* timing experiment (wrong results): every request re-reads one of the first 8 chunks -> operands L2-resident */
-        const unsigned so = (unsigned)(k & 7) * (isa ? chunk_a : chunk_b) + i * 1024u;
+        const unsigned so = (unsigned)(k & 7) * (isa ? chunk_a : chunk_b) + poff[j];
 #else
-        const unsigned so = (unsigned)k * (isa ? chunk_a : chunk_b) + i * 1024u;
+        const unsigned so = (unsigned)k * (isa ? chunk_a : chunk_b) + poff[j];
 #endif
         unsigned keep;
         if (isa)
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"((i & 1) ? voff_odd : voff_even), "s"(rsa), "s"(l), "s"(so) : "memory");
+                         : "=&s"(keep) : "v"((i & 1) ? voff_odd_a : voff_even_a), "s"(rsa), "s"(l), "s"(so) : "memory");
         else
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"((i & 1) ? voff_odd : voff_even), "s"(rsb), "s"(l), "s"(so) : "memory");
+                         : "=&s"(keep) : "v"((i & 1) ? voff_odd_b : voff_even_b), "s"(rsb), "s"(l), "s"(so) : "memory");
     };
     auto dma_chunk = [&](int k, int buf) {
 #pragma unroll
@@ -603,10 +632,13 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
     const bool img = wp.a_row != CHUNK;
     const unsigned kstride_a = img ? 128u : (unsigned)(wp.lda * CHUNK * 4), kstride_b = img ? 128u : (unsigned)(wp.ldb * CHUNK * 4);
     const unsigned pstride_a = img ? (unsigned)(8 * wp.a_row * 4) : 1024u, pstride_b = img ? (unsigned)(8 * wp.b_row * 4) : 1024u;
-    auto desc = [&](const float* base, long ld, long tile_row0, unsigned chunk_bytes, int valid, long row, long img_stride) {
+    auto desc = [&](const float* base, long ld, long tile_row0, unsigned chunk_bytes, int valid, long row, long img_stride, int s16) {
         unsigned long long a;
         long bytes;
-        if (img) {
+        if (s16) {         // fp32 chain dumps: the tile's first row sits tile_row0 * 16 floats into the chunk
+            a = (unsigned long long)(base + c0 * (CHUNK * ld) + tile_row0 * 16);
+            bytes = (long)nchunks * chunk_bytes - tile_row0 * 64;
+        } else if (img) {
             const long start = ((long)sp * wp.chunks_per_split) * CHUNK;              // first pixel of the split
             a = (unsigned long long)(base + (long)b * img_stride + tile_row0 * row + start);
             bytes = ((long)valid - tile_row0) * row * 4 - start * 4;
@@ -623,15 +655,26 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
         r.w = 0x00020000;
         return r;
     };
-    const i32x4 rsa = desc(wp.A, wp.lda, (long)tn * TN, kstride_a, wp.n_valid, wp.a_row, wp.a_img);
-    const i32x4 rsb = desc(wp.B, wp.ldb, (long)tk * TK, kstride_b, wp.k_valid, wp.b_row, wp.b_img);
-    // lane l fills slot l%8 of row 8i + l/8 with source piece (l%8) ^ ((4i + l/16) % 8)   (as wgrad_pipe_kernel)
-    const unsigned vpiece = (unsigned)((lane & 7) ^ (lane >> 4)) * 16u;
-    const unsigned voff_even_a = (unsigned)(lane >> 3) * (img ? (unsigned)(wp.a_row * 4) : 128u) + vpiece;
-    const unsigned voff_even_b = (unsigned)(lane >> 3) * (img ? (unsigned)(wp.b_row * 4) : 128u) + vpiece;
-    const unsigned voff_odd_a = voff_even_a ^ 64u, voff_odd_b = voff_even_b ^ 64u;
+    const i32x4 rsa = desc(wp.A, wp.lda, (long)tn * TN, kstride_a, wp.n_valid, wp.a_row, wp.a_img, wp.a_s16);
+    const i32x4 rsb = desc(wp.B, wp.ldb, (long)tk * TK, kstride_b, wp.k_valid, wp.b_row, wp.b_img, wp.b_s16);
+    // lane l fills slot l%8 of row 8i + l/8 with source piece (l%8) ^ ((4i + l/16) % 8)   (as wgrad_pipe_kernel): odd i =
+    // the piece index ^ 4
+    const int pe = (lane & 7) ^ (lane >> 4);
+    const unsigned vpiece = (unsigned)pe * 16u;
+    const unsigned voff_even_a = wp.a_s16 ? s16_lane_off(lane >> 3, pe, wp.lda) : (unsigned)(lane >> 3) * (img ? (unsigned)(wp.a_row * 4) : 128u) + vpiece;
+    const unsigned voff_even_b = wp.b_s16 ? s16_lane_off(lane >> 3, pe, wp.ldb) : (unsigned)(lane >> 3) * (img ? (unsigned)(wp.b_row * 4) : 128u) + vpiece;
+    const unsigned voff_odd_a = wp.a_s16 ? s16_lane_off(lane >> 3, pe ^ 4, wp.lda) : voff_even_a ^ 64u;
+    const unsigned voff_odd_b = wp.b_s16 ? s16_lane_off(lane >> 3, pe ^ 4, wp.ldb) : voff_even_b ^ 64u;
     const unsigned lds0 = (unsigned)(size_t)&lds[0];
     constexpr int PA = TN / 8;                                    // A pieces per chunk (24), then TK / 8 B pieces
+    // scalar source offset of this wave's piece j inside a chunk (piece i = 8 rows of the tile)
+    unsigned poff[NPIECE];
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) {
+        const bool isa = 8 * j < PA;
+        const unsigned i = isa ? (unsigned)(8 * j + wave) : (unsigned)(8 * j + wave) - PA;
+        poff[j] = (isa ? wp.a_s16 : wp.b_s16) ? s16_piece_off(i) : i * (isa ? pstride_a : pstride_b);
+    }
     // piece j (0 .. NPIECE-1) of this wave's share of chunk c0 + k, into ring buffer `buf`: global piece index 8 j + wave
     auto dma_piece = [&](int k, int buf, int j) {
         const unsigned gp = (unsigned)(8 * j + wave);
@@ -639,9 +682,9 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
         const unsigned i = isa ? gp : gp - PA;
         const unsigned l = lds0 + (unsigned)buf * BUF_BYTES + (isa ? 0u : (unsigned)(TN * CHUNK * 4)) + i * 1024u;
 #ifdef GNR_WG_HOT      /* timing experiment (wrong results): every request re-reads one of the first 8 chunks -> operands L2-resident */
-        const unsigned so = (unsigned)(k & 7) * (isa ? kstride_a : kstride_b) + i * (isa ? pstride_a : pstride_b);
+        const unsigned so = (unsigned)(k & 7) * (isa ? kstride_a : kstride_b) + poff[j];
 #else
-        const unsigned so = (unsigned)k * (isa ? kstride_a : kstride_b) + i * (isa ? pstride_a : pstride_b);
+        const unsigned so = (unsigned)k * (isa ? kstride_a : kstride_b) + poff[j];
 #endif
         unsigned keep;
         if (isa)
@@ -1324,7 +1367,7 @@ static int choose_tile(int n_valid, int k_valid, bool vec) {
 static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, int batch,
                               long chunks_per_image, float* dW, int ldw, int col_off, int enc_map, float* colsum_out,
                               int colsum_ld, const float* vec, float* vec_out, float* scratch, hipStream_t stream,
-                              bool bf16x3, long pixels_per_image, int n_crop, int k_crop) {
+                              bool bf16x3, long pixels_per_image, int n_crop, int k_crop, bool small_tiles = false) {
     WgradParams wp{};
     wp.A = A; wp.B = B; wp.lda = lda; wp.ldb = ldb; wp.n_valid = n_valid; wp.k_valid = k_valid;
     if (pixels_per_image > 0) {       // channels-first images [B][C][P]
@@ -1334,6 +1377,9 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
         wp.a_row = CHUNK; wp.a_chunk = (long)CHUNK * lda; wp.a_img = chunks_per_image * wp.a_chunk;
         wp.b_row = CHUNK; wp.b_chunk = (long)CHUNK * ldb; wp.b_img = chunks_per_image * wp.b_chunk;
     }
+    // fp32 chain dumps are S16 (gnr_chain16.h); the encoding dump (enc_map != 0) keeps rows of 32 samples
+    wp.a_s16 = (!bf16x3 && pixels_per_image == 0) ? 1 : 0;
+    wp.b_s16 = (wp.a_s16 && enc_map == 0) ? 1 : 0;
     wp.clk = clock_probe_slot(GNR_STAGE_WGRAD);
     const bool with_vec = vec_out != nullptr;
     // chunk-channel-major fp32 operands of the MLP's shapes go to the pipelined one-workgroup-per-CU kernel
@@ -1344,6 +1390,9 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
         (!with_vec || (n_valid > 192 && k_valid == 384)))        // the density rider needs the 2 x 2 tile grid
         pipe_xk = k_valid == 64 ? 1 : 3;
 #endif
+    // small_tiles: a product far below the 192-row tile (the 66 rows RGB_layer_2 has beyond its first 192) goes to
+    // wgrad_kernel's per-shape tiles instead of a 192 x 192 tile that would be two-thirds padding
+    if (small_tiles && !bf16x3 && !with_vec) pipe_xk = 0;
     // bf16x3: pre-split QHL dumps of the chain kernels -> the transposing-read kernel (192-row tiles)
     if (bf16x3 && pixels_per_image == 0 && n_valid <= 384 && lda % 32 == 0 && ldb % 32 == 0 &&
         (k_valid == 64 || k_valid == 192 || k_valid == 384) && (!with_vec || (n_valid > 192 && k_valid == 384)))
@@ -1450,10 +1499,10 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
 void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, int batch,
                   long chunks_per_image, float* dW, int ldw, int col_off, int enc_map, float* colsum_out,
                   int colsum_ld, const float* vec, float* vec_out, float* scratch, hipStream_t stream, bool bf16x3,
-                  int n_crop = -1, int k_crop = -1) {
+                  int n_crop = -1, int k_crop = -1, bool small_tiles = false) {
     launch_wgrad_impl(A, lda, n_valid, B, ldb, k_valid, batch, chunks_per_image, dW, ldw, col_off, enc_map, colsum_out,
                       colsum_ld, vec, vec_out, scratch, stream, bf16x3, 0, n_crop < 0 ? n_valid : n_crop,
-                      k_crop < 0 ? k_valid : k_crop);
+                      k_crop < 0 ? k_valid : k_crop, small_tiles);
 }
 
 // dW[n_valid x k_valid] = sum over images and pixels of A[b][n][p] * B[b][k][p] for channels-first fp32 images

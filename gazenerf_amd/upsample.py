@@ -141,6 +141,76 @@ def neural_render(x, params: Dict[str, torch.Tensor], n_blocks: int = 3, min_fea
     return _UpsampleFn.apply(cfg, x, *[params[n] for n in names])
 
 
+class GraphedUpsample:
+    """Inference forward of the upsampler replayed from a HIP graph (round 4).
+
+    One ``gnr_upsample_fwd`` call is 20 kernel launches; at B = 1 (the reference's render loops,
+    utils/render_utils.py:199-219) 110 of its 512 us were the gaps between them.  The library makes no host
+    synchronisation and takes every buffer from the caller, so the call captures as is: static input, workspace and image
+    buffers, one ``torch.cuda.CUDAGraph`` per (input shape, device, parameter storage).  The weight re-layout
+    (``conv16_pack_kernel``) is INSIDE the graph, so in-place parameter updates are seen by the next replay; a parameter
+    that moves to other storage (``.to()``, ``load_state_dict`` into new tensors, ``p.data = ...``) changes the key and the
+    forward is captured again.  Inference only: nothing is saved for a backward."""
+
+    def __init__(self, max_entries: int = 4):
+        self.entries = {}
+        self.max_entries = max_entries
+        self.captures = 0
+        self.replays = 0
+
+    def clear(self):
+        self.entries.clear()
+
+    def __call__(self, x, params: Dict[str, torch.Tensor], n_blocks: int, min_feat: int, final_actvn: bool, copy_output: bool = True):
+        names = renderer_param_names(n_blocks)
+        flat = [params[n] for n in names]
+        key = (tuple(x.shape), x.device, n_blocks, min_feat, bool(final_actvn)) + tuple(t.data_ptr() for t in flat) + \
+            tuple(tuple(t.shape) for t in flat)
+        ent = self.entries.get(key)
+        if ent is None:
+            ent = self._capture(x, flat, dict(n_blocks=int(n_blocks), min_feat=int(min_feat), final_actvn=bool(final_actvn)))
+            if len(self.entries) >= self.max_entries:
+                self.entries.pop(next(iter(self.entries)))
+            self.entries[key] = ent
+        graph, x_static, img_static = ent[:3]
+        x_static.copy_(x)
+        graph.replay()
+        self.replays += 1
+        return img_static.clone() if copy_output else img_static
+
+    def _capture(self, x, flat, cfg):
+        lib = _lib.load()
+        dev = x.device
+        x_static = torch.empty_like(x, memory_format=torch.contiguous_format)
+        x_static.copy_(x)
+        p, xc, params, names = _prep_upsample(cfg, x_static, flat)
+        for n, t, f in zip(names, [params[n] for n in names], flat):
+            if t.data_ptr() != f.data_ptr():
+                raise ValueError("GraphedUpsample: parameter %s is not contiguous; the graph would read a temporary copy" % n)
+        B, S, n_blocks = p.batch, p.featmap_size, p.n_blocks
+        with torch.cuda.device(dev):
+            nbytes = lib.gnr_upsample_workspace_bytes(C.byref(p), _lib.UP_WS_FWD)
+            if nbytes == 0:
+                _lib.check(1, lib)
+            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+            img = torch.empty(B, 3, S << n_blocks, S << n_blocks, device=dev, dtype=torch.float32)
+            w = _weights_struct(params, n_blocks)
+
+            def call():
+                _lib.check(lib.gnr_upsample_fwd(C.byref(p), C.byref(w), C.c_void_p(img.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                                ws.numel(), _stream_ptr(dev)), lib)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                call()                                  # warm-up outside the capture (module load, argument errors)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                call()
+        self.captures += 1
+        return graph, x_static, img, ws, params, p, w      # the graph's kernels point into all of these: keep them alive
+
+
 class _BlurBuf(nn.Module):
     """Holds Blur's registered buffer ``f = [1, 2, 1]`` (pixel_shuffle_upsample.py:8-11) so that the
     reference's state-dict keys ``*.blur_layer.f`` / ``rgb_upsample.1.f`` exist here too (strict loading)."""
@@ -165,8 +235,12 @@ class NeuralRendererAMD(nn.Module):
     shapes and initialisation; ``forward`` runs on the HIP kernels)."""
 
     def __init__(self, bg_type="white", feat_nc=258, out_dim=3, final_actvn=True, min_feat=32, featmap_size=64,
-                 img_size=512, **kwargs):
+                 img_size=512, graph_inference=True, **kwargs):
         super().__init__()
+        # graph_inference: under torch.no_grad() the forward is replayed from a HIP graph (GraphedUpsample) -- the
+        # reference's render loops call the network one image at a time, where launch gaps were a fifth of the call
+        self.graph_inference = bool(graph_inference)
+        self._graphed = GraphedUpsample()
         if out_dim != 3:
             raise ValueError("only out_dim = 3 (the reference's value, gaze_nerf.py:114) is supported")
         if bg_type not in ("white", "black"):
@@ -189,4 +263,11 @@ class NeuralRendererAMD(nn.Module):
 
     def forward(self, x):
         params = {k: v for k, v in self.named_parameters() if k != "bg_featmap"}
+        if (self.graph_inference and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+                and not torch.cuda.is_current_stream_capturing()):
+            return self._graphed(x, params, self.n_blocks, self.min_feat, self.final_actvn)
         return neural_render(x, params, self.n_blocks, self.min_feat, self.final_actvn)
+
+    def _apply(self, fn, *args, **kw):          # .to() / .cuda() / .half(): parameters move, captured graphs are stale
+        self._graphed.clear()
+        return super()._apply(fn, *args, **kw)

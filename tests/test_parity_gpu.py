@@ -743,7 +743,45 @@ GRAD_EPS = {"fp32": 2e-5, "bf16x3": 1.5e-4}
 GRAD_STABLE_ABS = {"fp32": 2e-4, "bf16x3": 4e-4}   # mask-stable problem: bound on every parameter / latent gradient
 
 
-def _noise_errors(stable, draw, precisions, dev):
+def _permuted_network(params, seed):
+    """The SAME function with every hidden layer's channels permuted (rows of W_l and b_l, the matching input columns of the
+    layers that read them): mathematically identical, but fp32 sums every dot product in another order -- an independent
+    draw of the reference's own fp32 rounding noise.  Returns (permuted params, un-permute for a gradient dict)."""
+    g = torch.Generator().manual_seed(seed)
+    H, vp = 384, 244
+    P = {i: torch.randperm(H, generator=g) for i in range(8)}
+    Pr0, Pr1 = torch.randperm(H, generator=g), torch.randperm(H // 2, generator=g)
+    ident = lambda n: torch.arange(n)
+    rows, cols = {}, {}
+    for i in range(8):
+        name = "FeaExt_module_%d" % i
+        rows[name] = P[i]
+        cols[name] = ident(vp) if i == 0 else (torch.cat([ident(vp), vp + P[4]]) if i == 5 else P[i - 1])
+    rows["density_module"], cols["density_module"] = ident(1), P[7]
+    rows["RGB_layer_0"], cols["RGB_layer_0"] = Pr0, P[7]
+    rows["RGB_layer_1"], cols["RGB_layer_1"] = Pr1, torch.cat([Pr0, H + ident(params["RGB_layer_1.weight"].shape[1] - H)])
+    rows["RGB_layer_2"], cols["RGB_layer_2"] = ident(params["RGB_layer_2.weight"].shape[0]), Pr1
+    out = {}
+    for name in rows:
+        w = params[name + ".weight"]
+        w2 = w.reshape(w.shape[0], w.shape[1])[rows[name]][:, cols[name]]
+        out[name + ".weight"] = w2.reshape(w.shape).contiguous()
+        out[name + ".bias"] = params[name + ".bias"][rows[name]].contiguous()
+
+    def unpermute(name, grad):          # name: "FeaExt_module_3.weight" ...
+        base, kind = name.rsplit(".", 1)
+        if kind == "bias":
+            res = torch.empty_like(grad)
+            res[rows[base]] = grad
+            return res
+        g2 = grad.reshape(grad.shape[0], grad.shape[1])
+        res = torch.empty_like(g2)
+        res[rows[base][:, None], cols[base][None, :]] = g2
+        return res.reshape(grad.shape)
+    return out, unpermute
+
+
+def _noise_errors(stable, draw, precisions, dev, with_null=False):
     """Per tensor: rel-L2 error against the fp64 oracle of (the oracle's own fp32 autograd, the HIP gradient per precision)."""
     p, face, eyes, t_rand = _grad_problem(stable, draw)
     d64 = lambda d: {k: v.double() for k, v in d.items()}
@@ -753,11 +791,23 @@ def _noise_errors(stable, draw, precisions, dev):
     hips = {pr: _all_grads(_to(p, dev), _to(face, dev), _to(eyes, dev), t_rand.to(dev),
                            lambda xy, R, T, K, s, g, a, f, e, tr, pr=pr: render.render_two_stream(
                                xy, R, T, K, s, g, a, f, e, n_samples=64, t_rand=tr, precision=pr)) for pr in precisions}
+    null = None
+    if with_null:
+        # the reference's OWN fp32 arithmetic on a channel-permuted copy of the network: a second, independent draw of its
+        # rounding noise -- the yardstick for "another fp32 arithmetic" that involves no HIP code at all
+        fperm, fun = _permuted_network(face, 1000 + draw)
+        eperm, eun = _permuted_network(eyes, 2000 + draw)
+        raw = _all_grads(p, fperm, eperm, t_rand, ofn)
+        null = {}
+        for k, v in raw.items():
+            null[k] = fun(k[5:], v) if k.startswith("face.") else (eun(k[5:], v) if k.startswith("eyes.") else v)
     out = {}
     for k, r in exact.items():
         n = max(float(r.norm()), 1e-30)
-        out[k] = (float((ref32[k].double() - r).norm()) / n,
-                  {pr: float((h[k].cpu().double() - r).norm()) / n for pr, h in hips.items()})
+        e_hip = {pr: float((h[k].cpu().double() - r).norm()) / n for pr, h in hips.items()}
+        if null is not None:
+            e_hip["null"] = float((null[k].double() - r).norm()) / n
+        out[k] = (float((ref32[k].double() - r).norm()) / n, e_hip)
     return out
 
 

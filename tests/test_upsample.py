@@ -229,6 +229,44 @@ def test_module_has_reference_state_dict_and_is_deterministic():
 
 
 @pytest.mark.gpu
+def test_graph_replayed_inference_equals_the_eager_forward():
+    """NeuralRendererAMD under torch.no_grad(): the forward is captured once per (shape, parameter storage) in a HIP graph
+    and replayed; same bits as the eager call, in-place parameter updates are seen (the weight re-layout is inside the
+    graph), a parameter moved to new storage re-captures, another batch size is another graph."""
+    from gazenerf_amd import NeuralRendererAMD
+    dev = _dev()
+    torch.manual_seed(0)
+    net = NeuralRendererAMD(feat_nc=258, featmap_size=64, img_size=512).to(dev).eval()
+    x = synth.synth_featmap(1, 258, 64, seed=1).to(dev)
+    eager = neural_render_eager(net, x)
+    with torch.no_grad():
+        a = net(x)
+        b = net(x * 0.5 + 0.1)
+        c = net(x)
+    assert net._graphed.captures == 1 and net._graphed.replays == 3
+    assert torch.equal(a, eager) and torch.equal(c, eager) and not torch.equal(a, b)
+    assert a.data_ptr() != c.data_ptr()                              # outputs are copies, not the graph's buffer
+    with torch.no_grad():
+        net.feat_layers[1].weight.mul_(1.5)                          # in place: same storage, the replay must see it
+        d = net(x)
+    assert net._graphed.captures == 1 and torch.equal(d, neural_render_eager(net, x)) and not torch.equal(d, eager)
+    with torch.no_grad():
+        net.feat_layers[1].weight.data = net.feat_layers[1].weight.data.clone()      # new storage: captured again
+        e = net(x)
+        f = net(torch.cat([x, x * 0.5]))                             # B = 2: its own graph
+    assert net._graphed.captures == 3 and torch.equal(e, d) and torch.equal(f[:1], d)
+    y = net(x.requires_grad_(True))                                  # grad mode: the autograd op, no graph
+    assert y.requires_grad and net._graphed.replays == 6 and torch.equal(y.detach(), d)
+
+
+def neural_render_eager(net, x):
+    from gazenerf_amd import neural_render
+    with torch.no_grad():
+        params = {k: v for k, v in net.named_parameters() if k != "bg_featmap"}
+        return neural_render(x, params, net.n_blocks, net.min_feat, net.final_actvn)
+
+
+@pytest.mark.gpu
 def test_bad_inputs_are_rejected():
     from gazenerf_amd import _lib, neural_render
     dev = _dev()

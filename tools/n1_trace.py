@@ -27,7 +27,7 @@ def main():
     if tile:
         from gazenerf_amd import _lib
         _lib.check(_lib.load().gnr_set_conv16_tile(*[int(v) for v in tile.split(",")]))
-    net = NeuralRendererAMD().to(dev)
+    net = NeuralRendererAMD(graph_inference=os.environ.get("N1_GRAPH", "1") == "1").to(dev)
     x = torch.randn(a.batch, 258, 64, 64, device=dev, requires_grad=not a.fwd_only)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 

@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""GPU: ONE stage of the fp32 / bf16x3 training step in a loop, for power / clock measurements per stage
+(tools/smi_sample.py around it) -- the bench interleaves the three stages every ~120 ms, too fast for the SMI's samples.
+
+    python tools/stage_loop.py fwd|bwd [--seconds 12] [--rays 16384] [--precision fp32|bf16x3]
+
+fwd: gnr_fwd with save_for_backward (fwd16_kernel<true> + combine) over and over in one workspace;
+bwd: gnr_bwd over and over on one saved workspace (comp_bwd + dgrad chain + weight gradients, both streams).
+Prints the stage's HIP-event time and the in-kernel clock probe."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gazenerf_amd import render, synth                                   # noqa: E402
+from gazenerf_amd.hiptime import ClockProbe, StageTimer                  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("stage", choices=("fwd", "bwd"))
+    ap.add_argument("--seconds", type=float, default=12.0)
+    ap.add_argument("--rays", type=int, default=16384)
+    ap.add_argument("--precision", default="fp32")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    x3 = a.precision == "bf16x3"
+    p = {k: v.to(dev) for k, v in synth.synth_problem(512, batch=1, camera="3", seed=100, ray_subset=torch.arange(a.rays)).items()}
+    face = {k: v.to(dev) for k, v in synth.hash_mlp_params("face", seed=0, density_scale=50.0).items()}
+    eyes = {k: v.to(dev) for k, v in synth.hash_mlp_params("eyes", seed=0, density_scale=50.0).items()}
+    t_rand = synth.synth_jitter(1, a.rays, 64, seed=7).to(dev)
+    prob = render._Problem(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"], p["appea_code"], 64, 2.5, -3.5,
+                           t_rand, None, 384, 258)
+    streams = [render._prep_params(render.params_to_list(d), 384, prob.vp, prob.c.appea_dims, 258, "s") for d in (face, eyes)]
+    os.environ["GNR_BINDING"] = "ctypes"
+    res, ws = render._run_forward(prob, streams, True, False, False, x3)
+    gout = [(torch.randn_like(r[0]) * 1e-3, torch.randn_like(r[1]) * 1e-3) for r in res]
+    keys = ("fwd_mlp",) if a.stage == "fwd" else ("dgrad", "wgrad", "comp_bwd")
+    timers = {k: StageTimer(k, pool=4096) for k in keys}
+    for t in timers.values():
+        t.reset(True)
+
+    def one():
+        for t in timers.values():
+            t.arm()
+        if a.stage == "fwd":
+            # same workspace every time: allocate-free loop
+            lib_res, _ = render._run_forward(prob, streams, True, False, False, x3)
+        else:
+            render._run_backward(prob, streams, gout, ws, x3)
+
+    one()
+    torch.cuda.synchronize()
+    n = 0
+    with ClockProbe(dev) as probe:
+        t0 = time.time()
+        while time.time() - t0 < a.seconds:
+            one()
+            n += 1
+            if n % 8 == 0:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+    clocks = probe.mhz()
+    out = []
+    for k, t in timers.items():
+        ms = t.collect()
+        if ms:
+            ms = ms[1:]
+            out.append("%s %.3f ms (n=%d) %s MHz" % (k, sum(ms) / len(ms), len(ms), round(clocks.get(k, 0))))
+    print("stage_loop %s %s %d rays: %d calls in %.1f s; %s" % (a.stage, a.precision, a.rays, n, a.seconds, "; ".join(out)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
