@@ -63,7 +63,10 @@ def parse():
     ap.add_argument("--mode", choices=("fwd", "fwdbwd"), default=os.environ.get("GNR_BENCH_MODE", "fwdbwd"))
     ap.add_argument("--side", type=int, default=512, help="cfg2b: rays per image = side^2")
     ap.add_argument("--samples", type=int, default=64)
-    ap.add_argument("--micro", type=int, default=16384, help="cfg2b fwdbwd: rays per micro-batch")
+    ap.add_argument("--micro", type=int, default=32768,
+                    help="cfg2b fwdbwd: rays per tile of the tiled training entry point (forward-with-save, loss, backward per tile). "
+                         "32768 rays keep 66 GB of activations + 33 GB of backward scratch resident (of 288 GB); rounds 1-3 used "
+                         "16384: the larger tile halves the per-launch ramps and tails (+1 % on the step, profiles/r4_micro_sweep.txt)")
     ap.add_argument("--precision", choices=("fp32", "bf16x3"), default=os.environ.get("GNR_BENCH_PRECISION", "fp32"),
                     help="fp32: exact fp32 MFMA everywhere; bf16x3: dense layers on bf16 MFMA with a "
                          "3-term hi/lo split (fp32 accumulate)")
@@ -489,11 +492,15 @@ def run_cfg2b(ctx):
         x3 = precision == "bf16x3"
         peak = PEAK_BF16X3_TFLOPS if x3 else PEAK_FP32_MFMA_TFLOPS
         ms = dt / args.steps * 1e3
-        rays_per_launch = micro if fwdbwd else n_local
+        launches_per_step = (n_local + micro - 1) // micro if fwdbwd else 1
+        # a ragged last tile (micro does not divide the image) makes the timed launches unequal: the stage rates are then
+        # total FLOPs / total time, i.e. priced on the MEAN launch (rays_per_launch is fractional in that case only)
+        rays_per_launch = n_local / launches_per_step if fwdbwd else n_local
+        if rays_per_launch == int(rays_per_launch):
+            rays_per_launch = int(rays_per_launch)
         m = rays_per_launch * n_p                                  # samples per launch (per stream)
         flop_2s = m * 2 * FLOP_PER_SAMPLE_STREAM                   # both streams, one pass
         flop_1s = m * FLOP_PER_SAMPLE_STREAM
-        launches_per_step = (n_local + micro - 1) // micro if fwdbwd else 1
         sfx = chain_suffix(x3)
         save = "true" if fwdbwd else "false"
         defs = [("fwd_mlp", "forward%s: march + encode + 2-stream MLP + composite" % (" with activation save" if fwdbwd else ""),

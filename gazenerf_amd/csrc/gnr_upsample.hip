@@ -94,27 +94,52 @@ __global__ __launch_bounds__(256) void blur_kernel(const float* __restrict__ in,
 }
 
 // bilinear x2, align_corners=False: out[2m] = .25 in[m-1] + .75 in[m] (m = 0: in[0]); out[2m+1] = .75 in[m] + .25 in[m+1]
-__global__ __launch_bounds__(256) void bilinear2x_kernel(const float* __restrict__ in, float* __restrict__ out, long planes,
-                                                         int H, int W) {
+// blur(bilinear2x(in)) in one pass for the 3-channel RGB branch of the forward (neural_renderer.py:104-112: rgb_upsample =
+// Upsample(scale 2, bilinear) + Blur): a thread = 4 consecutive pixels of an output row; the 3 x 6 bilinear values it needs
+// are built from the (tiny, cached) input (taps as in the comment above) and combined with blur_kernel's expression (rows first),
+// the 2S x 2S intermediate is never written (rounds 1-3: bilinear2x_kernel + blur_kernel).  in != out.
+__global__ __launch_bounds__(256) void bilinear_blur_kernel(const float* __restrict__ in, float* __restrict__ out, long planes,
+                                                            int H, int W) {
     const int H2 = 2 * H, W2 = 2 * W;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= planes * H2 * W2) return;
-    const int ox = (int)(idx % W2), oy = (int)((idx / W2) % H2);
-    const float* p = in + (idx / ((long)H2 * W2)) * ((long)H * W);
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= planes * H2 * (W2 / 4)) return;
+    const int xq = (int)(q % (W2 / 4)), y = (int)((q / (W2 / 4)) % H2);
+    const int x = 4 * xq;
+    const long plane = q / ((long)(W2 / 4) * H2);
+    const float* p = in + plane * ((long)H * W);
     auto taps = [](int o, int n, int& i0, int& i1, float& w0, float& w1) {
         const int m = o >> 1;
         if (o & 1) { i0 = m; i1 = m + 1 < n ? m + 1 : m; w0 = 0.75f; w1 = 0.25f; }
         else { i0 = m >= 1 ? m - 1 : 0; i1 = m; w0 = m >= 1 ? 0.25f : 0.0f; w1 = m >= 1 ? 0.75f : 1.0f; }
     };
-    int x0, x1, y0, y1;
-    float wx0, wx1, wy0, wy1;
-    taps(ox, W, x0, x1, wx0, wx1);
-    taps(oy, H, y0, y1, wy0, wy1);
-    out[idx] = wy0 * (wx0 * p[(long)y0 * W + x0] + wx1 * p[(long)y0 * W + x1]) +
-               wy1 * (wx0 * p[(long)y1 * W + x0] + wx1 * p[(long)y1 * W + x1]);
+    const int xm = x >= 1 ? x - 1 : x, xp = x + 4 < W2 ? x + 4 : x + 3;
+    int cx0[6], cx1[6];
+    float cw0[6], cw1[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) taps(e == 0 ? xm : (e == 5 ? xp : x + e - 1), W, cx0[e], cx1[e], cw0[e], cw1[e]);
+    float yl, yc, yr, wl[4], wc[4], wr[4];
+    blur_taps(y, H2, false, yl, yc, yr);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) blur_taps(x + e, W2, false, wl[e], wc[e], wr[e]);
+    const int ys[3] = {y >= 1 ? y - 1 : y, y, y + 1 < H2 ? y + 1 : y};
+    f32x4 rows[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        int y0, y1;
+        float wy0, wy1;
+        taps(ys[r], H, y0, y1, wy0, wy1);
+        const float* r0 = p + (long)y0 * W;
+        const float* r1 = p + (long)y1 * W;
+        float u[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e)
+            u[e] = wy0 * (cw0[e] * r0[cx0[e]] + cw1[e] * r0[cx1[e]]) + wy1 * (cw0[e] * r1[cx0[e]] + cw1[e] * r1[cx1[e]]);
+        rows[r] = f32x4{wl[0] * u[0] + wc[0] * u[1] + wr[0] * u[2], wl[1] * u[1] + wc[1] * u[2] + wr[1] * u[3],
+                        wl[2] * u[2] + wc[2] * u[3] + wr[2] * u[4], wl[3] * u[3] + wc[3] * u[4] + wr[3] * u[5]};
+    }
+    *(f32x4*)(out + plane * ((long)H2 * W2) + (long)y * W2 + x) = yl * rows[0] + yc * rows[1] + yr * rows[2];
 }
 
-// adjoint: din[m] = sum_o w(o,m) dout[o] with o in {2m-1, 2m, 2m+1, 2m+2}
 __global__ __launch_bounds__(256) void bilinear2x_adj_kernel(const float* __restrict__ dout, float* __restrict__ din,
                                                              long planes, int H, int W) {
     const int H2 = 2 * H, W2 = 2 * W;
@@ -209,6 +234,60 @@ static int rgbf_channel_groups(long nwg, int C) {          // ~1024 workgroups i
     long g = (1024 + nwg - 1) / nwg;
     if (g > C / 8) g = C / 8;
     return g < 1 ? 1 : (int)g;
+}
+
+// The same product for SMALL maps (batch * P <= 32 768 pixels: the 64 x 64 level, where 4096 threads walking 258 channels
+// each were 33 dependent load rounds = 18.6 us of a 0.4 ms inference forward): a workgroup owns 64 pixels, its four waves a
+// quarter of the channels each (in-order fmaf chains), partial sums combined through LDS in wave order -- deterministic;
+// differs from rgb_conv_kernel by summation order only.
+__global__ __launch_bounds__(256) void rgb_conv_split_kernel(const float* __restrict__ net, int C, long P, int batch,
+                                                             const float* __restrict__ w, const float* __restrict__ bias,
+                                                             float* __restrict__ rgb, int accumulate, float* __restrict__ img,
+                                                             float* __restrict__ out) {
+    __shared__ float part[4][3][64];
+    const int px = threadIdx.x & 63, cq = threadIdx.x >> 6;
+    const long idx = (long)blockIdx.x * 64 + px;
+    const bool live = idx < (long)batch * P;
+    const long b = live ? idx / P : 0, p = live ? idx - b * P : 0;
+    const float* np = net + b * C * P + p;
+    const int cper = (C + 3) / 4, c0 = cq * cper, c1 = c0 + cper < C ? c0 + cper : C;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+    int c = c0;
+    for (; c + 8 <= c1; c += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = np[(long)(c + u) * P];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a0 = fmaf(w[c + u], v[u], a0);
+            a1 = fmaf(w[C + c + u], v[u], a1);
+            a2 = fmaf(w[2 * C + c + u], v[u], a2);
+        }
+    }
+    for (; c < c1; ++c) {
+        const float v = np[(long)c * P];
+        a0 = fmaf(w[c], v, a0);
+        a1 = fmaf(w[C + c], v, a1);
+        a2 = fmaf(w[2 * C + c], v, a2);
+    }
+    part[cq][0][px] = a0; part[cq][1][px] = a1; part[cq][2][px] = a2;
+    __syncthreads();
+    if (cq != 0 || !live) return;
+    a0 = bias[0] + ((part[0][0][px] + part[1][0][px]) + (part[2][0][px] + part[3][0][px]));
+    a1 = bias[1] + ((part[0][1][px] + part[1][1][px]) + (part[2][1][px] + part[3][1][px]));
+    a2 = bias[2] + ((part[0][2][px] + part[1][2][px]) + (part[2][2][px] + part[3][2][px]));
+    float* rp = rgb + b * 3 * P + p;
+    if (accumulate) { a0 += rp[0]; a1 += rp[P]; a2 += rp[2 * P]; }
+    rp[0] = a0; rp[P] = a1; rp[2 * P] = a2;
+    if (img) {
+        float* ip = img + b * 3 * P + p;
+        a0 = 1.0f / (1.0f + expf(-a0)); a1 = 1.0f / (1.0f + expf(-a1)); a2 = 1.0f / (1.0f + expf(-a2));
+        ip[0] = a0; ip[P] = a1; ip[2 * P] = a2;
+    }
+    if (out) {
+        float* op = out + b * 3 * P + p;
+        op[0] = a0; op[P] = a1; op[2 * P] = a2;
+    }
 }
 
 __global__ __launch_bounds__(256) void rgb_bwd_fused_kernel(const float* __restrict__ drgb, const float* __restrict__ net, int C,
@@ -692,11 +771,20 @@ static int check_up_weights(const GnrUpsampleWeights* w, int n_blocks) {
     return 0;
 }
 
-// rgb <- blur(bilinear2x(rgb_in)) for 3-channel images at side S -> 2S; tmp holds the bilinear result
-static void up_rgb(const float* in, float* tmp, float* out, int batch, int S, hipStream_t st) {
+static void launch_rgb_conv(const float* net, int C, long P, int batch, const float* w, const float* bias, float* rgb,
+                            int accumulate, float* img, float* out, hipStream_t st) {
+    if ((long)batch * P <= 32768 && C >= 32)
+        hipLaunchKernelGGL(rgb_conv_split_kernel, dim3((unsigned)(((long)batch * P + 63) / 64)), dim3(256), 0, st, net, C, P, batch, w,
+                           bias, rgb, accumulate, img, out);
+    else
+        hipLaunchKernelGGL(rgb_conv_kernel, dim3(blocks_for((long)batch * P)), dim3(256), 0, st, net, C, P, batch, w, bias, rgb,
+                           accumulate, img, out);
+}
+
+// out <- blur(bilinear2x(in)) for 3-channel images at side S -> 2S, one kernel (round 4; two before)
+static void up_rgb(const float* in, float* out, int batch, int S, hipStream_t st) {       // in != out
     const long planes = (long)batch * 3;
-    hipLaunchKernelGGL(bilinear2x_kernel, dim3(blocks_for(planes * 4L * S * S)), dim3(256), 0, st, in, tmp, planes, S, S);
-    hipLaunchKernelGGL(blur_kernel, dim3(blocks_for(planes * 4L * S * S / 4)), dim3(256), 0, st, tmp, out, planes, 2 * S, 2 * S, 0);
+    hipLaunchKernelGGL(bilinear_blur_kernel, dim3(blocks_for(planes * 4L * S * S / 4)), dim3(256), 0, st, in, out, planes, S, S);
 }
 
 }  // namespace gnr
@@ -731,9 +819,8 @@ int gnr_upsample_fwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, f
     // rgb = up(conv_rgb0(x))
     {
         const long P = (long)d.side[0] * d.side[0];
-        hipLaunchKernelGGL(rgb_conv_kernel, dim3(blocks_for((long)B * P)), dim3(256), 0, st, p->x, d.ch[0], P, B, w->rgb_w[0],
-                           w->rgb_b[0], s.rgb_a, 0, (float*)nullptr, (float*)nullptr);
-        up_rgb(s.rgb_a, s.rgb_b, s.rgb_a, B, d.side[0], st);          // in -> tmp -> out: in may be overwritten
+        launch_rgb_conv(p->x, d.ch[0], P, B, w->rgb_w[0], w->rgb_b[0], s.rgb_a, 0, nullptr, nullptr, st);
+        up_rgb(s.rgb_a, s.rgb_b, B, d.side[0], st);
     }
     BlockPlans bp[UP_MAX];
     Conv16PackJobs jobs;
@@ -741,8 +828,8 @@ int gnr_upsample_fwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, f
     jobs.dst = s.pack;
     launch_conv16_pack(jobs, st);                 // every weight matrix of the call, one launch
     const float* net = p->x;
-    float* rgb = s.rgb_a;
-    float* rgb_tmp = s.rgb_b;
+    float* rgb = s.rgb_b;             // the running RGB image ping-pongs between the two scratch images
+    float* rgb_other = s.rgb_a;
     for (int i = 0; i < d.n_blocks; ++i) {
         const int C = d.ch[i], Cn = d.ch[i + 1], S = d.side[i];
         const long P = (long)S * S;
@@ -771,10 +858,12 @@ int gnr_upsample_fwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, f
         if (launch_conv16(g, st)) return 1;
         // rgb += conv_rgb(i+1)(net');  last block: img = sigmoid(rgb) (or rgb itself), also straight into the caller's image
         const bool last = i == d.n_blocks - 1;
-        hipLaunchKernelGGL(rgb_conv_kernel, dim3(blocks_for((long)B * 4 * P)), dim3(256), 0, st, s.net[i], Cn, 4 * P, B,
-                           w->rgb_w[i + 1], w->rgb_b[i + 1], rgb, 1, last && p->final_sigmoid ? s.img : (float*)nullptr,
-                           last ? img : (float*)nullptr);
-        if (!last) up_rgb(rgb, rgb_tmp, rgb, B, 2 * S, st);
+        launch_rgb_conv(s.net[i], Cn, 4 * P, B, w->rgb_w[i + 1], w->rgb_b[i + 1], rgb, 1, last && p->final_sigmoid ? s.img : nullptr,
+                        last ? img : nullptr, st);
+        if (!last) {
+            up_rgb(rgb, rgb_other, B, 2 * S, st);
+            float* t = rgb; rgb = rgb_other; rgb_other = t;
+        }
         net = s.net[i];
     }
     const hipError_t e = hipGetLastError();

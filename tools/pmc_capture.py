@@ -49,7 +49,7 @@ def main():
         mode = args[args.index("--mode") + 1]
     side = int(args[args.index("--side") + 1]) if "--side" in args else 512
     samples = int(args[args.index("--samples") + 1]) if "--samples" in args else 64
-    micro = int(args[args.index("--micro") + 1]) if "--micro" in args else 16384
+    micro = int(args[args.index("--micro") + 1]) if "--micro" in args else 32768          # bench.py's default tile
     rays = min(micro, side * side) if mode == "fwdbwd" else side * side
     outdir = os.path.join(ROOT, "gpurun_out", out_name)
     os.makedirs(outdir, exist_ok=True)

@@ -5,7 +5,8 @@
     python tools/stage_loop.py fwd|bwd [--seconds 12] [--rays 16384] [--precision fp32|bf16x3]
 
 fwd: gnr_fwd with save_for_backward (fwd16_kernel<true> + combine) over and over in one workspace;
-bwd: gnr_bwd over and over on one saved workspace (comp_bwd + dgrad chain + weight gradients, both streams).
+bwd: gnr_bwd over and over on one saved workspace (comp_bwd + dgrad chain + weight gradients, both streams);
+alt: forward, backward, forward, ... as a training loop issues them.
 Prints the stage's HIP-event time and the in-kernel clock probe."""
 import argparse
 import os
@@ -21,7 +22,7 @@ from gazenerf_amd.hiptime import ClockProbe, StageTimer                  # noqa:
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("stage", choices=("fwd", "bwd"))
+    ap.add_argument("stage", choices=("fwd", "bwd", "alt"))
     ap.add_argument("--seconds", type=float, default=12.0)
     ap.add_argument("--rays", type=int, default=16384)
     ap.add_argument("--precision", default="fp32")
@@ -38,7 +39,7 @@ def main():
     os.environ["GNR_BINDING"] = "ctypes"
     res, ws = render._run_forward(prob, streams, True, False, False, x3)
     gout = [(torch.randn_like(r[0]) * 1e-3, torch.randn_like(r[1]) * 1e-3) for r in res]
-    keys = ("fwd_mlp",) if a.stage == "fwd" else ("dgrad", "wgrad", "comp_bwd")
+    keys = ("fwd_mlp",) if a.stage == "fwd" else (("dgrad", "wgrad", "comp_bwd") if a.stage == "bwd" else ("fwd_mlp", "dgrad", "wgrad"))
     timers = {k: StageTimer(k, pool=4096) for k in keys}
     for t in timers.values():
         t.reset(True)
@@ -46,11 +47,11 @@ def main():
     def one():
         for t in timers.values():
             t.arm()
-        if a.stage == "fwd":
-            # same workspace every time: allocate-free loop
-            lib_res, _ = render._run_forward(prob, streams, True, False, False, x3)
-        else:
-            render._run_backward(prob, streams, gout, ws, x3)
+        if a.stage in ("fwd", "alt"):
+            # (the caching allocator hands the same workspace back every time)
+            lib_res, ws2 = render._run_forward(prob, streams, True, False, False, x3)
+        if a.stage in ("bwd", "alt"):
+            render._run_backward(prob, streams, gout, ws2 if a.stage == "alt" else ws, x3)
 
     one()
     torch.cuda.synchronize()
