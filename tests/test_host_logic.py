@@ -89,3 +89,72 @@ def test_hot_path_renderer_drops_its_caches_when_parameters_can_change():
         net._wcache.shape_key, net._wcache.ws = ("x",), torch.zeros(1)
         poke()
         assert net._wcache.ws is None and net._wcache.shape_key is None
+
+
+def test_tiled_training_entry_accumulates_like_one_backward(monkeypatch):
+    """render_two_stream_tiled's gradient plumbing, with the HIP op replaced by a small differentiable stand-in (CPU): the
+    op's inputs enter the tiles as detached proxies, per-tile gradients are summed with multi-tensor adds and pushed into the
+    real inputs once -- leaves get .grad, NON-leaf inputs propagate upstream, parameters owned by the loss get theirs from
+    the per-tile backward, a second call accumulates on top (as loss.backward() would)."""
+    import torch
+    from gazenerf_amd import render
+
+    def fake(xy, R, T, Kinv, shape, gaze, appea, face, eyes=None, *, n_samples, t_rand=None, z_edges=None, ray_bias_face=None,
+             ray_bias_eyes=None, ray_tile=None, **kw):
+        assert ray_tile == xy.shape[2]
+        base = xy[:, :1] * R.sum() + xy[:, 1:] * T.sum() + (shape.sum() + gaze.sum() * 2 + appea.sum() * 3)
+        f = base * face["w"].sum() + face["b"].mean()
+        if t_rand is not None:
+            f = f + t_rand[:, :, 0].unsqueeze(1)
+        if ray_bias_face is not None:
+            f = f + ray_bias_face.sum(-1).unsqueeze(1)
+        return {"feat_face": f, "bg_alpha_face": torch.sigmoid(base)}
+
+    monkeypatch.setattr(render, "render_two_stream", fake)
+    monkeypatch.setattr(render, "plan_ray_tiles", lambda *a, **k: None)
+    torch.manual_seed(0)
+    B, n = 2, 37
+    xy = torch.randn(B, 2, n)
+    euler = torch.randn(B, 3, requires_grad=True)
+    T = torch.randn(B, 3, 1, requires_grad=True)
+    codes = [torch.randn(B, k, requires_grad=True) for k in (5, 2, 4)]
+    face = {"w": torch.randn(6, requires_grad=True), "b": torch.randn(3, requires_grad=True), "frozen": torch.randn(2)}
+    rb = torch.randn(B, n, 4, requires_grad=True)
+    t_rand = torch.rand(B, n, 9)
+    loss_w = torch.tensor(0.7, requires_grad=True)                 # a parameter of the LOSS, not of the op
+    target = torch.randn(B, 1, n)
+
+    def share(out, sl):
+        return loss_w * ((out["feat_face"] - target[:, :, sl]) ** 2).sum() / n + out["bg_alpha_face"].sum() / n
+
+    leaves = [euler, T] + codes + [face["w"], face["b"], rb, loss_w]
+
+    def run(tile):
+        for t in leaves:
+            t.grad = None
+        R = torch.stack([euler, euler * 2, euler ** 2], dim=1)      # NON-leaf input: its gradient must reach `euler`
+        total, outs = render.render_two_stream_tiled(xy, R, T, None, *codes, face, None, loss_fn=share, n_samples=8, ray_tile=tile,
+                                                     t_rand=t_rand, ray_bias_face=rb, return_outputs=True)
+        return float(total), outs, [t.grad.clone() for t in leaves]
+
+    t1, o1, g1 = run(n)            # one tile == plain backward
+    t2, o2, g2 = run(10)           # 10 + 10 + 10 + 7
+    assert abs(t1 - t2) <= 1e-4 * abs(t1)
+    for k in o1:
+        assert torch.allclose(o1[k], o2[k], atol=1e-6)
+    for a, b in zip(g1, g2):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
+    # plain autograd reference
+    for t in leaves:
+        t.grad = None
+    R = torch.stack([euler, euler * 2, euler ** 2], dim=1)
+    share(fake(xy, R, T, None, *codes, face, n_samples=8, t_rand=t_rand, ray_bias_face=rb, ray_tile=n), slice(0, n)).backward()
+    for a, t in zip(g1, leaves):
+        assert torch.allclose(a, t.grad, rtol=1e-5, atol=1e-6)
+    # accumulation on top of existing .grad, like loss.backward()
+    R = torch.stack([euler, euler * 2, euler ** 2], dim=1)
+    render.render_two_stream_tiled(xy, R, T, None, *codes, face, None, loss_fn=share, n_samples=8, ray_tile=10, t_rand=t_rand,
+                                   ray_bias_face=rb)
+    for a, t in zip(g1, leaves):
+        assert torch.allclose(2 * a, t.grad, rtol=1e-4, atol=1e-5)
+    assert face["frozen"].grad is None
