@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=12.0)
     ap.add_argument("--rays", type=int, default=16384)
     ap.add_argument("--precision", default="fp32")
+    ap.add_argument("--nosave", action="store_true", help="fwd: the inference kernel (fwd16_kernel<false>), no dumps")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     x3 = a.precision == "bf16x3"
@@ -49,7 +50,7 @@ def main():
             t.arm()
         if a.stage in ("fwd", "alt"):
             # (the caching allocator hands the same workspace back every time)
-            lib_res, ws2 = render._run_forward(prob, streams, True, False, False, x3)
+            lib_res, ws2 = render._run_forward(prob, streams, not a.nosave, False, False, x3)
         if a.stage in ("bwd", "alt"):
             render._run_backward(prob, streams, gout, ws2 if a.stage == "alt" else ws, x3)
 
@@ -71,6 +72,8 @@ def main():
         if ms:
             ms = ms[1:]
             out.append("%s %.3f ms (n=%d) %s MHz" % (k, sum(ms) / len(ms), len(ms), round(clocks.get(k, 0))))
+    if a.nosave:
+        a.stage += " (inference kernel)"
     print("stage_loop %s %s %d rays: %d calls in %.1f s; %s" % (a.stage, a.precision, a.rays, n, a.seconds, "; ".join(out)), flush=True)
 
 
