@@ -99,9 +99,15 @@ __device__ __forceinline__ int enc16_slot_rt(int idx, int g) {
 // ---- weight stream: rows of 1 KiB (64 lanes x float4 = the A fragments of 4 MFMAs), batches of 4 ---------------
 constexpr int WB16 = 4;
 #ifndef GNR_DUMP_BURST
-#define GNR_DUMP_BURST 1
+#define GNR_DUMP_BURST_DEFAULT 8
+#else
+#define GNR_DUMP_BURST_DEFAULT GNR_DUMP_BURST
 #endif
-constexpr int DUMP_BURST = GNR_DUMP_BURST;      // dump stores per burst (1 = one store every NROW / NREG rows)
+// dump stores per burst (1 = one store every NROW / NREG rows).  Round 3 (half-row stores): 1 was best.  Round 4, whole-line
+// stores (S16): bursts of 4-12 measure 0.5-0.9 % faster on the training forward and 0.2 % on the dgrad chain
+// (profiles/r4_dump_burst.txt: the store queue takes a burst of full lines without stalling the issue, and fewer, longer
+// interruptions of the MFMA stream cost less than many short ones); 8 is the default.
+constexpr int DUMP_BURST = GNR_DUMP_BURST_DEFAULT;
 struct WStream16 {
     __amdgpu_buffer_rsrc_t rs;
     unsigned voff;               // lane * 16 (constant)
@@ -142,6 +148,14 @@ __device__ __forceinline__ void wstream16_init(WStream16& w, const float* packed
 // the FIRST round that land in an odd wave slot sleep ~25 us once; every later workgroup inherits the offset of the slot
 // it takes over.  (HW_ID bits 3:0 = wave slot within the SIMD.)
 __device__ __forceinline__ void dephase_first_round(unsigned linear_block) {
+#ifdef GNR_RAMP_SLEEPS      /* timing experiment (round 4): does a staggered start of the first round (workgroup b waits
+                               b / 512 of GNR_RAMP_SLEEPS x 3.4 us) avoid the clock dip a backward -> forward power step causes? */
+    if (linear_block < 512u) {
+        const unsigned n = (linear_block * (unsigned)(GNR_RAMP_SLEEPS)) >> 9;
+#pragma unroll 1
+        for (unsigned i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
 #ifndef GNR_NO_DEPHASE
     if (linear_block < 512u) {                          // 2 workgroups x 256 CUs
         unsigned hw;
