@@ -1110,6 +1110,41 @@ def test_narrow_network_vs_oracle_live(hidden, precision):
         _grads_hip(p, big, big, 40, t_rand, dev, precision, hidden=386)
 
 
+@pytest.mark.parametrize("feat_nc", [6, 192, 195, 288])
+def test_other_feature_widths_vs_oracle_live(feat_nc):
+    """feat_nc other than the reference's 258 (opt.featmap_nc: any value 4..288 here; 3 would switch the reference to its
+    sigmoid RGB head, mlp_nerf.py:116).  Round 4 computes RGB_layer_2's weight gradient as a full 192-row tile plus a
+    remainder whenever feat_nc > 192: 192 (no remainder, the one-product path), 195 (3 remainder rows), 288 (the whole padded
+    width) and a tiny head, forward + all gradients against the oracle."""
+    dev = _dev()
+    p = synth.synth_problem(64, batch=2, camera="5", seed=17, ray_subset=torch.arange(23) * 173 % 4096)
+    face = synth.hash_mlp_params("face", seed=6, feat_nc=feat_nc, density_scale=8.0)
+    eyes = synth.hash_mlp_params("eyes", seed=6, feat_nc=feat_nc, density_scale=8.0)
+    t_rand = synth.synth_jitter(2, 23, 64, seed=4)
+    leaves = {k: p[k].clone().requires_grad_(True) for k in ("R", "T", "shape_code", "gaze", "appea_code")}
+    fo = {k: v.clone().requires_grad_(True) for k, v in face.items()}
+    eo = {k: v.clone().requires_grad_(True) for k, v in eyes.items()}
+    ref = O.render_two_stream(p["xy"], leaves["R"], leaves["T"], p["Kinv"], leaves["shape_code"], leaves["gaze"],
+                              leaves["appea_code"], fo, eo, 64, t_rand=t_rand)
+    O.synthetic_loss(ref).backward()
+    pd = _to(p, dev)
+    hl = {k: pd[k].clone().requires_grad_(True) for k in leaves}
+    fp = {k: v.to(dev).clone().requires_grad_(True) for k, v in face.items()}
+    ep = {k: v.to(dev).clone().requires_grad_(True) for k, v in eyes.items()}
+    out = render.render_two_stream(pd["xy"], hl["R"], hl["T"], pd["Kinv"], hl["shape_code"], hl["gaze"], hl["appea_code"], fp, ep,
+                                   n_samples=64, t_rand=t_rand.to(dev), feat_nc=feat_nc)
+    sum((out["feat_" + t] ** 2).mean() + out["bg_alpha_" + t].mean() for t in ("face", "eyes")).backward()
+    for tag in ("face", "eyes"):
+        assert tuple(out["feat_" + tag].shape) == (2, feat_nc, 23)
+        assert _maxabs(out["feat_" + tag], ref["feat_" + tag]) <= TOL
+        assert _maxabs(out["bg_alpha_" + tag], ref["bg_alpha_" + tag]) <= TOL
+    for k in leaves:
+        _check_grad("d" + k, hl[k].grad, leaves[k].grad)
+    for got, want in ((fp, fo), (ep, eo)):
+        for name in want:
+            _check_grad(name, got[name].grad, want[name].grad)
+
+
 def _vd_weights(g):
     ds, seed = float(g["density_scale"]), int(g["weight_seed"])
     vd_ch = int(g["vd_dims"]) + synth.APPEA_DIMS
