@@ -148,14 +148,6 @@ __device__ __forceinline__ void wstream16_init(WStream16& w, const float* packed
 // the FIRST round that land in an odd wave slot sleep ~25 us once; every later workgroup inherits the offset of the slot
 // it takes over.  (HW_ID bits 3:0 = wave slot within the SIMD.)
 __device__ __forceinline__ void dephase_first_round(unsigned linear_block) {
-#ifdef GNR_RAMP_SLEEPS      /* timing experiment (round 4): does a staggered start of the first round (workgroup b waits
-                               b / 512 of GNR_RAMP_SLEEPS x 3.4 us) avoid the clock dip a backward -> forward power step causes? */
-    if (linear_block < 512u) {
-        const unsigned n = (linear_block * (unsigned)(GNR_RAMP_SLEEPS)) >> 9;
-#pragma unroll 1
-        for (unsigned i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
 #ifndef GNR_NO_DEPHASE
     if (linear_block < 512u) {                          // 2 workgroups x 256 CUs
         unsigned hw;
