@@ -352,10 +352,13 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv16_kernel(const Conv16Params 
 }
 
 std::atomic<int> g_forced_tile{0};          // 100 MT + NT, 0 = cost model (gnr_set_conv16_tile)
-struct Variant { int MT, NT; bool blur; };
+struct Variant { int MT, NT; bool blur; bool small_only; };      // small_only: chosen by the cost model only for small problems
 // (row tiles, pixel tiles) instances; blur: the instance that reads B through the stencil exists (register budget)
 // (ties in the cost model go to the earlier entry: the smaller tiles, which measured equal or better -- DESIGN.md 3.5)
-const Variant kVariants[] = {{2, 4, true}, {4, 4, true}, {8, 4, false}, {9, 2, true}, {11, 2, false}, {13, 2, false}};
+// (round 4: 2x2 and 4x2 for SMALL problems -- a B = 1 inference launches about one 2x4 wave per SIMD and is latency-bound; half
+// the pixels per wave doubles the waves.  Last in the list: they only win where the cost model's whole rounds make them cheaper.)
+const Variant kVariants[] = {{2, 4, true, false}, {4, 4, true, false}, {8, 4, false, false}, {9, 2, true, false}, {11, 2, false, false},
+                             {13, 2, false, false}, {2, 2, true, true}, {4, 2, true, true}};
 
 template <int MT, int NT>
 void launch_variant(const Conv16Params& cp, unsigned blocks, hipStream_t st) {
@@ -374,9 +377,12 @@ int conv16_set_tile(int mt, int nt) {
     if (mt == 0 && nt == 0) { g_forced_tile = 0; return 0; }
     for (const Variant& v : kVariants)
         if (v.MT == mt && v.NT == nt) { g_forced_tile = 100 * mt + nt; return 0; }
-    return fail("gnr_set_conv16_tile: no GEMM instance with %d row tiles x %d pixel tiles (have 2x4, 4x4, 8x4, 9x2, 11x2, 13x2; "
+    return fail("gnr_set_conv16_tile: no GEMM instance with %d row tiles x %d pixel tiles (have 2x4, 4x4, 8x4, 9x2, 11x2, 13x2, 2x2, 4x2; "
                 "0, 0 restores the cost model)", mt, nt);
 }
+
+// the half-width tiles pay only where a launch has about one 2x4 wave per SIMD or less (set from profiles/r4_n1_small_tiles.txt)
+static bool conv16_small_ok(long pixels_total) { return false && pixels_total <= 0; }
 
 Conv16Plan conv16_plan(int M, int K, long pixels_total, int blur_w) {
     const int tiles = (M + 15) / 16;
@@ -389,6 +395,7 @@ Conv16Plan conv16_plan(int M, int K, long pixels_total, int blur_w) {
     for (const Variant& v : kVariants) {
         if (blur_w && (!v.blur || blur_w % (16 * v.NT))) continue;      // a wave's pixels must lie in one image row
         if (fmt && (v.MT != fmt || v.NT != fnt)) continue;
+        if (!fmt && v.small_only && !conv16_small_ok(pixels_total)) continue;
         const int slices = (tiles + v.MT - 1) / v.MT;
         const double waves = (double)slices * (double)(pixels_total / (16 * v.NT));
         // two waves share a SIMD's matrix pipe: below 1024 waves the chip is not full and a wave's length is the time
@@ -438,6 +445,8 @@ int launch_conv16(const Conv16Params& cp, hipStream_t st) {
         case 84: launch_variant<8, 4>(cp, blocks, st); break;
         case 44: launch_variant_blur<4, 4>(cp, blocks, st); break;
         case 24: launch_variant_blur<2, 4>(cp, blocks, st); break;
+        case 22: launch_variant_blur<2, 2>(cp, blocks, st); break;
+        case 42: launch_variant_blur<4, 2>(cp, blocks, st); break;
         default: return fail("conv16: no instance for MT = %d, NT = %d", cp.plan.MT, cp.plan.NT);
     }
     return 0;

@@ -9,7 +9,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
 # iteration starts: the rgb_conv_kernel launch on the input feature map (the smallest grid of that kernel)
 gx = [int(r.get("Grid_Size_X", r.get("Grid_Size", 0))) for r in rows]
-rgb = [i for i, n in enumerate(names) if "rgb_conv_kernel" in n]
+rgb = [i for i, n in enumerate(names) if "rgb_conv_kernel" in n or "rgb_conv_split_kernel" in n]
 gmin = min(gx[i] for i in rgb) if rgb else 0
 starts = [i for i in rgb if gx[i] == gmin]
 s = starts[-1] if starts else 0
