@@ -20,6 +20,10 @@ struct Conv16Plan {
 // feat_layers); only some variants have that instance -- plan.MT == 0 on return means "none fits, run the stencil as
 // its own kernel".
 Conv16Plan conv16_plan(int M, int K, long pixels_total, int blur_w);
+// The variant for du = Wf^T g with the un-shuffle fused into its epilogue (NT == 8: a lane owns the 2 x 2 blocks of two
+// adjacent low-resolution pixels).  MT == 0 on return: not available (M % 4, side % 32, or a tile pinned by
+// gnr_set_conv16_tile) -- run the plain GEMM and the un-shuffle kernel.
+Conv16Plan conv16_plan_unshuffle(int M, int K, int side);
 
 constexpr int CONV16_MAX_JOBS = 12;
 struct Conv16PackJobs {
@@ -27,12 +31,13 @@ struct Conv16PackJobs {
     struct Job {
         const float* W; long rs, cs;      // A(m,k) = W[m*rs + k*cs]
         int M, K, MT, nkb, slices;
+        int perm4;                        // packed row r holds A row (r >> 2) + (r & 3) * (M / 4)   (conv16_plan_unshuffle)
         long dst_off, floats;             // into `dst`
     } j[CONV16_MAX_JOBS];
     float* dst;
 };
 // Adds a job; returns the offset (floats) of its packed operand inside the pack buffer.
-long conv16_add_job(Conv16PackJobs& jobs, const float* W, long rs, long cs, int M, int K, const Conv16Plan& plan);
+long conv16_add_job(Conv16PackJobs& jobs, const float* W, long rs, long cs, int M, int K, const Conv16Plan& plan, int perm4 = 0);
 void launch_conv16_pack(const Conv16PackJobs& jobs, hipStream_t st);      // ONE launch for every GEMM of a call
 
 struct Conv16Params {
@@ -49,6 +54,19 @@ struct Conv16Params {
     const float* res; long res_batch;              // residual res(b, m % (M/4), n)
     unsigned char* sign_out; long sign_batch;      // shuffle: bit e of byte (b, m/4, n) = (acc + bias > 0) of channel 4(m/4)+e
     int blur, H;                                   // B operand = blur(B) with reflect padding, image H x W (W above)
+    // plan.NT == 8 (conv16_plan_unshuffle): the adjoint of the PixelShuffleUpsample tail in the epilogue.  M = C out-channels
+    // of the shuffled map, B = g [K][2W x 2W] (P = 4 W W), rows packed with perm4;  C = dpre2 [4 C][W x W]:
+    //   dpre2(4c + 2i + j, y, x) = du(c, 2y + i, 2x + j) * (bit 2i + j of sign_in(c, y, x) ? 1 : 0.2),
+    //   dres(c', y, x) = sum_q du((c' >> 2) + q C / 4, 2y + ((c' >> 1) & 1), 2x + (c' & 1))          (x.repeat adjoint)
+    const unsigned char* sign_in;                  // [batch][C][W*W] (sign_batch above)
+    float* dres; long dres_batch;
+    // plain epilogue with plan.slices == 1 (a wave holds every output channel of its pixels): the 3-channel RGB branch
+    // rides on it (round 4; rgb_conv_kernel re-read the whole block output for it) --
+    //   rgb(b,o,n) = [rgb(b,o,n) +] rgb_bias[o] + sum_m rgb_w[o][m] C(b,m,n);  rgb_img = sigmoid(rgb) if given;
+    //   rgb_out = rgb_img if given else rgb (the caller's image, last block)
+    const float* rgb_w; const float* rgb_bias;     // [3][M], [3]
+    float* rgb; int rgb_accumulate;                // [batch][3][P]
+    float* rgb_img; float* rgb_out;
 };
 int launch_conv16(const Conv16Params& cp, hipStream_t st);       // non-zero (+ gnr_last_error) when the plan names no instance
 int conv16_set_tile(int mt, int nt);                             // gnr_set_conv16_tile

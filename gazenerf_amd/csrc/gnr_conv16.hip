@@ -96,8 +96,9 @@ __global__ __launch_bounds__(256) void conv16_pack_kernel(const Conv16PackJobs j
     const int mt = (int)(r % J.MT); r /= J.MT;
     const int kb = (int)(r % J.nkb);
     const int slice = (int)(r / J.nkb);
-    const int m = 16 * (slice * J.MT + mt) + (lane & 15), k = 16 * kb + 4 * s + (lane >> 4);
-    jobs.dst[J.dst_off + i] = (m < J.M && k < J.K) ? J.W[(long)m * J.rs + (long)k * J.cs] : 0.0f;
+    const int row = 16 * (slice * J.MT + mt) + (lane & 15), k = 16 * kb + 4 * s + (lane >> 4);
+    const int m = J.perm4 ? (row >> 2) + (row & 3) * (J.M >> 2) : row;       // perm4: a lane's four rows are channels cb + q M/4
+    jobs.dst[J.dst_off + i] = (row < J.M && k < J.K) ? J.W[(long)m * J.rs + (long)k * J.cs] : 0.0f;
 }
 
 template <int MT, int NT, bool SHUF, bool BLUR>
@@ -118,6 +119,15 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv16_kernel(const Conv16Params 
     const int p0 = (int)(pixg - (unsigned)b * (unsigned)cp.P);    // the wave's first pixel inside image b
     const int nkb = cp.plan.nkb;
     const int m0 = ms * (16 * MT);
+    // the RGB branch's 3 x M weights wait in LDS for the epilogue (the only LDS of the kernel, one barrier at the start:
+    // fetched from memory in the epilogue their latency was exposed -- 307 instead of 241 us at 7 x 32 x 512 x 512)
+    __shared__ float rgbw[SHUF ? 1 : 3 * 16 * MT];
+    if constexpr (!SHUF) {
+        if (cp.rgb_w) {                                           // kernel argument: uniform
+            for (int i = (int)threadIdx.x; i < 3 * cp.M; i += 64 * WPB) rgbw[i] = cp.rgb_w[i];
+            __syncthreads();
+        }
+    }
 
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(cp.At + (long)ms * nkb * (MT * 256)), 0, nkb * (MT * 1024), 0x00020000);
@@ -324,6 +334,12 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv16_kernel(const Conv16Params 
             }
         }
     } else {
+        // the RGB branch on the block output (slices == 1): per lane the dot over its channels, then over the four lane groups
+        float ra[3][NT];
+#pragma unroll
+        for (int o = 0; o < 3; ++o)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) ra[o][t] = 0.0f;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -347,18 +363,182 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv16_kernel(const Conv16Params 
                 if (cp.accumulate && !(GNR_C16_ABL & 32)) v += *(const pv*)dst;
                 if ((GNR_C16_ABL & 64) && v[0] != 1.2345f) continue;
                 *(pv*)dst = v;
+                if (cp.rgb_w) {
+#pragma unroll
+                    for (int o = 0; o < 3; ++o) {
+                        const float wo = rgbw[o * cp.M + m];
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) ra[o][t] = fmaf(wo, v[t], ra[o][t]);
+                    }
+                }
             }
+        if (cp.rgb_w) {
+            // Sum over the four lane groups (rows of 16 lanes) with the gfx950 row / half swaps: for four values a, b, c, d
+            //   v_permlane16_swap(a, b) -> [a0 b0 a2 b2], [a1 b1 a3 b3]  (rows; sum = a01 b01 a23 b23)
+            //   v_permlane32_swap(sum_ab, sum_cd) -> [a01 b01 c01 d01], [a23 b23 c23 d23]  (sum: row g = total of value g)
+            // -- three swaps and three adds per four values, and row g of the wave ends up with value 4 k + g of group k:
+            // every lane finishes ONE pixel of up to three outputs (24 ds_bpermute + one lane group doing 12 sigmoids before).
+            auto sw16 = [](float x, float y) {
+                auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
+                const unsigned r0 = r[0], r1 = r[1];       // (bit_cast of a vector ELEMENT reads element 0 with this hipcc: scalars first)
+                return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+            };
+            auto sw32 = [](float x, float y) {
+                auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
+                const unsigned r0 = r[0], r1 = r[1];       // (bit_cast of a vector ELEMENT reads element 0 with this hipcc: scalars first)
+                return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+            };
+            constexpr int NV = 3 * NT, NG = (NV + 3) / 4;
+#pragma unroll
+            for (int k = 0; k < NG; ++k) {
+                float v4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v4[q] = 4 * k + q < NV ? ra[(4 * k + q) / NT][(4 * k + q) % NT] : 0.0f;
+                const float tot = sw32(sw16(v4[0], v4[1]), sw16(v4[2], v4[3]));
+                const int idx = 4 * k + g;
+                if (idx < NV) {
+                    const int o = idx / NT, t = idx - o * NT;
+                    const long off = ((long)b * 3 + o) * cp.P + n + t;
+                    float r = tot + cp.rgb_bias[o];
+                    if (cp.rgb_accumulate) r += cp.rgb[off];
+                    cp.rgb[off] = r;
+                    if (cp.rgb_img) {
+                        r = 1.0f / (1.0f + expf(-r));
+                        cp.rgb_img[off] = r;
+                    }
+                    if (cp.rgb_out) cp.rgb_out[off] = r;
+                }
+            }
+        }
+    }
+}
+
+// du = Wf^T g with the adjoint of the PixelShuffleUpsample tail in the epilogue (round 4; until then the GEMM wrote du
+// [C][2S x 2S] and unshuffle_bwd4_kernel read it back: 2 x 470 MB per 7 images at the 256 x 256 level).  NT = 8: a wave owns
+// one low-resolution row y and 32 columns, a lane the 2 x 2 blocks of TWO adjacent low-resolution pixels -- its B load per
+// k row is 4 consecutive pixels of image row 2y and of row 2y + 1 (two b128; 16 lanes = 256 contiguous bytes), pixel tile
+// t = 4 i + 2 xs + j is sub-pixel (i, j) of its pixel xs.  The rows are packed with perm4 (conv16_pack_kernel): register q of
+// a lane's accumulator quad is channel cb + q C/4, so the four terms of every x.repeat-adjoint sum
+//   dres(4 cb + e) = sum_q G(cb + q C/4, sub-pixel e)
+// sit in ONE lane (the same fixed order as unshuffle_bwd4_kernel: results are bit-identical to the two-kernel path), and
+// dpre2 = G * lrelu'(pre2) leaves as 8-byte stores (16 lanes = 128 contiguous bytes of one channel plane).
+template <int MT>
+__global__ __launch_bounds__(64 * WPB, 2) void conv16_unshuffle_kernel(const Conv16Params cp) {
+    constexpr int NT = 8;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int li = lane & 15, g = lane >> 4;
+    const int slices = cp.plan.slices;
+    const int S = cp.W, xchunks = S >> 5;                          // low-resolution side; 32-column chunks per row
+    const unsigned wave_items = (unsigned)cp.batch * (unsigned)(S * xchunks);
+    const unsigned items = (wave_items / WPB) * (unsigned)slices;
+    const unsigned per_xcd = (items + 7u) >> 3;
+    const unsigned item = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (item >= items) return;
+    const unsigned pt = item / (unsigned)slices;
+    const int ms = (int)(item - pt * (unsigned)slices);
+    const unsigned wi = pt * WPB + (unsigned)wave;                 // (image, row, chunk), chunk fastest
+    const int b = (int)(wi / (unsigned)(S * xchunks));
+    const int rem = (int)(wi - (unsigned)b * (unsigned)(S * xchunks));
+    const int y = rem / xchunks, xw = (rem - y * xchunks) << 5;
+    const int nkb = cp.plan.nkb;
+    const int m0 = ms * (16 * MT);
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(cp.At + (long)ms * nkb * (MT * 256)), 0, nkb * (MT * 1024), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(cp.B + (long)b * cp.b_batch), 0, (int)((long)cp.K * cp.P * 4), 0x00020000);
+    const unsigned voffA = (unsigned)lane * 16u;
+    const unsigned rowB = (unsigned)cp.P * 4u;                    // bytes per k row (P = 4 S S high-resolution pixels)
+    const int x0 = xw + 2 * li;                                   // the lane's two low-resolution pixels: x0, x0 + 1
+    unsigned voffB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) voffB[i] = ((unsigned)g * (unsigned)cp.P + (unsigned)((2 * y + i) * (2 * S) + 2 * x0)) * 4u;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[mt][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    f32x4 Aq[2][MT];
+    f32x4 Bq[2][4][2];
+    auto load_a = [&](int kb, f32x4 (&A)[MT]) {
+        const unsigned sa = (unsigned)__builtin_amdgcn_readfirstlane(kb * (MT * 1024));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            A[mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, voffA, (int)(sa + (unsigned)mt * 1024u), 0));
+    };
+    auto load_b = [&](int kb, f32x4 (&Bv)[4][2]) {
+        const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)kb * 16u * rowB));
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                Bv[s][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], (int)(sb + (unsigned)s * 4u * rowB), 0));
+    };
+    auto compute = [&](const f32x4 (&A)[MT], const f32x4 (&Bv)[4][2]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[mt][t] = mfma16c(A[mt][s], Bv[s][t >> 2][t & 3], acc[mt][t]);
+    };
+    load_b(0, Bq[0]);
+    load_a(0, Aq[0]);
+    int kb = 0;
+    for (; kb + 1 < nkb; kb += 2) {
+        load_b(kb + 1, Bq[1]);
+        load_a(kb + 1, Aq[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(Aq[0], Bq[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        const int k2 = kb + 2 < nkb ? kb + 2 : nkb - 1;
+        load_b(k2, Bq[0]);
+        load_a(k2, Aq[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(Aq[1], Bq[1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (nkb & 1) compute(Aq[0], Bq[0]);
+
+    // ---- epilogue: register q of acc[mt][4 i + 2 xs + j] is du(cb + q Cq, 2y + i, 2 (x0 + xs) + j) ----
+    const int Cq = cp.M >> 2;
+    const long Plo = (long)S * S;
+    const long pix = (long)y * S + x0;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int cb = (m0 >> 2) + 4 * mt + g;
+        if (cb >= Cq) continue;
+        f32x2 G[4][4];                                            // [q][sub-pixel e = 2 i + j] over the lane's two pixels
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = cb + q * Cq;
+            const unsigned nib2 = *(const unsigned short*)(cp.sign_in + (long)b * cp.sign_batch + (long)c * Plo + pix);
+            float* dst = cp.C + (long)b * cp.c_batch + (long)(4 * c) * Plo + pix;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                G[q][e] = f32x2{acc[mt][4 * (e >> 1) + (e & 1)][q], acc[mt][4 * (e >> 1) + 2 + (e & 1)][q]};
+                *(f32x2*)(dst + (long)e * Plo) = f32x2{G[q][e].x * (((nib2 >> e) & 1u) ? 1.0f : LEAK16),
+                                                       G[q][e].y * (((nib2 >> (8 + e)) & 1u) ? 1.0f : LEAK16)};
+            }
+        }
+        float* dr = cp.dres + (long)b * cp.dres_batch + (long)(4 * cb) * Plo + pix;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) *(f32x2*)(dr + (long)e * Plo) = (G[0][e] + G[1][e]) + (G[2][e] + G[3][e]);
     }
 }
 
 std::atomic<int> g_forced_tile{0};          // 100 MT + NT, 0 = cost model (gnr_set_conv16_tile)
-struct Variant { int MT, NT; bool blur; bool small_only; };      // small_only: chosen by the cost model only for small problems
+std::atomic<int> g_unshuffle_mt{0};         // row tiles of the fused un-shuffle GEMM pinned by gnr_set_conv16_tile(MT, 8); 0 = heuristic
+struct Variant { int MT, NT; bool blur; };
 // (row tiles, pixel tiles) instances; blur: the instance that reads B through the stencil exists (register budget)
 // (ties in the cost model go to the earlier entry: the smaller tiles, which measured equal or better -- DESIGN.md 3.5)
-// (round 4: 2x2 and 4x2 for SMALL problems -- a B = 1 inference launches about one 2x4 wave per SIMD and is latency-bound; half
-// the pixels per wave doubles the waves.  Last in the list: they only win where the cost model's whole rounds make them cheaper.)
-const Variant kVariants[] = {{2, 4, true, false}, {4, 4, true, false}, {8, 4, false, false}, {9, 2, true, false}, {11, 2, false, false},
-                             {13, 2, false, false}, {2, 2, true, true}, {4, 2, true, true}};
+// (round 4: half-width 2x2 / 4x2 instances were measured for the single-image forward and removed again -- a B = 1 GEMM is not
+// short of waves, profiles/r4_n1_small_tiles.txt)
+const Variant kVariants[] = {{2, 4, true}, {4, 4, true}, {8, 4, false}, {9, 2, true}, {11, 2, false}, {13, 2, false}};
+constexpr int kUnshuffleMT[] = {2, 3, 4};
 
 template <int MT, int NT>
 void launch_variant(const Conv16Params& cp, unsigned blocks, hipStream_t st) {
@@ -374,15 +554,38 @@ void launch_variant_blur(const Conv16Params& cp, unsigned blocks, hipStream_t st
 }  // namespace
 
 int conv16_set_tile(int mt, int nt) {
-    if (mt == 0 && nt == 0) { g_forced_tile = 0; return 0; }
+    if (mt == 0 && nt == 0) { g_forced_tile = 0; g_unshuffle_mt = 0; return 0; }
+    if (nt == 8) {                          // the fused un-shuffle GEMM's row tiles; the plain GEMMs keep the cost model
+        for (int v : kUnshuffleMT)
+            if (v == mt) { g_forced_tile = 0; g_unshuffle_mt = mt; return 0; }
+    }
     for (const Variant& v : kVariants)
-        if (v.MT == mt && v.NT == nt) { g_forced_tile = 100 * mt + nt; return 0; }
-    return fail("gnr_set_conv16_tile: no GEMM instance with %d row tiles x %d pixel tiles (have 2x4, 4x4, 8x4, 9x2, 11x2, 13x2, 2x2, 4x2; "
-                "0, 0 restores the cost model)", mt, nt);
+        if (v.MT == mt && v.NT == nt) { g_forced_tile = 100 * mt + nt; g_unshuffle_mt = 0; return 0; }
+    return fail("gnr_set_conv16_tile: no GEMM instance with %d row tiles x %d pixel tiles (have 2x4, 4x4, 8x4, 9x2, 11x2, 13x2, and "
+                "2x8, 3x8, 4x8 for the GEMM with the fused un-shuffle; 0, 0 restores the cost model)", mt, nt);
 }
 
-// the half-width tiles pay only where a launch has about one 2x4 wave per SIMD or less (set from profiles/r4_n1_small_tiles.txt)
-static bool conv16_small_ok(long pixels_total) { return false && pixels_total <= 0; }
+// du = Wf^T g + un-shuffle in one kernel: needs the x.repeat adjoint's four terms in one lane (M % 4 == 0) and a wave's 32
+// low-resolution columns inside one row.  A pinned plain tile (gnr_set_conv16_tile) means "the two-kernel path".
+Conv16Plan conv16_plan_unshuffle(int M, int K, int side) {
+    Conv16Plan p{};
+    if (M % 4 || side % 32 || g_forced_tile.load()) return p;
+    const int tiles = (M + 15) / 16;
+    int mt = g_unshuffle_mt.load();
+    if (!mt) {
+        // fewest padded row tiles, then the smallest tile (64 channels at 256 x 256, 7 images: 2 x (2,8) 190 us, 1 x (4,8) 210 us)
+        int best_pad = 1 << 30;
+        for (int v : kUnshuffleMT) {
+            const int sl = (tiles + v - 1) / v, pad = sl * v - tiles;
+            if (pad < best_pad) { best_pad = pad; mt = v; }
+        }
+    }
+    p.MT = mt; p.NT = 8;
+    p.slices = (tiles + mt - 1) / mt;
+    p.nkb = (K + 15) / 16;
+    p.pack_floats = (size_t)p.slices * p.nkb * p.MT * 256;
+    return p;
+}
 
 Conv16Plan conv16_plan(int M, int K, long pixels_total, int blur_w) {
     const int tiles = (M + 15) / 16;
@@ -395,7 +598,6 @@ Conv16Plan conv16_plan(int M, int K, long pixels_total, int blur_w) {
     for (const Variant& v : kVariants) {
         if (blur_w && (!v.blur || blur_w % (16 * v.NT))) continue;      // a wave's pixels must lie in one image row
         if (fmt && (v.MT != fmt || v.NT != fnt)) continue;
-        if (!fmt && v.small_only && !conv16_small_ok(pixels_total)) continue;
         const int slices = (tiles + v.MT - 1) / v.MT;
         const double waves = (double)slices * (double)(pixels_total / (16 * v.NT));
         // two waves share a SIMD's matrix pipe: below 1024 waves the chip is not full and a wave's length is the time
@@ -417,11 +619,11 @@ Conv16Plan conv16_plan(int M, int K, long pixels_total, int blur_w) {
     return best;
 }
 
-long conv16_add_job(Conv16PackJobs& jobs, const float* W, long rs, long cs, int M, int K, const Conv16Plan& plan) {
+long conv16_add_job(Conv16PackJobs& jobs, const float* W, long rs, long cs, int M, int K, const Conv16Plan& plan, int perm4) {
     Conv16PackJobs::Job& J = jobs.j[jobs.n];
     long off = 0;
     for (int i = 0; i < jobs.n; ++i) off += jobs.j[i].floats;
-    J.W = W; J.rs = rs; J.cs = cs; J.M = M; J.K = K; J.MT = plan.MT; J.nkb = plan.nkb; J.slices = plan.slices;
+    J.W = W; J.rs = rs; J.cs = cs; J.M = M; J.K = K; J.MT = plan.MT; J.nkb = plan.nkb; J.slices = plan.slices; J.perm4 = perm4;
     J.dst_off = off; J.floats = (long)plan.pack_floats;
     ++jobs.n;
     return off;
@@ -435,6 +637,17 @@ void launch_conv16_pack(const Conv16PackJobs& jobs, hipStream_t st) {
 }
 
 int launch_conv16(const Conv16Params& cp, hipStream_t st) {
+    if (cp.plan.NT == 8) {
+        const long witems = (long)cp.batch * cp.W * (cp.W / 32) / WPB * cp.plan.slices;
+        const unsigned wblocks = (unsigned)(8 * ((witems + 7) / 8));
+        switch (cp.plan.MT) {
+            case 2: hipLaunchKernelGGL((conv16_unshuffle_kernel<2>), dim3(wblocks), dim3(64 * WPB), 0, st, cp); break;
+            case 3: hipLaunchKernelGGL((conv16_unshuffle_kernel<3>), dim3(wblocks), dim3(64 * WPB), 0, st, cp); break;
+            case 4: hipLaunchKernelGGL((conv16_unshuffle_kernel<4>), dim3(wblocks), dim3(64 * WPB), 0, st, cp); break;
+            default: return fail("conv16: no fused un-shuffle instance for MT = %d", cp.plan.MT);
+        }
+        return 0;
+    }
     const long items = (long)cp.batch * cp.P / (16 * WPB * cp.plan.NT) * cp.plan.slices;
     const unsigned blocks = (unsigned)(8 * ((items + 7) / 8));
     const int key = cp.plan.MT * 10 + cp.plan.NT;
@@ -445,8 +658,6 @@ int launch_conv16(const Conv16Params& cp, hipStream_t st) {
         case 84: launch_variant<8, 4>(cp, blocks, st); break;
         case 44: launch_variant_blur<4, 4>(cp, blocks, st); break;
         case 24: launch_variant_blur<2, 4>(cp, blocks, st); break;
-        case 22: launch_variant_blur<2, 2>(cp, blocks, st); break;
-        case 42: launch_variant_blur<4, 2>(cp, blocks, st); break;
         default: return fail("conv16: no instance for MT = %d, NT = %d", cp.plan.MT, cp.plan.NT);
     }
     return 0;

@@ -633,6 +633,7 @@ struct BlockPlans {
     Conv16Plan c1, c2, c3;
     long o1, o2, o3;
     bool blur_fused;                    // forward only: feat_layers reads blur(u) on the fly
+    bool unshuffle_fused;               // backward only: the du GEMM's epilogue is the PixelShuffleUpsample tail's adjoint
 };
 
 // Forward GEMMs: a1 = W1 net (2C x C), u = shuffle(W2 a1) (4C x 2C), net' = Wf blur(u) (Cn x C over 4P pixels).
@@ -667,8 +668,10 @@ static size_t plan_bwd(const UpDims& d, int B, const GnrUpsampleWeights* w, Bloc
         const int C = d.ch[i], Cn = d.ch[i + 1], S = d.side[i];
         const long px = (long)B * S * S;
         BlockPlans q{};
-        q.c3 = conv16_plan(C, Cn, 4 * px, 0);
-        q.o3 = conv16_add_job(J, w ? w->feat_w[i] : nullptr, 1, C, C, Cn, q.c3);
+        q.c3 = conv16_plan_unshuffle(C, Cn, S);
+        q.unshuffle_fused = q.c3.MT != 0;
+        if (!q.unshuffle_fused) q.c3 = conv16_plan(C, Cn, 4 * px, 0);
+        q.o3 = conv16_add_job(J, w ? w->feat_w[i] : nullptr, 1, C, C, Cn, q.c3, q.unshuffle_fused ? 1 : 0);
         q.c2 = conv16_plan(2 * C, 4 * C, px, 0);
         q.o2 = conv16_add_job(J, w ? w->up2_w[i] : nullptr, 1, 2 * C, 2 * C, 4 * C, q.c2);
         q.c1 = conv16_plan(C, 2 * C, px, 0);
@@ -855,11 +858,19 @@ int gnr_upsample_fwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, f
                                2 * S, 0);
             g.B = s.vtmp;
         }
-        if (launch_conv16(g, st)) return 1;
-        // rgb += conv_rgb(i+1)(net');  last block: img = sigmoid(rgb) (or rgb itself), also straight into the caller's image
+        // rgb += conv_rgb(i+1)(net');  last block: img = sigmoid(rgb) (or rgb itself), also straight into the caller's image.
+        // Round 4: when one wave holds every output channel of its pixels (one row slice: 129 / 64 / 32 channels) the three
+        // dots ride on the GEMM's epilogue; otherwise rgb_conv_kernel re-reads the block output.
         const bool last = i == d.n_blocks - 1;
-        launch_rgb_conv(s.net[i], Cn, 4 * P, B, w->rgb_w[i + 1], w->rgb_b[i + 1], rgb, 1, last && p->final_sigmoid ? s.img : nullptr,
-                        last ? img : nullptr, st);
+        const bool rgb_fused = bp[i].c3.slices == 1;
+        if (rgb_fused) {
+            g.rgb_w = w->rgb_w[i + 1]; g.rgb_bias = w->rgb_b[i + 1]; g.rgb = rgb; g.rgb_accumulate = 1;
+            g.rgb_img = last && p->final_sigmoid ? s.img : nullptr; g.rgb_out = last ? img : nullptr;
+        }
+        if (launch_conv16(g, st)) return 1;
+        if (!rgb_fused)
+            launch_rgb_conv(s.net[i], Cn, 4 * P, B, w->rgb_w[i + 1], w->rgb_b[i + 1], rgb, 1, last && p->final_sigmoid ? s.img : nullptr,
+                            last ? img : nullptr, st);
         if (!last) {
             up_rgb(rgb, rgb_other, B, 2 * S, st);
             float* t = rgb; rgb = rgb_other; rgb_other = t;
@@ -949,21 +960,29 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
         }
         // feat_layers[i]: dWf = g u^T, dbf; du = Wf^T g
         launch_wgrad_img(Y, Cn, Cn, s.u[i], C, C, B, P4, G.feat_w[i], C, G.feat_b[i], 0, t.wg, st);
-        Conv16Params g{};
-        g.plan = bp[i].c3; g.At = s.pack + bp[i].o3; g.B = Y; g.b_batch = (long)Cn * P4; g.C = X; g.c_batch = (long)C * P4;
-        g.M = C; g.K = Cn; g.P = (int)P4; g.batch = B;
-        if (launch_conv16(g, st)) return 1;                                      // X = du
-        // un-shuffle: dpre2 (-> Y) and the residual part of d(net_in) into backward scratch (block 0: straight into the
+        // un-shuffle: dpre2 and the residual part of d(net_in) into backward scratch (block 0: straight into the
         // caller's d_x).  X is g0 (last block) or the previous d(net), Y the other of g0 / g1: d(net) takes g2, g1, g2, ...
         // -- never a buffer of the saved forward workspace (round 3 wrote it over u[i], which made a second backward over
         // the same saved state wrong).
         float* dnet = (i == 0 && d_x) ? d_x : (((nb - 1 - i) & 1) ? t.g1 : t.g2);
-        if (C % 4 == 0)
-            hipLaunchKernelGGL(unshuffle_bwd4_kernel, dim3(blocks_for((long)B * (C / 4) * (P / 4))), dim3(256), 0, st, X, s.sign2[i], C, S, S,
-                               B, Y, dnet);
-        else
-            hipLaunchKernelGGL(unshuffle_bwd_kernel, dim3(blocks_for((long)B * 2 * C * P)), dim3(256), 0, st, X, s.sign2[i], C, S, S, B, Y,
-                               dnet);
+        Conv16Params g{};
+        g.plan = bp[i].c3; g.At = s.pack + bp[i].o3; g.B = Y; g.b_batch = (long)Cn * P4; g.M = C; g.K = Cn; g.P = (int)P4; g.batch = B;
+        if (bp[i].unshuffle_fused) {
+            // round 4: du never reaches memory -- the GEMM's epilogue writes dpre2 (-> X; Y = g is still being read) and dres
+            g.C = X; g.c_batch = 4L * C * P; g.W = S; g.sign_in = s.sign2[i]; g.sign_batch = (long)C * P;
+            g.dres = dnet; g.dres_batch = (long)C * P;
+            if (launch_conv16(g, st)) return 1;
+            float* sw = X; X = Y; Y = sw;                                        // Y = dpre2, X free for dpre1
+        } else {
+            g.C = X; g.c_batch = (long)C * P4;
+            if (launch_conv16(g, st)) return 1;                                  // X = du
+            if (C % 4 == 0)
+                hipLaunchKernelGGL(unshuffle_bwd4_kernel, dim3(blocks_for((long)B * (C / 4) * (P / 4))), dim3(256), 0, st, X, s.sign2[i], C, S, S,
+                                   B, Y, dnet);
+            else
+                hipLaunchKernelGGL(unshuffle_bwd_kernel, dim3(blocks_for((long)B * 2 * C * P)), dim3(256), 0, st, X, s.sign2[i], C, S, S, B, Y,
+                                   dnet);
+        }
         // layer_2: dW2 = dpre2 a1^T, db2; dpre1 = (W2^T dpre2) * lrelu'(a1)  (-> X)
         launch_wgrad_img(Y, 4 * C, 4 * C, s.a1[i], 2 * C, 2 * C, B, P, G.up2_w[i], 2 * C, G.up2_b[i], 0, t.wg, st);
         g = Conv16Params{};

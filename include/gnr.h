@@ -337,9 +337,12 @@ const char* gnr_last_error(void);
 const char* gnr_build_info(void);
 
 /* ABI 4.  Tuning / test hook (process-wide like the timing hooks; results are the same to rounding for every choice): pin the
- * (row tiles, pixel tiles) instance of the upsampler's 1x1-convolution GEMMs -- 2x4, 4x4, 8x4, 9x2, 11x2, 13x2, 2x2, 4x2 -- instead of
+ * (row tiles, pixel tiles) instance of the upsampler's 1x1-convolution GEMMs -- 2x4, 4x4, 8x4, 9x2, 11x2, 13x2 -- instead of
  * the cost model's choice per GEMM; (0, 0) restores the cost model.  A pair without an instance is an error.  The blur-fused
- * feat_layers GEMM exists for 2x4, 4x4, 9x2, 2x2, 4x2; with another pair pinned the stencil runs as its own kernel. */
+ * feat_layers GEMM exists for 2x4, 4x4, 9x2; with another pair pinned the stencil runs as its own kernel.  The backward's
+ * du GEMM with the fused un-shuffle epilogue (channel counts that are multiples of 4, sides that are multiples of 32) has its
+ * own instances 2x8, 3x8, 4x8: pinning one of those leaves every other GEMM to the cost model; with a plain pair pinned the
+ * un-shuffle runs as its own kernel behind the plain GEMM. */
 int gnr_set_conv16_tile(int row_tiles, int pixel_tiles);
 
 #ifdef __cplusplus

@@ -163,19 +163,27 @@ def test_every_gemm_tile_variant_gives_the_same_result():
     C ABI -- until round 3 an environment variable the library read behind the caller's back) pins one for every GEMM.
     (8,4), (11,2), (13,2) have no blur instance: pinning them also runs the separate-stencil fallback of feat_layers.  All
     must agree with the cost model's choice to rounding (different tiles sum the contraction in the same k order:
-    identical up to the blur path); a pair without an instance is rejected."""
+    identical up to the blur path); a pair without an instance is rejected.  Round 4: with the cost model the backward's
+    du GEMM of case "b" (64 / 32 channels at 32 / 64 pixels a side) carries the un-shuffle in its epilogue
+    (conv16_unshuffle_kernel; (2,8), (3,8), (4,8) pin its row tiles), with a plain pair pinned the un-shuffle is its own
+    kernel behind the plain GEMM: the fused path must reproduce the two-kernel path BIT FOR BIT (same k order, same order of
+    the four x.repeat-adjoint terms)."""
     from gazenerf_amd import _lib
     lib = _lib.load()
     dev = _dev()
     res = {}
     try:
-        for force in ((0, 0), (13, 2), (11, 2), (9, 2), (8, 4), (4, 4), (2, 4)):
+        for force in ((0, 0), (13, 2), (11, 2), (9, 2), (8, 4), (4, 4), (2, 4), (2, 8), (3, 8), (4, 8)):
             _lib.check(lib.gnr_set_conv16_tile(*force))
             res[force] = _variant_run(dev)
         assert lib.gnr_set_conv16_tile(3, 3) != 0 and b"no GEMM instance" in lib.gnr_last_error()
     finally:
         lib.gnr_set_conv16_tile(0, 0)
     base = res[(0, 0)]
+    for k, v in res[(2, 4)].items():          # (2,4) is what the cost model picks for every GEMM of case "b": only the fusion differs
+        if k.startswith("b_"):
+            for fused in ((0, 0), (2, 8), (3, 8), (4, 8)):
+                assert np.array_equal(res[fused][k], v), (fused, k)
     for force, got in res.items():
         for k, v in base.items():
             if k.endswith("_img"):
