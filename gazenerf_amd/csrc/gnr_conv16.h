@@ -32,6 +32,8 @@ struct Conv16PackJobs {
         const float* W; long rs, cs;      // A(m,k) = W[m*rs + k*cs]
         int M, K, MT, nkb, slices;
         int perm4;                        // packed row r holds A row (r >> 2) + (r & 3) * (M / 4)   (conv16_plan_unshuffle)
+        int kchain;                       // element s of lane group g is k = 16 kb + 4 g + s (register-chained operand: the
+                                          // previous GEMM's C/D layout) instead of 16 kb + 4 s + g (operand loaded from memory)
         long dst_off, floats;             // into `dst`
     } j[CONV16_MAX_JOBS];
     float* dst;
@@ -68,6 +70,35 @@ struct Conv16Params {
     float* rgb; int rgb_accumulate;                // [batch][3][P]
     float* rgb_img; float* rgb_out;
 };
+// ---------------------------------------------------------------------------------------------------------------
+// PixelShuffleUpsample's layer_1 -> layer_2 in one kernel (round 4): a1 = lrelu(W1 x + b1), u = shuffle(lrelu(W2 a1 + b2) +
+// repeat(x)).  A wave owns 16 NP pixels and EVERY channel: phase 1 reads its operand from memory like conv16_kernel and keeps
+// all M1 = 2C output rows in registers; their C/D layout IS the B-operand layout of phase 2 (gnr_chain16.h), which runs over
+// the M2 = 4C output rows in slabs of 8 / NP row tiles.  a1 is still written (the backward reads it) but never read back.
+struct UpChainPlan {
+    int T1, NP;                       // row tiles of the middle activation, pixel tiles per wave; T1 == 0: no instance
+    int nkb1, slabs2;                 // k-blocks of phase 1, slabs of 8 / NP row tiles of phase 2
+    size_t pack1_floats, pack2_floats;
+};
+UpChainPlan upchain_plan(int K1, int M1, int M2, long pixels_per_image);
+// the two pack jobs (phase 1: rows M1 x K1, phase 2: rows M2 x M1); offsets returned through o1 / o2
+void upchain_add_jobs(Conv16PackJobs& jobs, const UpChainPlan& plan, const float* W1, long rs1, long cs1, int M1, int K1,
+                      const float* W2, long rs2, long cs2, int M2, long* o1, long* o2);
+struct UpChainParams {
+    UpChainPlan plan;
+    const float* A1; const float* A2;              // packed operands
+    const float* B; long b_batch;                  // phase-1 operand [batch][K1][P]
+    int K1, M1, M2, P, batch;
+    const float* bias1;                            // [M1]
+    float* out1; long out1_batch;                  // a1 [batch][M1][P]
+    const float* bias2;                            // [M2]
+    const float* res; long res_batch;              // residual x [batch][M2/4][P]
+    unsigned char* sign_out; long sign_batch;      // [batch][M2/4][P]
+    float* out2; long out2_batch;                  // u [batch][M2/4][4P] (pixel-shuffled)
+    int W;                                         // image width (n = y W + x)
+};
+int launch_upchain(const UpChainParams& cp, hipStream_t st);
+
 int launch_conv16(const Conv16Params& cp, hipStream_t st);       // non-zero (+ gnr_last_error) when the plan names no instance
 int conv16_set_tile(int mt, int nt);                             // gnr_set_conv16_tile
 

@@ -40,6 +40,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "gnr_chain16.h"
 
@@ -96,7 +97,8 @@ __global__ __launch_bounds__(256) void conv16_pack_kernel(const Conv16PackJobs j
     const int mt = (int)(r % J.MT); r /= J.MT;
     const int kb = (int)(r % J.nkb);
     const int slice = (int)(r / J.nkb);
-    const int row = 16 * (slice * J.MT + mt) + (lane & 15), k = 16 * kb + 4 * s + (lane >> 4);
+    const int row = 16 * (slice * J.MT + mt) + (lane & 15);
+    const int k = J.kchain ? 16 * kb + 4 * (lane >> 4) + s : 16 * kb + 4 * s + (lane >> 4);
     const int m = J.perm4 ? (row >> 2) + (row & 3) * (J.M >> 2) : row;       // perm4: a lane's four rows are channels cb + q M/4
     jobs.dst[J.dst_off + i] = (row < J.M && k < J.K) ? J.W[(long)m * J.rs + (long)k * J.cs] : 0.0f;
 }
@@ -530,6 +532,204 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv16_unshuffle_kernel(const Con
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// upchain_kernel: PixelShuffleUpsample's layer_1 -> layer_2 chained in registers (gnr_conv16.h).  T1 = row tiles of the middle
+// activation (all of them in registers: 4 T1 NP), NP = pixel tiles per wave (a lane owns NP consecutive pixels).
+// Weight rows stream per wave in batches of 4 row tiles (b128 per lane = 4 MFMA steps), one batch ahead, as in the MLP
+// chain (gnr_chain16.h); two waves share a SIMD.  Biases wait in LDS (one barrier at the start).
+// Measured (profiles/r4_n1_chain_experiment.txt): a gain only at the 64-channel level (453 -> ~395 us per 7 images, 72 -> 60 us
+// per image); the 129-channel instance and the backward variant (the two data gradients chained) were slower than their two
+// GEMMs -- short contractions under a 7-VALU-per-element epilogue need conv16_kernel's five waves per SIMD -- and were removed.
+// ---------------------------------------------------------------------------------------------------------------
+template <int T1, int NP>
+__global__ __launch_bounds__(64 * WPB, 2) void upchain_kernel(const UpChainParams cp) {
+    constexpr int TB = 4, MS = 8 / NP, NB1 = (T1 + TB - 1) / TB, T1P = NB1 * TB;      // MS: row tiles of a phase-2 slab (64 accumulator registers)
+    typedef typename Pix<NP>::T pv;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int li = lane & 15, g = lane >> 4;
+    const unsigned groups = (unsigned)((long)cp.batch * cp.P / (16 * WPB * NP));
+    const unsigned per_xcd = (groups + 7u) >> 3;
+    const unsigned item = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (item >= groups) return;
+    __shared__ float bias_lds[16 * T1 + 64 * T1];                 // [M1 padded][M2 <= 2 M1 padded]
+    for (int i = (int)threadIdx.x; i < cp.M1 + cp.M2; i += 64 * WPB) bias_lds[i < cp.M1 ? i : 16 * T1 + (i - cp.M1)] = i < cp.M1 ? cp.bias1[i] : cp.bias2[i - cp.M1];
+    __syncthreads();
+    const unsigned pixg = item * (unsigned)(16 * WPB * NP) + (unsigned)wave * (unsigned)(16 * NP);
+    const int b = (int)(pixg / (unsigned)cp.P);
+    const int p0 = (int)(pixg - (unsigned)b * (unsigned)cp.P);
+    const int n = p0 + NP * li;
+    const int nkb1 = cp.plan.nkb1, slabs2 = cp.plan.slabs2;
+
+    const __amdgpu_buffer_rsrc_t rsA1 = __builtin_amdgcn_make_buffer_rsrc((void*)cp.A1, 0, nkb1 * (T1P * 1024), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)cp.A2, 0, slabs2 * (T1 * MS * 1024), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(cp.B + (long)b * cp.b_batch), 0, (int)((long)cp.K1 * cp.P * 4), 0x00020000);
+    const unsigned voffA = (unsigned)lane * 16u;
+    const unsigned rowB = (unsigned)cp.P * 4u;
+    const unsigned voffB = ((unsigned)g * (unsigned)cp.P + (unsigned)n) * 4u;
+
+    f32x4 acc1[T1][NP];
+#pragma unroll
+    for (int t1 = 0; t1 < T1; ++t1)
+#pragma unroll
+        for (int t = 0; t < NP; ++t) acc1[t1][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    // ---- phase 1: acc1 = A1 B over K1 (B from memory; lane group g takes k = 16 kb + 4 s + g) ----
+    {
+        pv Bq[2][4];
+        f32x4 Aq[2][TB];
+        unsigned sa = 0;                                          // byte offset of the next A batch (wave-uniform)
+        auto load_b = [&](int kb, pv (&Bv)[4]) {
+            const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)kb * 16u * rowB));
+#pragma unroll
+            for (int s = 0; s < 4; ++s) Bv[s] = Pix<NP>::load(rsB, voffB, sb + (unsigned)s * 4u * rowB);
+        };
+        auto load_a = [&](f32x4 (&A)[TB]) {
+            const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)sa);
+#pragma unroll
+            for (int q = 0; q < TB; ++q)
+                A[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA1, voffA, (int)(so + (unsigned)q * 1024u), 0));
+            sa += TB * 1024u;
+        };
+        // one k-block: NB1 batches; the A buffers alternate along the linear batch stream, PAR = parity of its first batch
+        auto kblock = [&](auto par, const pv (&Bv)[4]) {
+            constexpr int PAR = decltype(par)::value;
+#pragma unroll
+            for (int i = 0; i < NB1; ++i) {
+                load_a(Aq[(PAR + i + 1) & 1]);                    // the next batch of the stream (runs off the end harmlessly)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int q = 0; q < TB; ++q)
+                        if (i * TB + q < T1) {
+#pragma unroll
+                            for (int t = 0; t < NP; ++t)
+                                acc1[i * TB + q][t] = mfma16c(Aq[(PAR + i) & 1][q][s], Bv[s][t], acc1[i * TB + q][t]);
+                        }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        load_b(0, Bq[0]);
+        load_a(Aq[0]);
+        int kb = 0;
+        for (; kb + 1 < nkb1; kb += 2) {
+            load_b(kb + 1, Bq[1]);
+            kblock(std::integral_constant<int, 0>{}, Bq[0]);
+            load_b(kb + 2 < nkb1 ? kb + 2 : nkb1 - 1, Bq[0]);
+            kblock(std::integral_constant<int, NB1 & 1>{}, Bq[1]);
+        }
+        if (nkb1 & 1) kblock(std::integral_constant<int, 0>{}, Bq[0]);
+    }
+
+    // ---- epilogue 1: the middle activation, stored and kept (row 16 t1 + 4 g + e, pixels n .. n + NP - 1) ----
+#pragma unroll
+    for (int t1 = 0; t1 < T1; ++t1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = 16 * t1 + 4 * g + e;
+            const bool live = m < cp.M1;
+            pv v;
+#pragma unroll
+            for (int t = 0; t < NP; ++t) v[t] = acc1[t1][t][e];
+            v += bias_lds[m];                                     // (rows >= M1: unset LDS, discarded below)
+#pragma unroll
+            for (int t = 0; t < NP; ++t) v[t] = v[t] > 0.0f ? v[t] : LEAK16 * v[t];
+            if (live) *(pv*)(cp.out1 + (long)b * cp.out1_batch + (long)m * cp.P + n) = v;
+#pragma unroll
+            for (int t = 0; t < NP; ++t) acc1[t1][t][e] = live ? v[t] : 0.0f;
+        }
+
+    // ---- phase 2: slabs of MS row tiles over K2 = 16 T1 (step e of input tile j = register e of acc1[j]) ----
+    f32x4 A2q[2][MS];
+    unsigned sa2 = 0;
+    auto load_a2 = [&](f32x4 (&A)[MS]) {
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)sa2);
+#pragma unroll
+        for (int q = 0; q < MS; ++q)
+            A[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA2, voffA, (int)(so + (unsigned)q * 1024u), 0));
+        sa2 += MS * 1024u;
+    };
+    auto slab = [&](auto par, int sl) {
+        constexpr int PAR = decltype(par)::value;
+        f32x4 acc2[MS][NP];
+#pragma unroll
+        for (int mt = 0; mt < MS; ++mt)
+#pragma unroll
+            for (int t = 0; t < NP; ++t) acc2[mt][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        // the residual rows are requested before the slab's MFMAs
+        const int m0 = sl * (16 * MS);
+        const int Cq = cp.M2 / 4;
+        const int rbase = (m0 + 4 * g) % Cq;                      // x.repeat: in-channel m reads x channel m % Cq; one division per slab,
+                                                                  // the slab's rows follow by adding < 16 MS + 4 <= Cq and wrapping once
+        pv pre[MS][4];
+#pragma unroll
+        for (int mt = 0; mt < MS; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int rr = rbase + 16 * mt + e;
+                if (rr >= Cq) rr -= Cq;
+                pre[mt][e] = *(const pv*)(cp.res + (long)b * cp.res_batch + (long)rr * cp.P + n);
+            }
+#pragma unroll
+        for (int j = 0; j < T1; ++j) {
+            load_a2(A2q[(PAR + j + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mt = 0; mt < MS; ++mt)
+#pragma unroll
+                    for (int t = 0; t < NP; ++t) acc2[mt][t] = mfma16c(A2q[(PAR + j) & 1][mt][e], acc1[j][t][e], acc2[mt][t]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // PixelShuffleUpsample tail, as conv16_kernel<.., SHUF>: a lane's four registers of a tile are in-channels
+        // 4c .. 4c+3 of its NP pixels = the 2 x 2 output blocks of out-channel c at NP consecutive x
+        const int py = n / cp.W, px = n - py * cp.W;
+#pragma unroll
+        for (int mt = 0; mt < MS; ++mt) {
+            const int mb = m0 + 16 * mt + 4 * g;
+            if (mb >= cp.M2) continue;
+            float v[4][NP];
+            unsigned nib = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = mb + e;
+                const float bias = bias_lds[16 * T1 + m];
+                const pv res = pre[mt][e];
+#pragma unroll
+                for (int t = 0; t < NP; ++t) {
+                    float u = acc2[mt][t][e] + bias;
+                    nib |= (u > 0.0f ? 1u : 0u) << (8 * t + e);
+                    u = u > 0.0f ? u : LEAK16 * u;
+                    v[e][t] = u + res[t];
+                }
+            }
+            unsigned char* sp = cp.sign_out + (long)b * cp.sign_batch + (long)(mb >> 2) * cp.P + n;
+            if constexpr (NP == 4) *(unsigned*)sp = nib;
+            else *(unsigned short*)sp = (unsigned short)nib;
+            float* dst = cp.out2 + (long)b * cp.out2_batch + (long)(mb >> 2) * (4L * cp.P) + (long)(2 * py) * (2 * cp.W) + 2 * px;
+#pragma unroll
+            for (int t = 0; t < NP; t += 2) {
+                *(f32x4*)(dst + 2 * t) = f32x4{v[0][t], v[1][t], v[0][t + 1], v[1][t + 1]};
+                *(f32x4*)(dst + 2 * cp.W + 2 * t) = f32x4{v[2][t], v[3][t], v[2][t + 1], v[3][t + 1]};
+            }
+        }
+    };
+    load_a2(A2q[0]);
+    int sl = 0;
+    if constexpr (T1 & 1) {
+        for (; sl + 1 < slabs2; sl += 2) {
+            slab(std::integral_constant<int, 0>{}, sl);
+            slab(std::integral_constant<int, 1>{}, sl + 1);
+        }
+        if (slabs2 & 1) slab(std::integral_constant<int, 0>{}, sl);
+    } else {
+        for (; sl < slabs2; ++sl) slab(std::integral_constant<int, 0>{}, sl);
+    }
+}
+
 std::atomic<int> g_forced_tile{0};          // 100 MT + NT, 0 = cost model (gnr_set_conv16_tile)
 std::atomic<int> g_unshuffle_mt{0};         // row tiles of the fused un-shuffle GEMM pinned by gnr_set_conv16_tile(MT, 8); 0 = heuristic
 struct Variant { int MT, NT; bool blur; };
@@ -623,7 +823,7 @@ long conv16_add_job(Conv16PackJobs& jobs, const float* W, long rs, long cs, int 
     Conv16PackJobs::Job& J = jobs.j[jobs.n];
     long off = 0;
     for (int i = 0; i < jobs.n; ++i) off += jobs.j[i].floats;
-    J.W = W; J.rs = rs; J.cs = cs; J.M = M; J.K = K; J.MT = plan.MT; J.nkb = plan.nkb; J.slices = plan.slices; J.perm4 = perm4;
+    J.W = W; J.rs = rs; J.cs = cs; J.M = M; J.K = K; J.MT = plan.MT; J.nkb = plan.nkb; J.slices = plan.slices; J.perm4 = perm4; J.kchain = 0;
     J.dst_off = off; J.floats = (long)plan.pack_floats;
     ++jobs.n;
     return off;
@@ -634,6 +834,44 @@ void launch_conv16_pack(const Conv16PackJobs& jobs, hipStream_t st) {
     for (int i = 0; i < jobs.n; ++i) total += jobs.j[i].floats;
     if (total == 0) return;
     hipLaunchKernelGGL(conv16_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, jobs);
+}
+
+// The chained pair has one instance: 128 middle channels (the 64-channel level), 64 pixels per wave.  A pinned tile
+// (gnr_set_conv16_tile) means the two-GEMM path.
+UpChainPlan upchain_plan(int K1, int M1, int M2, long pixels_per_image) {
+    UpChainPlan p{};
+    if (g_forced_tile.load() || g_unshuffle_mt.load()) return p;
+    const int t1 = (M1 + 15) / 16;
+    const int np = t1 == 8 ? 4 : 0;                               // the one instance: 128 middle channels, 64 pixels per wave
+    if (!np || pixels_per_image % (16 * WPB * np)) return p;
+    // shuffle epilogue: four in-channels per out-channel, biases of both layers in LDS, one wrap of the residual row
+    if (M2 > 2 * 16 * t1 || M2 % 4 || M2 / 4 < 16 * (8 / np) + 4) return p;
+    p.T1 = t1; p.NP = np;
+    p.nkb1 = (K1 + 15) / 16;
+    const int ms = 8 / np;
+    p.slabs2 = (M2 + 16 * ms - 1) / (16 * ms);
+    p.pack1_floats = (size_t)p.nkb1 * ((t1 + 3) / 4 * 4) * 256;
+    p.pack2_floats = (size_t)p.slabs2 * t1 * ms * 256;
+    return p;
+}
+
+void upchain_add_jobs(Conv16PackJobs& jobs, const UpChainPlan& plan, const float* W1, long rs1, long cs1, int M1, int K1,
+                      const float* W2, long rs2, long cs2, int M2, long* o1, long* o2) {
+    Conv16Plan a{};
+    a.MT = (plan.T1 + 3) / 4 * 4; a.NT = 0; a.slices = 1; a.nkb = plan.nkb1; a.pack_floats = plan.pack1_floats;
+    *o1 = conv16_add_job(jobs, W1, rs1, cs1, M1, K1, a);
+    Conv16Plan c{};
+    c.MT = 8 / plan.NP; c.NT = 0; c.slices = plan.slabs2; c.nkb = plan.T1; c.pack_floats = plan.pack2_floats;
+    *o2 = conv16_add_job(jobs, W2, rs2, cs2, M2, M1, c);
+    jobs.j[jobs.n - 1].kchain = 1;
+}
+
+int launch_upchain(const UpChainParams& cp, hipStream_t st) {
+    const long groups = (long)cp.batch * cp.P / (16 * WPB * cp.plan.NP);
+    const unsigned blocks = (unsigned)(8 * ((groups + 7) / 8));
+    if (cp.plan.T1 == 8 && cp.plan.NP == 4) hipLaunchKernelGGL((upchain_kernel<8, 4>), dim3(blocks), dim3(64 * WPB), 0, st, cp);
+    else return fail("upchain: no instance for %d middle row tiles x %d pixel tiles", cp.plan.T1, cp.plan.NP);
+    return 0;
 }
 
 int launch_conv16(const Conv16Params& cp, hipStream_t st) {

@@ -634,6 +634,8 @@ struct BlockPlans {
     long o1, o2, o3;
     bool blur_fused;                    // forward only: feat_layers reads blur(u) on the fly
     bool unshuffle_fused;               // backward only: the du GEMM's epilogue is the PixelShuffleUpsample tail's adjoint
+    UpChainPlan chain;                  // forward only, T1 != 0: layer_1 -> layer_2 as ONE kernel;
+    long oc1, oc2;                      // c1 / c2 / o1 / o2 are then unused
 };
 
 // Forward GEMMs: a1 = W1 net (2C x C), u = shuffle(W2 a1) (4C x 2C), net' = Wf blur(u) (Cn x C over 4P pixels).
@@ -644,10 +646,16 @@ static size_t plan_fwd(const UpDims& d, int B, const GnrUpsampleWeights* w, Bloc
         const int C = d.ch[i], Cn = d.ch[i + 1], S = d.side[i];
         const long px = (long)B * S * S;
         BlockPlans q{};
-        q.c1 = conv16_plan(2 * C, C, px, 0);
-        q.o1 = conv16_add_job(J, w ? w->up1_w[i] : nullptr, C, 1, 2 * C, C, q.c1);
-        q.c2 = conv16_plan(4 * C, 2 * C, px, 0);
-        q.o2 = conv16_add_job(J, w ? w->up2_w[i] : nullptr, 2 * C, 1, 4 * C, 2 * C, q.c2);
+        // forward chain: a1 = W1 net (K1 = C -> M1 = 2C), u = shuffle(W2 a1) (M2 = 4C)
+        q.chain = upchain_plan(C, 2 * C, 4 * C, (long)S * S);
+        if (q.chain.T1) {
+            upchain_add_jobs(J, q.chain, w ? w->up1_w[i] : nullptr, C, 1, 2 * C, C, w ? w->up2_w[i] : nullptr, 2 * C, 1, 4 * C, &q.oc1, &q.oc2);
+        } else {
+            q.c1 = conv16_plan(2 * C, C, px, 0);
+            q.o1 = conv16_add_job(J, w ? w->up1_w[i] : nullptr, C, 1, 2 * C, C, q.c1);
+            q.c2 = conv16_plan(4 * C, 2 * C, px, 0);
+            q.o2 = conv16_add_job(J, w ? w->up2_w[i] : nullptr, 2 * C, 1, 4 * C, 2 * C, q.c2);
+        }
         q.c3 = conv16_plan(Cn, C, 4 * px, 2 * S);
         q.blur_fused = q.c3.MT != 0;
         if (!q.blur_fused) q.c3 = conv16_plan(Cn, C, 4 * px, 0);
@@ -837,16 +845,27 @@ int gnr_upsample_fwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, f
         const int C = d.ch[i], Cn = d.ch[i + 1], S = d.side[i];
         const long P = (long)S * S;
         Conv16Params g{};
-        // a1 = lrelu(W1 net + b1)
-        g.plan = bp[i].c1; g.At = s.pack + bp[i].o1; g.B = net; g.b_batch = (long)C * P; g.C = s.a1[i]; g.c_batch = 2L * C * P;
-        g.M = 2 * C; g.K = C; g.P = (int)P; g.batch = B; g.bias = w->up1_b[i]; g.leaky = 1;
-        if (launch_conv16(g, st)) return 1;
-        // u = pixel_shuffle(lrelu(W2 a1 + b2) + repeat(net))
-        g = Conv16Params{};
-        g.plan = bp[i].c2; g.At = s.pack + bp[i].o2; g.B = s.a1[i]; g.b_batch = 2L * C * P; g.C = s.u[i]; g.c_batch = 4L * C * P;
-        g.M = 4 * C; g.K = 2 * C; g.P = (int)P; g.batch = B; g.bias = w->up2_b[i]; g.leaky = 1; g.shuffle = 1; g.W = S;
-        g.res = net; g.res_batch = (long)C * P; g.sign_out = s.sign2[i]; g.sign_batch = (long)C * P;
-        if (launch_conv16(g, st)) return 1;
+        if (bp[i].chain.T1) {
+            // round 4: both layers in one kernel -- a1 is written (the backward reads it) but never read back
+            UpChainParams c{};
+            c.plan = bp[i].chain; c.A1 = s.pack + bp[i].oc1; c.A2 = s.pack + bp[i].oc2; c.B = net; c.b_batch = (long)C * P;
+            c.K1 = C; c.M1 = 2 * C; c.M2 = 4 * C; c.P = (int)P; c.batch = B;
+            c.bias1 = w->up1_b[i]; c.out1 = s.a1[i]; c.out1_batch = 2L * C * P;
+            c.bias2 = w->up2_b[i]; c.res = net; c.res_batch = (long)C * P; c.sign_out = s.sign2[i]; c.sign_batch = (long)C * P;
+            c.out2 = s.u[i]; c.out2_batch = 4L * C * P; c.W = S;
+            if (launch_upchain(c, st)) return 1;
+        } else {
+            // a1 = lrelu(W1 net + b1)
+            g.plan = bp[i].c1; g.At = s.pack + bp[i].o1; g.B = net; g.b_batch = (long)C * P; g.C = s.a1[i]; g.c_batch = 2L * C * P;
+            g.M = 2 * C; g.K = C; g.P = (int)P; g.batch = B; g.bias = w->up1_b[i]; g.leaky = 1;
+            if (launch_conv16(g, st)) return 1;
+            // u = pixel_shuffle(lrelu(W2 a1 + b2) + repeat(net))
+            g = Conv16Params{};
+            g.plan = bp[i].c2; g.At = s.pack + bp[i].o2; g.B = s.a1[i]; g.b_batch = 2L * C * P; g.C = s.u[i]; g.c_batch = 4L * C * P;
+            g.M = 4 * C; g.K = 2 * C; g.P = (int)P; g.batch = B; g.bias = w->up2_b[i]; g.leaky = 1; g.shuffle = 1; g.W = S;
+            g.res = net; g.res_batch = (long)C * P; g.sign_out = s.sign2[i]; g.sign_batch = (long)C * P;
+            if (launch_conv16(g, st)) return 1;
+        }
         // net' = lrelu(Wf blur(u) + bf): the stencil inside the GEMM's operand load, or as its own kernel
         g = Conv16Params{};
         g.plan = bp[i].c3; g.At = s.pack + bp[i].o3; g.B = s.u[i]; g.b_batch = 4L * C * P; g.C = s.net[i]; g.c_batch = 4L * Cn * P;
