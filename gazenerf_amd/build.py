@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libgnr.so")
-SOURCES = ["gnr_api.hip", "gnr_prep.hip", "gnr_fwd16.hip", "gnr_bwd.hip", "gnr_bwd16.hip", "gnr_wgrad.hip", "gnr_merge.hip", "gnr_vd.hip", "gnr_fwd3.hip", "gnr_bwd3.hip", "gnr_conv16.hip", "gnr_upsample.hip"]
+SOURCES = ["gnr_api.hip", "gnr_prep.hip", "gnr_fwd16.hip", "gnr_bwd.hip", "gnr_bwd16.hip", "gnr_wgrad.hip", "gnr_wgrad16.hip", "gnr_merge.hip", "gnr_vd.hip", "gnr_fwd3.hip", "gnr_bwd3.hip", "gnr_conv16.hip", "gnr_upsample.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "gnr.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

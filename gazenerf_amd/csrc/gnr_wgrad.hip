@@ -1508,9 +1508,19 @@ void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb,
 // dW[n_valid x k_valid] = sum over images and pixels of A[b][n][p] * B[b][k][p] for channels-first fp32 images
 // ([B][lda][P] and [B][ldb][P], P % 32 == 0); colsum_out[b * colsum_ld + n] = sum_p A[b][n][p], or with colsum_ld == 0
 // colsum_out[n] = the sum over the images too.  Exact fp32 MFMA.
+bool launch_wgrad16_img(const float* A, int M, const float* B, int K, int batch, long P, float* dW, int ldw, float* bias_out,
+                        float* scratch, size_t scratch_floats, hipStream_t st);
+
 void launch_wgrad_img(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, int batch,
                       long pixels_per_image, float* dW, int ldw, float* colsum_out, int colsum_ld, float* scratch,
                       hipStream_t stream) {
+    // round 4: the wide products (both sides >= 100 channels) go to the register-fed kernel with 16-granular tiles
+    // (gnr_wgrad16.hip); the narrow high-resolution ones stay with the LDS-staged kernels below
+#ifndef GNR_WG_NO16
+    if (lda == n_valid && ldb == k_valid && (colsum_ld == 0 || !colsum_out) &&
+        launch_wgrad16_img(A, n_valid, B, k_valid, batch, pixels_per_image, dW, ldw, colsum_out, scratch, wgrad_scratch_floats(), stream))
+        return;
+#endif
     launch_wgrad_impl(A, lda, n_valid, B, ldb, k_valid, batch, pixels_per_image / CHUNK, dW, ldw, 0, 0, colsum_out,
                       colsum_ld, nullptr, nullptr, scratch, stream, false, pixels_per_image, n_valid, k_valid);
 }
