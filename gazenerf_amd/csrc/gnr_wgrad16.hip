@@ -9,8 +9,11 @@
 // no LDS, no barrier, independent waves, several per SIMD, operands straight from memory into v_mfma_f32_16x16x4_f32 --
 //   * a wave owns MT x NT tiles of 16 x 16 outputs over its split's pixels; padding is to multiples of 16 MT / 16 NT
 //     ((3,6) and (6,3): 516 = 11 x 48, 1032 = 11 x 96 - 24, 258 + 1 -> 3 x 96, 129 + 1 -> 3 x 48: <= 6 % in every product);
-//   * both operands are "rows of pixels": lane (li, g) loads pixels 32 kb + 8 g .. + 7 of row li of each of its tiles (two
-//     b128 per tile per 32 pixels = 8 MFMA steps; the contraction order over the pixels is free);
+//   * both operands are "rows of pixels": lane (li, g) loads pixels 16 h + 4 g .. + 3 of row li of each of its tiles (one
+//     b128 per tile per 16-pixel half step = 4 MFMA steps; the contraction order over the pixels is free), two operand
+//     sets, one half step ahead; three waves per SIMD (148 VGPRs).  Measured and dropped: 32-pixel steps with both halves of
+//     a 128-byte line requested back to back (three operand sets, 204 VGPRs, two waves per SIMD): 306 us against 272 on
+//     516 x 258 -- the second wave slot matters, the line halves do not;
 //   * the bias gradient is the last padded column of the product, against a row of ones that is never loaded (the lane that
 //     would hold it adds 1.0 to the zeros the descriptor's bound returns);
 //   * split-K over pixel ranges inside an image, one round of waves; partial tiles are summed in a fixed order by
@@ -35,11 +38,12 @@ struct Wgrad16Params {
 };
 
 constexpr int W16_WPB = 4;
+constexpr int W16_OCC = 3;               // waves per SIMD (148 VGPRs)
 
 __device__ __forceinline__ f32x4 mfma16g(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 template <int MT, int NT>
-__global__ __launch_bounds__(64 * W16_WPB, 2) void wgrad16_kernel(const Wgrad16Params wp) {
+__global__ __launch_bounds__(64 * W16_WPB, W16_OCC) void wgrad16_kernel(const Wgrad16Params wp) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int li = lane & 15, g = lane >> 4;
@@ -65,10 +69,7 @@ __global__ __launch_bounds__(64 * W16_WPB, 2) void wgrad16_kernel(const Wgrad16P
         (void*)(wp.A + ((long)b * wp.M + m0) * wp.P), 0, (int)(a_rows * wp.P * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(wp.B + ((long)b * wp.K + k0) * wp.P), 0, (int)(b_rows * wp.P * 4), 0x00020000);
-    // A step of the contraction is 32 pixels = one 128-byte line per row: lane group g takes pixels 8 g .. 8 g + 7 as TWO b128
-    // loads issued back to back (with 16-pixel steps the two halves of a line were requested one step -- ~18 KB of other
-    // waves' lines per wave -- apart and the second half came from L2 again: 14 TB/s of L2 reads at 63 % of the MFMA peak).
-    const unsigned row = ((unsigned)li * (unsigned)wp.P + 8u * (unsigned)g) * 4u;       // this lane's row / first pixel inside a tile
+    const unsigned row = ((unsigned)li * (unsigned)wp.P + 4u * (unsigned)g) * 4u;       // this lane's row / pixel quad inside a tile
     const unsigned tstride = (unsigned)__builtin_amdgcn_readfirstlane((int)(16u * (unsigned)wp.P * 4u));     // bytes between row tiles
 
     // the bias column is the LAST column of the padded product (the host pads to at least one column past K): tile NT - 1,
@@ -81,11 +82,9 @@ __global__ __launch_bounds__(64 * W16_WPB, 2) void wgrad16_kernel(const Wgrad16P
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    // three operand sets: the first halves (H0), and two alternating sets for the second halves (H1) -- both halves of step
-    // kb + 1 are requested together, right after the MFMAs of H0(kb), into the set H0(kb) just left and the H1 set not in use
-    f32x4 A0[MT], B0[NT], A1[2][MT], B1[2][NT];
+    f32x4 A1[2][MT], B1[2][NT];
     auto load = [&](int kb, int half, f32x4 (&A)[MT], f32x4 (&Bv)[NT]) {
-        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((kb0 + kb) * 128 + half * 16);
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((2 * (kb0 + kb) + half) * 64);
         // the row-tile stride rides in the scalar offset: one address register per lane
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -104,31 +103,17 @@ __global__ __launch_bounds__(64 * W16_WPB, 2) void wgrad16_kernel(const Wgrad16P
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16g(A[mt][s], nt == NT - 1 ? blast : Bv[nt][s], acc[mt][nt]);
         }
     };
-    if (nkb > 0) {
-        load(0, 0, A0, B0);
-        load(0, 1, A1[0], B1[0]);
-        int kb = 0;
-        for (; kb + 1 < nkb; kb += 2) {
-            __builtin_amdgcn_sched_barrier(0);
-            compute(A0, B0);
-            __builtin_amdgcn_sched_barrier(0);
-            load(kb + 1, 0, A0, B0);
-            load(kb + 1, 1, A1[1], B1[1]);
+    if (nkb > 0) {                                                // 16-pixel half steps, two operand sets, one half ahead
+        load(0, 0, A1[0], B1[0]);
+        for (int kb = 0; kb < nkb; ++kb) {
+            load(kb, 1, A1[1], B1[1]);
             __builtin_amdgcn_sched_barrier(0);
             compute(A1[0], B1[0]);
             __builtin_amdgcn_sched_barrier(0);
-            compute(A0, B0);
-            __builtin_amdgcn_sched_barrier(0);
-            const int k2 = kb + 2 < nkb ? kb + 2 : nkb - 1;       // even count: one redundant request at the end
-            load(k2, 0, A0, B0);
-            load(k2, 1, A1[0], B1[0]);
+            load(kb + 1 < nkb ? kb + 1 : kb, 0, A1[0], B1[0]);
             __builtin_amdgcn_sched_barrier(0);
             compute(A1[1], B1[1]);
             __builtin_amdgcn_sched_barrier(0);
-        }
-        if (nkb & 1) {
-            compute(A0, B0);
-            compute(A1[0], B1[0]);
         }
     }
     // register e of acc[mt][nt]: row m0 + 16 mt + 4 g + e, column k0 + 16 nt + li
@@ -176,10 +161,12 @@ __global__ __launch_bounds__(256) void wgrad16_reduce_kernel(const Wgrad16Reduce
 bool launch_wgrad16_img(const float* A, int M, const float* B, int K, int batch, long P, float* dW, int ldw, float* bias_out,
                         float* scratch, size_t scratch_floats, hipStream_t st) {
     // Only where the 192 x 192 tiles of the LDS-staged kernel are badly filled: measured per 7 images (us, this kernel / the
-    // old path) 516 x 258: 306 / 366, 258 x 129: 84 / 128, 129 x 258: 86 / 129, 516 x 258 at 64 x 64: 84 / 101 -- but
-    // 1032 x 516 (fill 0.80): 278 / 273 and the HBM-bound 256 x 128 at 256 x 256 (128 x 128 tiles, fill 1): 321 / 256.
+    // old path) 516 x 258: 272 / 366, 258 x 129: 90 / 128, 129 x 258: 86 / 129, 516 x 258 at 64 x 64: 79 / 101 -- but
+    // 1032 x 516 (fill 0.80): 288 / 273-285, and the tile-friendly, HBM-bound 256 x 128 at 256 x 256 (128 x 128 tiles): 315 / 256.
     const double fill192 = (double)M * K / ((double)((M + 191) / 192) * ((K + 191) / 192) * 192.0 * 192.0);
-    if (M < 100 || K < 100 || fill192 >= 0.7 || P % 32 || P * 4L * 96 >= (1L << 31)) return false;
+    if (M < 100 || K < 100 || !(M % 64 || K % 64) || fill192 >= 0.7 || P % 32 ||
+        (long)M * P * 4 >= (1L << 32) || (long)K * P * 4 >= (1L << 32))        // one 32-bit buffer descriptor per image operand
+        return false;
     const int kw = K + (bias_out ? 1 : 0);
     const int mt16 = (M + 15) / 16, kt16 = (kw + 15) / 16;
     // (3,6) or (6,3): the orientation with fewer padded tiles
@@ -193,7 +180,7 @@ bool launch_wgrad16_img(const float* A, int M, const float* B, int K, int batch,
     const long tiles = (long)wp.mg * wp.kg, area = (long)wp.mg * 16 * MT * wp.kg * 16 * NT;
     const long kb_img = P / 32;
     // one round of waves: 1024 SIMDs x 2 waves
-    long spi = 2048 / (tiles * batch);
+    long spi = 1024 * W16_OCC / (tiles * batch);
     if (spi < 1) spi = 1;
     if (spi > kb_img / 4) spi = kb_img / 4 > 0 ? kb_img / 4 : 1;                 // >= 128 pixels per split
     while (spi > 1 && (size_t)(batch * spi * area) > scratch_floats) --spi;

@@ -1,0 +1,11 @@
+#!/bin/bash
+# Round 4, GPU session 14: wgrad16 variants -- upsampler tests + B = 7 trace (kernel lines only)
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r4s14
+mkdir -p $O
+export TMPDIR=/tmp
+cd $R
+timeout 900 python -m pytest tests/test_upsample.py -m gpu -x -q 2>&1 | tail -2
+bash tools/n1_trace.sh r4s14/b7 --batch 7 --iters 5 > /dev/null 2>&1
+grep "N1 B" $O/b7/wall.log; grep -E "wgrad|kernel time" $O/b7/launches.txt | grep -v reduce
+rm -rf $O/*/prof
