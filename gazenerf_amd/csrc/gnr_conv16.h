@@ -21,8 +21,9 @@ struct Conv16Plan {
 // its own kernel".
 Conv16Plan conv16_plan(int M, int K, long pixels_total, int blur_w);
 // The variant for du = Wf^T g with the un-shuffle fused into its epilogue (NT == 8: a lane owns the 2 x 2 blocks of two
-// adjacent low-resolution pixels).  MT == 0 on return: not available (M % 4, side % 32, or a tile pinned by
-// gnr_set_conv16_tile) -- run the plain GEMM and the un-shuffle kernel.
+// adjacent low-resolution pixels).  MT == 0 on return: not available (side % 32, or a tile pinned by gnr_set_conv16_tile) --
+// run the plain GEMM and the un-shuffle kernel.  M % 4 == 0: pack with perm4 and pass dres; otherwise pack plainly, pass
+// dres = NULL and collect dres from dpre2 afterwards (unshuffle_dres_kernel).
 Conv16Plan conv16_plan_unshuffle(int M, int K, int side);
 
 constexpr int CONV16_MAX_JOBS = 12;
@@ -61,7 +62,7 @@ struct Conv16Params {
     //   dpre2(4c + 2i + j, y, x) = du(c, 2y + i, 2x + j) * (bit 2i + j of sign_in(c, y, x) ? 1 : 0.2),
     //   dres(c', y, x) = sum_q du((c' >> 2) + q C / 4, 2y + ((c' >> 1) & 1), 2x + (c' & 1))          (x.repeat adjoint)
     const unsigned char* sign_in;                  // [batch][C][W*W] (sign_batch above)
-    float* dres; long dres_batch;
+    float* dres; long dres_batch;                  // NULL: rows in natural order, dpre2 only
     // plain epilogue with plan.slices == 1 (a wave holds every output channel of its pixels): the 3-channel RGB branch
     // rides on it (round 4; rgb_conv_kernel re-read the whole block output for it) --
     //   rgb(b,o,n) = [rgb(b,o,n) +] rgb_bias[o] + sum_m rgb_w[o][m] C(b,m,n);  rgb_img = sigmoid(rgb) if given;

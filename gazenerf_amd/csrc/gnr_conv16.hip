@@ -424,7 +424,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv16_kernel(const Conv16Params 
 //   dres(4 cb + e) = sum_q G(cb + q C/4, sub-pixel e)
 // sit in ONE lane (the same fixed order as unshuffle_bwd4_kernel: results are bit-identical to the two-kernel path), and
 // dpre2 = G * lrelu'(pre2) leaves as 8-byte stores (16 lanes = 128 contiguous bytes of one channel plane).
-template <int MT>
+template <int MT, bool PERM>
 __global__ __launch_bounds__(64 * WPB, 2) void conv16_unshuffle_kernel(const Conv16Params cp) {
     constexpr int NT = 8;
     const int lane = threadIdx.x & 63;
@@ -505,30 +505,50 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv16_unshuffle_kernel(const Con
     }
     if (nkb & 1) compute(Aq[0], Bq[0]);
 
-    // ---- epilogue: register q of acc[mt][4 i + 2 xs + j] is du(cb + q Cq, 2y + i, 2 (x0 + xs) + j) ----
-    const int Cq = cp.M >> 2;
+    // ---- epilogue: register q of acc[mt][4 i + 2 xs + j] is du(channel of row q, 2y + i, 2 (x0 + xs) + j) ----
     const long Plo = (long)S * S;
     const long pix = (long)y * S + x0;
+    if constexpr (PERM) {
+        // rows packed with perm4: row q of a lane's quad is channel cb + q Cq -- the four x.repeat-adjoint terms in one lane
+        const int Cq = cp.M >> 2;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int cb = (m0 >> 2) + 4 * mt + g;
-        if (cb >= Cq) continue;
-        f32x2 G[4][4];                                            // [q][sub-pixel e = 2 i + j] over the lane's two pixels
+        for (int mt = 0; mt < MT; ++mt) {
+            const int cb = (m0 >> 2) + 4 * mt + g;
+            if (cb >= Cq) continue;
+            f32x2 G[4][4];                                        // [q][sub-pixel e = 2 i + j] over the lane's two pixels
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = cb + q * Cq;
-            const unsigned nib2 = *(const unsigned short*)(cp.sign_in + (long)b * cp.sign_batch + (long)c * Plo + pix);
-            float* dst = cp.C + (long)b * cp.c_batch + (long)(4 * c) * Plo + pix;
+            for (int q = 0; q < 4; ++q) {
+                const int c = cb + q * Cq;
+                const unsigned nib2 = *(const unsigned short*)(cp.sign_in + (long)b * cp.sign_batch + (long)c * Plo + pix);
+                float* dst = cp.C + (long)b * cp.c_batch + (long)(4 * c) * Plo + pix;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                G[q][e] = f32x2{acc[mt][4 * (e >> 1) + (e & 1)][q], acc[mt][4 * (e >> 1) + 2 + (e & 1)][q]};
-                *(f32x2*)(dst + (long)e * Plo) = f32x2{G[q][e].x * (((nib2 >> e) & 1u) ? 1.0f : LEAK16),
-                                                       G[q][e].y * (((nib2 >> (8 + e)) & 1u) ? 1.0f : LEAK16)};
+                for (int e = 0; e < 4; ++e) {
+                    G[q][e] = f32x2{acc[mt][4 * (e >> 1) + (e & 1)][q], acc[mt][4 * (e >> 1) + 2 + (e & 1)][q]};
+                    *(f32x2*)(dst + (long)e * Plo) = f32x2{G[q][e].x * (((nib2 >> e) & 1u) ? 1.0f : LEAK16),
+                                                           G[q][e].y * (((nib2 >> (8 + e)) & 1u) ? 1.0f : LEAK16)};
+                }
             }
-        }
-        float* dr = cp.dres + (long)b * cp.dres_batch + (long)(4 * cb) * Plo + pix;
+            float* dr = cp.dres + (long)b * cp.dres_batch + (long)(4 * cb) * Plo + pix;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) *(f32x2*)(dr + (long)e * Plo) = (G[0][e] + G[1][e]) + (G[2][e] + G[3][e]);
+            for (int e = 0; e < 4; ++e) *(f32x2*)(dr + (long)e * Plo) = (G[0][e] + G[1][e]) + (G[2][e] + G[3][e]);
+        }
+    } else {
+        // any channel count: rows in their natural order, dpre2 only -- the x.repeat adjoint's four terms of an output sit in
+        // four different row slices and are collected by unshuffle_dres_kernel from dpre2
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = m0 + 16 * mt + 4 * g + q;
+                if (c >= cp.M) continue;
+                const unsigned nib2 = *(const unsigned short*)(cp.sign_in + (long)b * cp.sign_batch + (long)c * Plo + pix);
+                float* dst = cp.C + (long)b * cp.c_batch + (long)(4 * c) * Plo + pix;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    *(f32x2*)(dst + (long)e * Plo) =
+                        f32x2{acc[mt][4 * (e >> 1) + (e & 1)][q] * (((nib2 >> e) & 1u) ? 1.0f : LEAK16),
+                              acc[mt][4 * (e >> 1) + 2 + (e & 1)][q] * (((nib2 >> (8 + e)) & 1u) ? 1.0f : LEAK16)};
+            }
     }
 }
 
@@ -765,11 +785,12 @@ int conv16_set_tile(int mt, int nt) {
                 "2x8, 3x8, 4x8 for the GEMM with the fused un-shuffle; 0, 0 restores the cost model)", mt, nt);
 }
 
-// du = Wf^T g + un-shuffle in one kernel: needs the x.repeat adjoint's four terms in one lane (M % 4 == 0) and a wave's 32
-// low-resolution columns inside one row.  A pinned plain tile (gnr_set_conv16_tile) means "the two-kernel path".
+// du = Wf^T g + un-shuffle in one kernel: a wave's 32 low-resolution columns must lie inside one row.  With M % 4 == 0 the rows
+// are packed with perm4 and the x.repeat adjoint (dres) comes out of the same epilogue; otherwise the epilogue writes dpre2 and
+// unshuffle_dres_kernel collects dres from it.  A pinned plain tile (gnr_set_conv16_tile) means "the two-kernel path".
 Conv16Plan conv16_plan_unshuffle(int M, int K, int side) {
     Conv16Plan p{};
-    if (M % 4 || side % 32 || g_forced_tile.load()) return p;
+    if (side % 32 || g_forced_tile.load()) return p;
     const int tiles = (M + 15) / 16;
     int mt = g_unshuffle_mt.load();
     if (!mt) {
@@ -878,10 +899,15 @@ int launch_conv16(const Conv16Params& cp, hipStream_t st) {
     if (cp.plan.NT == 8) {
         const long witems = (long)cp.batch * cp.W * (cp.W / 32) / WPB * cp.plan.slices;
         const unsigned wblocks = (unsigned)(8 * ((witems + 7) / 8));
-        switch (cp.plan.MT) {
-            case 2: hipLaunchKernelGGL((conv16_unshuffle_kernel<2>), dim3(wblocks), dim3(64 * WPB), 0, st, cp); break;
-            case 3: hipLaunchKernelGGL((conv16_unshuffle_kernel<3>), dim3(wblocks), dim3(64 * WPB), 0, st, cp); break;
-            case 4: hipLaunchKernelGGL((conv16_unshuffle_kernel<4>), dim3(wblocks), dim3(64 * WPB), 0, st, cp); break;
+        const int key = 2 * cp.plan.MT + (cp.dres ? 1 : 0);       // dres given: rows packed with perm4 (M % 4 == 0)
+        if (cp.dres && cp.M % 4) return fail("conv16: the un-shuffle epilogue with dres needs M %% 4 == 0 (M = %d)", cp.M);
+        switch (key) {
+            case 5: hipLaunchKernelGGL((conv16_unshuffle_kernel<2, true>), dim3(wblocks), dim3(64 * WPB), 0, st, cp); break;
+            case 7: hipLaunchKernelGGL((conv16_unshuffle_kernel<3, true>), dim3(wblocks), dim3(64 * WPB), 0, st, cp); break;
+            case 9: hipLaunchKernelGGL((conv16_unshuffle_kernel<4, true>), dim3(wblocks), dim3(64 * WPB), 0, st, cp); break;
+            case 4: hipLaunchKernelGGL((conv16_unshuffle_kernel<2, false>), dim3(wblocks), dim3(64 * WPB), 0, st, cp); break;
+            case 6: hipLaunchKernelGGL((conv16_unshuffle_kernel<3, false>), dim3(wblocks), dim3(64 * WPB), 0, st, cp); break;
+            case 8: hipLaunchKernelGGL((conv16_unshuffle_kernel<4, false>), dim3(wblocks), dim3(64 * WPB), 0, st, cp); break;
             default: return fail("conv16: no fused un-shuffle instance for MT = %d", cp.plan.MT);
         }
         return 0;

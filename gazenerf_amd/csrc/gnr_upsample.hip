@@ -590,6 +590,31 @@ __global__ __launch_bounds__(256) void unshuffle_bwd4_kernel(const float* __rest
         *(f32x4*)(dres + (b * C + 4 * cb + e) * P + p) = (G[0][e] + G[1][e]) + (G[2][e] + G[3][e]);
 }
 
+// x.repeat adjoint from the MASKED gradient (round 4: when the du GEMM's epilogue has already written dpre2 and the channel
+// count is no multiple of 4, so that the four terms of an output come from four different row slices of that GEMM):
+//   dres(b,c,p) = sum_q G(b, c + q C, p),   G(b,k,p) = dpre2(b,k,p) * (bit k&3 of sign(b,k>>2,p) ? 1 : 1/0.2)
+// The un-masking multiplies by 5.0f where the mask multiplied by 0.2f: one rounding (<= 1 ulp of that term) away from the
+// two-kernel path, which sums the unmasked du.  Same order of the four terms.  A thread = 4 consecutive pixels.
+__global__ __launch_bounds__(256) void unshuffle_dres_kernel(const float* __restrict__ dpre2, const unsigned char* __restrict__ sign,
+                                                             int C, long P, int batch, float* __restrict__ dres) {
+    const long nq = P / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)batch * C * nq) return;
+    const long b = idx / ((long)C * nq), rem = idx - b * (long)C * nq;
+    const int c = (int)(rem / nq);
+    const long p = 4 * (rem - (long)c * nq);
+    f32x4 G[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = c + q * C;
+        const f32x4 v = *(const f32x4*)(dpre2 + (b * 4 * C + k) * P + p);
+        const unsigned nib4 = *(const unsigned*)(sign + (b * C + (k >> 2)) * P + p);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) G[q][t] = v[t] * (((nib4 >> (8 * t + (k & 3))) & 1u) ? 1.0f : 1.0f / LEAK);
+    }
+    *(f32x4*)(dres + (b * C + c) * P + p) = (G[0] + G[1]) + (G[2] + G[3]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -679,7 +704,7 @@ static size_t plan_bwd(const UpDims& d, int B, const GnrUpsampleWeights* w, Bloc
         q.c3 = conv16_plan_unshuffle(C, Cn, S);
         q.unshuffle_fused = q.c3.MT != 0;
         if (!q.unshuffle_fused) q.c3 = conv16_plan(C, Cn, 4 * px, 0);
-        q.o3 = conv16_add_job(J, w ? w->feat_w[i] : nullptr, 1, C, C, Cn, q.c3, q.unshuffle_fused ? 1 : 0);
+        q.o3 = conv16_add_job(J, w ? w->feat_w[i] : nullptr, 1, C, C, Cn, q.c3, q.unshuffle_fused && C % 4 == 0 ? 1 : 0);
         q.c2 = conv16_plan(2 * C, 4 * C, px, 0);
         q.o2 = conv16_add_job(J, w ? w->up2_w[i] : nullptr, 1, 2 * C, 2 * C, 4 * C, q.c2);
         q.c1 = conv16_plan(C, 2 * C, px, 0);
@@ -989,8 +1014,10 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
         if (bp[i].unshuffle_fused) {
             // round 4: du never reaches memory -- the GEMM's epilogue writes dpre2 (-> X; Y = g is still being read) and dres
             g.C = X; g.c_batch = 4L * C * P; g.W = S; g.sign_in = s.sign2[i]; g.sign_batch = (long)C * P;
-            g.dres = dnet; g.dres_batch = (long)C * P;
+            if (C % 4 == 0) { g.dres = dnet; g.dres_batch = (long)C * P; }
             if (launch_conv16(g, st)) return 1;
+            if (C % 4)            // the x.repeat adjoint's terms sit in different row slices of the GEMM: collected from dpre2
+                hipLaunchKernelGGL(unshuffle_dres_kernel, dim3(blocks_for((long)B * C * (P / 4))), dim3(256), 0, st, X, s.sign2[i], C, P, B, dnet);
             float* sw = X; X = Y; Y = sw;                                        // Y = dpre2, X free for dpre1
         } else {
             g.C = X; g.c_batch = (long)C * P4;
