@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "../../include/gnr.h"
 #include "gnr_conv16.h"
@@ -378,6 +379,34 @@ __global__ __launch_bounds__(256) void rgb_bwd_fused_kernel(const float* __restr
 // and one read of the C/2-channel gradient per block).  Weight-gradient partials as above (centre pixels only).
 constexpr int RB_TH = 16, RB_TW = 64, RB_LD = 72, RB_TILE = (RB_TH + 2) * RB_LD;      // LDS row: 3 pad + 66 used + 3
 
+// sum over the 16 lanes of a DPP row, in every lane of the row: xor-1 / xor-2 butterflies inside the quads, then the half-row and
+// row mirrors
+__device__ __forceinline__ float row_sum16(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});            // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});            // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});           // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});           // row_mirror
+    return v;
+}
+// a, b, c, d: four values that are uniform inside each 16-lane row; returns, in row r of the wave, the sum over the four rows of
+// value r (v_permlane16_swap: [a0 b0 a2 b2], [a1 b1 a3 b3]; v_permlane32_swap of the two pair sums: [a01 b01 c01 d01], [a23 ...])
+__device__ __forceinline__ float rows_total4(float a, float b, float c, float d) {
+    auto sw16 = [](float x, float y) {
+        auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
+        const unsigned r0 = r[0], r1 = r[1];
+        return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+    };
+    auto sw32 = [](float x, float y) {
+        auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
+        const unsigned r0 = r[0], r1 = r[1];
+        return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+    };
+    return sw32(sw16(a, b), sw16(c, d));
+}
+
 __global__ __launch_bounds__(256) void rgb_bwd_blur_kernel(const float* __restrict__ drgb, const float* __restrict__ net, int C,
                                                            int H, int W, int batch, const float* __restrict__ w,
                                                            const float* __restrict__ dnet_in, float* __restrict__ gout,
@@ -427,12 +456,28 @@ __global__ __launch_bounds__(256) void rgb_bwd_blur_kernel(const float* __restri
     const int cbeg = (int)blockIdx.y * cper;
     const int cend = cbeg + cper < C ? cbeg + cper : C;
     const bool with_bias = blockIdx.y + 1 == gridDim.y;
+    // The memory operands of channel c + 1 are requested before channel c is worked on (round 4): a workgroup's channels are a
+    // serial chain (load -> LDS -> barrier -> stencil -> store), and with the load at the top of the iteration every channel
+    // paid a full memory latency -- 155 us for 470 MB at the 512 x 512 level.
+    f32x4 nv_n = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, dn_n = nv_n;
+    float hn_n = 0.0f, hd_n = 0.0f;
+    auto fetch = [&](int c) {
+        nv_n = *(const f32x4*)(net + base + (long)c * P);
+        if (dnet_in) dn_n = *(const f32x4*)(dnet_in + base + (long)c * P);
+        if (hin) {
+            hn_n = net[hbase + (long)c * P];
+            if (dnet_in) hd_n = dnet_in[hbase + (long)c * P];
+        }
+    };
+    if (cbeg < cend) fetch(cbeg);
     for (int c = cbeg, j = 0; c < cend; ++c, ++j) {
         float* tb = tile + (j & 1) * RB_TILE;
         const float w0 = w[c], w1 = w[C + c], w2 = w[2 * C + c];
-        const f32x4 nv = *(const f32x4*)(net + base + (long)c * P);
+        const f32x4 nv = nv_n, dn = dn_n;
+        const float hn = hn_n, hd = hd_n;
+        fetch(c + 1 < cend ? c + 1 : c);
         f32x4 v = w0 * g[0] + w1 * g[1] + w2 * g[2];
-        if (dnet_in) v += *(const f32x4*)(dnet_in + base + (long)c * P);
+        if (dnet_in) v += dn;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= nv[e] > 0.0f ? 1.0f : LEAK;
         *(f32x4*)(tb + cpos) = v;
@@ -440,8 +485,8 @@ __global__ __launch_bounds__(256) void rgb_bwd_blur_kernel(const float* __restri
             float hv = 0.0f;
             if (hin) {
                 hv = w0 * hg[0] + w1 * hg[1] + w2 * hg[2];
-                if (dnet_in) hv += dnet_in[hbase + (long)c * P];
-                hv *= net[hbase + (long)c * P] > 0.0f ? 1.0f : LEAK;
+                if (dnet_in) hv += hd;
+                hv *= hn > 0.0f ? 1.0f : LEAK;
             }
             tb[hpos] = hv;
         }
@@ -451,11 +496,12 @@ __global__ __launch_bounds__(256) void rgb_bwd_blur_kernel(const float* __restri
             for (int o = 0; o < 3; ++o)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) a[o] = fmaf(g[o][e], nv[e], a[o]);
+            // the three wave sums without the LDS pipe (18 ds_bpermute per channel before): inside the 16-lane rows by DPP
+            // butterflies, across the four rows by the gfx950 row / half swaps -- row o of the wave ends up with the total of a[o]
 #pragma unroll
-            for (int o = 0; o < 3; ++o) {
-                const float t = wave_sum(a[o]);
-                if (lane == 0) wsum[(wave * 3 + o) * (C + 1) + c] = t;
-            }
+            for (int o = 0; o < 3; ++o) a[o] = row_sum16(a[o]);
+            const float t = rows_total4(a[0], a[1], a[2], 0.0f);
+            if ((lane & 15) == 0 && lane < 48) wsum[(wave * 3 + (lane >> 4)) * (C + 1) + c] = t;
         }
         __syncthreads();
         f32x4 rows[3];
