@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--batch", type=int, default=7)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--fwd-only", action="store_true")
+    ap.add_argument("--split", type=int, default=0, help="experiment: the batch as this many groups of images, each on its own stream")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -31,7 +32,38 @@ def main():
     x = torch.randn(a.batch, 258, 64, 64, device=dev, requires_grad=not a.fwd_only)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 
+    streams = [torch.cuda.Stream() for _ in range(a.split)]
+    parts = list(torch.chunk(x.detach(), a.split)) if a.split else []
+    for q in parts:
+        q.requires_grad_(not a.fwd_only)
+
+    def step_split(mark=False):
+        cur = torch.cuda.current_stream()
+        if mark: ev[0].record()
+        ys = []
+        for sidx, q in zip(streams, parts):
+            sidx.wait_stream(cur)
+            with torch.cuda.stream(sidx):
+                if a.fwd_only:
+                    with torch.no_grad():
+                        ys.append(net(q))
+                else:
+                    ys.append(net(q))
+        for sidx in streams:
+            cur.wait_stream(sidx)
+        if mark: ev[1].record()
+        if not a.fwd_only:
+            for sidx, y in zip(streams, ys):
+                sidx.wait_stream(cur)
+                with torch.cuda.stream(sidx):
+                    y.backward(torch.ones_like(y))
+            for sidx in streams:
+                cur.wait_stream(sidx)
+        if mark: ev[2].record()
+
     def step(mark=False):
+        if a.split:
+            return step_split(mark)
         if a.fwd_only:
             with torch.no_grad():
                 if mark: ev[0].record()
