@@ -14,15 +14,16 @@
 #include <atomic>
 
 #include "gnr_bwd_common.h"
+#include "gnr_wgrad.h"
 
 namespace gnr {
 int fail(const char* fmt, ...);
 size_t carve_fwd(const GnrProblem* p, int n_streams, bool save, char* base, FwdParams* fp);
-size_t wgrad_scratch_floats();
+size_t wgrad_arena_floats();
 void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, int batch,
                   long chunks_per_image, float* dW, int ldw, int col_off, int enc_map, float* colsum_out,
                   int colsum_ld, const float* vec, float* vec_out, float* scratch, hipStream_t stream, bool bf16x3,
-                  int n_crop = -1, int k_crop = -1, bool small_tiles = false);
+                  int n_crop = -1, int k_crop = -1, bool small_tiles = false, WgradDefer* defer = nullptr);
 void launch_vecsum(const float* v, int batch, long per_image, float* out, int out_stride, hipStream_t stream);
 void stage_mark(int stage, int which, hipStream_t st);
 struct VdBwdScratch { float* d_rb[2]; float* dR_part; float* dW_part; float* dR_extra; int bpi, segs; };
@@ -445,7 +446,7 @@ static size_t carve_bwd(const GnrProblem* p, char* base, BwdScratch* sc) {
     s.geo_part = take((size_t)p->batch * s.geo_blocks * 12);
     s.dbias = take((size_t)(N_CHAIN + 1) * p->batch * H);
     s.cs_part = nullptr;
-    s.wg_part = take(wgrad_scratch_floats());
+    s.wg_part = take(wgrad_arena_floats());           // partial tiles of every weight-gradient GEMM of one weight set (gnr_wgrad.h)
     s.vd = vd_on_device(p) ? take(vd_bwd_floats(p, 2)) : nullptr;
     if (sc) *sc = s;
     return off;
@@ -541,38 +542,42 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         auto dbl = [&](int l) { return sc.dbias + (size_t)l * p->batch * H; };
         const long cpi = (long)p->n_rays * cpr;                       // chunks per image
         if (s == 0) stage_mark(GNR_STAGE_WGRAD, 0, st);
+        // the split-K reductions of the GEMMs below are queued and run as ONE launch behind the last GEMM (gnr_wgrad.h)
+        WgradDefer wd;
+        wgrad_defer_init(&wd, sc.wg_part, wgrad_arena_floats());
         // GEMM shapes = the kernels' (H, H2); the last two arguments crop the written gradient to the network's width
         if (!bf16x3 && p->feat_nc > 192 && p->feat_nc <= 288) {
             // RGB_layer_2 (258 x 192): as ONE product its rows pad to two 192-row tiles, the second two-thirds empty
             // (1.04 ms: 0.6 of the clock's peak).  Rows 0..191 are a full 192 x 192 tile (all 256 CUs, one round); the 66 rows
             // beyond go to a 96-row tile of wgrad_kernel -- same dumps, the operand base moved 192 channels (S16 rows of 16 floats) into the sub-chunk.
             launch_wgrad(sc.dfeat, FEAT_PAD, 192, ws.act_y1, H2, H2, p->batch, cpi, DW.rgb_w[2], Hh2, 0, 0,
-                         dbl(LR2), H, nullptr, nullptr, sc.wg_part, st, false, 192, Hh2);
+                         dbl(LR2), H, nullptr, nullptr, sc.wg_part, st, false, 192, Hh2, false, &wd);
             launch_wgrad(sc.dfeat + 192 * 16, FEAT_PAD, p->feat_nc - 192, ws.act_y1, H2, H2, p->batch, cpi,      // S16: 16 floats per row
                          DW.rgb_w[2] ? DW.rgb_w[2] + (size_t)192 * Hh2 : nullptr, Hh2, 0, 0, dbl(LR2) + 192, H, nullptr, nullptr,
-                         sc.wg_part, st, false, p->feat_nc - 192, Hh2, true);
+                         sc.wg_part, st, false, p->feat_nc - 192, Hh2, true, &wd);
         } else {
             launch_wgrad(sc.dfeat, FEAT_PAD, p->feat_nc, ws.act_y1, H2, H2, p->batch, cpi, DW.rgb_w[2], Hh2, 0, 0,
-                         dbl(LR2), H, nullptr, nullptr, sc.wg_part, st, bf16x3, p->feat_nc, Hh2);
+                         dbl(LR2), H, nullptr, nullptr, sc.wg_part, st, bf16x3, p->feat_nc, Hh2, false, &wd);
         }
         launch_wgrad(sc.dY_r1, H2, H2, ws.act_y0, H, H, p->batch, cpi, DW.rgb_w[1], Hh + p->vd_dims + p->appea_dims, 0, 0,
-                     dbl(LR1), H, nullptr, nullptr, sc.wg_part, st, bf16x3, Hh2, Hh);
+                     dbl(LR1), H, nullptr, nullptr, sc.wg_part, st, bf16x3, Hh2, Hh, false, &wd);
         launch_wgrad(sc.dY_r0, H, H, hptr(7), H, H, p->batch, cpi, DW.rgb_w[0], Hh, 0, 0, dbl(LR0), H,
-                     sc.dsig, DW.density_w, sc.wg_part, st, bf16x3, Hh, Hh);
+                     sc.dsig, DW.density_w, sc.wg_part, st, bf16x3, Hh, Hh, false, &wd);
         for (int l = 7; l >= 1; --l) {
             if (l == 5) {
                 launch_wgrad(dyh(5), H, H, hptr(4), H, H, p->batch, cpi, DW.fea_w[5], vp + Hh, vp, 0, dbl(5), H,
-                             nullptr, nullptr, sc.wg_part, st, bf16x3, Hh, Hh);
+                             nullptr, nullptr, sc.wg_part, st, bf16x3, Hh, Hh, false, &wd);
                 if (DW.fea_w[5])
                     launch_wgrad(dyh(5), H, H, bf16x3 ? fp.enc3 : fp.enc, ENC_PAD, ENC_PAD, p->batch, cpi, DW.fea_w[5], vp + Hh, 0,
-                                 bf16x3 ? 2 : 1, nullptr, 0, nullptr, nullptr, sc.wg_part, st, bf16x3, Hh, ENC_PAD);
+                                 bf16x3 ? 2 : 1, nullptr, 0, nullptr, nullptr, sc.wg_part, st, bf16x3, Hh, ENC_PAD, false, &wd);
             } else {
                 launch_wgrad(dyh(l), H, H, hptr(l - 1), H, H, p->batch, cpi, DW.fea_w[l], Hh, 0, 0, dbl(l), H,
-                             nullptr, nullptr, sc.wg_part, st, bf16x3, Hh, Hh);
+                             nullptr, nullptr, sc.wg_part, st, bf16x3, Hh, Hh, false, &wd);
             }
         }
         launch_wgrad(dyh(0), H, H, bf16x3 ? fp.enc3 : fp.enc, ENC_PAD, ENC_PAD, p->batch, cpi, DW.fea_w[0], vp, 0, bf16x3 ? 2 : 1,
-                     dbl(0), H, nullptr, nullptr, sc.wg_part, st, bf16x3, Hh, ENC_PAD);
+                     dbl(0), H, nullptr, nullptr, sc.wg_part, st, bf16x3, Hh, ENC_PAD, false, &wd);
+        wgrad_defer_flush(&wd, st);
         if (s == 0) stage_mark(GNR_STAGE_WGRAD, 1, st);
         launch_vecsum(sc.dsig_ray, p->batch, p->n_rays, dbl(N_CHAIN), H, st);
 

@@ -30,13 +30,14 @@
 #include "../../include/gnr.h"
 #include "gnr_conv16.h"
 #include "gnr_device.h"
+#include "gnr_wgrad.h"
 
 namespace gnr {
 int fail(const char* fmt, ...);
-size_t wgrad_scratch_floats();
+size_t wgrad_arena_floats();
 void launch_wgrad_img(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, int batch,
                       long pixels_per_image, float* dW, int ldw, float* colsum_out, int colsum_ld, float* scratch,
-                      hipStream_t stream);
+                      hipStream_t stream, WgradDefer* defer);
 
 constexpr float LEAK = 0.2f;
 constexpr int UP_MAX = GNR_UPSAMPLE_MAX_BLOCKS;
@@ -806,7 +807,7 @@ struct UpScratch {                      // backward temporaries
                                         // saved forward state stays intact and a second backward (retain_graph) is valid
     float* drgb_a; float* drgb_b;       // [B][3][Pn]
     float* colsum;                      // [B][max M]
-    float* wg;                          // wgrad partial tiles
+    float* wg;                          // partial tiles of every weight-gradient GEMM of the call (gnr_wgrad.h)
 };
 
 static size_t up_carve_bwd(const GnrUpsampleProblem* p, const UpDims& d, char* base, UpScratch* s) {
@@ -836,7 +837,7 @@ static size_t up_carve_bwd(const GnrUpsampleProblem* p, const UpDims& d, char* b
         if (cs_floats < need) cs_floats = need;
     }
     z.colsum = (float*)take(cs_floats * 4);
-    z.wg = (float*)take(wgrad_scratch_floats() * 4);
+    z.wg = (float*)take(wgrad_arena_floats() * 4);
     if (s) *s = z;
     return off;
 }
@@ -1007,6 +1008,10 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
     jobs.dst = s.pack;
     launch_conv16_pack(jobs, st);                 // every transposed weight matrix of the call, one launch
 
+    // the split-K reductions of the nine weight-gradient GEMMs are queued and run as ONE launch at the end of the call
+    WgradDefer wd;
+    wgrad_defer_init(&wd, t.wg, wgrad_arena_floats());
+
     // Blur and the 1x1 convolution act on different axes (pixels / channels) and commute: with g = blur^T(dhid)
     //   dWf = g u^T,  dbf = sum g (= sum dhid: blur's rows sum to 1),  du = Wf^T g,
     // so the adjoint stencil runs on the C/2 channels of dhid instead of the C channels of dv, and the forward never has to
@@ -1049,7 +1054,7 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
             }
         }
         // feat_layers[i]: dWf = g u^T, dbf; du = Wf^T g
-        launch_wgrad_img(Y, Cn, Cn, s.u[i], C, C, B, P4, G.feat_w[i], C, G.feat_b[i], 0, t.wg, st);
+        launch_wgrad_img(Y, Cn, Cn, s.u[i], C, C, B, P4, G.feat_w[i], C, G.feat_b[i], 0, t.wg, st, &wd);
         // un-shuffle: dpre2 and the residual part of d(net_in) into backward scratch (block 0: straight into the
         // caller's d_x).  X is g0 (last block) or the previous d(net), Y the other of g0 / g1: d(net) takes g2, g1, g2, ...
         // -- never a buffer of the saved forward workspace (round 3 wrote it over u[i], which made a second backward over
@@ -1076,13 +1081,13 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
                                    dnet);
         }
         // layer_2: dW2 = dpre2 a1^T, db2; dpre1 = (W2^T dpre2) * lrelu'(a1)  (-> X)
-        launch_wgrad_img(Y, 4 * C, 4 * C, s.a1[i], 2 * C, 2 * C, B, P, G.up2_w[i], 2 * C, G.up2_b[i], 0, t.wg, st);
+        launch_wgrad_img(Y, 4 * C, 4 * C, s.a1[i], 2 * C, 2 * C, B, P, G.up2_w[i], 2 * C, G.up2_b[i], 0, t.wg, st, &wd);
         g = Conv16Params{};
         g.plan = bp[i].c2; g.At = s.pack + bp[i].o2; g.B = Y; g.b_batch = 4L * C * P; g.C = X; g.c_batch = 2L * C * P;
         g.M = 2 * C; g.K = 4 * C; g.P = (int)P; g.batch = B; g.mask_ref = s.a1[i]; g.mask_batch = 2L * C * P;
         if (launch_conv16(g, st)) return 1;
         // layer_1: dW1 = dpre1 net_in^T, db1; dnet += W1^T dpre1
-        launch_wgrad_img(X, 2 * C, 2 * C, net_in, C, C, B, P, G.up1_w[i], C, G.up1_b[i], 0, t.wg, st);
+        launch_wgrad_img(X, 2 * C, 2 * C, net_in, C, C, B, P, G.up1_w[i], C, G.up1_b[i], 0, t.wg, st, &wd);
         g = Conv16Params{};
         g.plan = bp[i].c1; g.At = s.pack + bp[i].o1; g.B = X; g.b_batch = 2L * C * P; g.C = dnet; g.c_batch = (long)C * P;
         g.M = C; g.K = 2 * C; g.P = (int)P; g.batch = B; g.accumulate = 1;
@@ -1104,6 +1109,7 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
                 hipLaunchKernelGGL(rgb_wsum_kernel, dim3(3 * (d.ch[0] + 1)), dim3(64), 0, st, t.colsum, d.ch[0], (int)nwg, G.rgb_w[0], G.rgb_b[0]);
         }
     }
+    wgrad_defer_flush(&wd, st);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("gnr_upsample_bwd: launch failed: %s", hipGetErrorString(e));
     return 0;

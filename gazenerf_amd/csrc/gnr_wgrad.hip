@@ -35,6 +35,7 @@
 #include <type_traits>
 
 #include "gnr_chain3.h"
+#include "gnr_wgrad.h"
 
 namespace gnr {
 
@@ -1172,32 +1173,19 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr_kernel(const WgradParams wp)
     }
 }
 
-struct WgradReduceParams {
-    const float* partial;
-    int splits, tiles_n, tiles_k;
-    int tn_rows, tk_cols;     // workgroup tile of the GEMM kernel that wrote the partials
-    int cs_q, vs_q;           // rider shares per split (wgrad_pipe_kernel: 2 tiles_k / 2 tiles_n; else 1)
-    int n_valid, k_valid;
-    float* dW;          // destination matrix (NULL: skip)
-    int ldw, col_off;
-    int enc_map;        // 1: column k is an encoding slot (2*step+h) -> reference channel; 2: the bf16x3 dump's order
-    // optional extras
-    const float* colsum_part; float* colsum_out; int colsum_ld; int batch, spi;   // out[b][n]
-    const float* vec_part; float* vec_out;                                         // out[k]
-};
 
 // dW: thread (e, g) of a 256-thread block adds the splits sp = g, g + G, g + 2G, ... of output element e in that order
 // (G = 4 groups x 64 elements, or 16 x 16 for small outputs with hundreds of splits), then the G partial sums are
 // combined in LDS in a fixed order: deterministic, coalesced (a wave reads 64 or 16 consecutive floats of one
 // partial tile row), and 4-16x the loads in flight of one thread per element.
 template <int G>
-__device__ __forceinline__ void reduce_dw(const WgradReduceParams& rp, float* sm) {
+__device__ __forceinline__ void reduce_dw(const WgradReduceParams& rp, float* sm, unsigned bid, unsigned nb) {
     constexpr int E = 256 / G;
     const long total = (long)rp.n_valid * rp.k_valid;
     const int tid = threadIdx.x, el = tid % E, g = tid / E;
     const long tsz = (long)rp.tn_rows * rp.tk_cols;
     const long sstride = (long)rp.tiles_n * rp.tiles_k * tsz;
-    for (long e0 = (long)blockIdx.x * E; e0 < total; e0 += (long)gridDim.x * E) {
+    for (long e0 = (long)bid * E; e0 < total; e0 += (long)nb * E) {
         const long e = e0 + el;
         float acc = 0.0f;
         int n = 0, k = 0;
@@ -1233,14 +1221,14 @@ __device__ __forceinline__ void reduce_dw(const WgradReduceParams& rp, float* sm
 // The same for four consecutive columns per thread (16-byte loads; k_valid and the tile width are multiples of 4 for
 // every layer of the full-width network): per element the SAME order of additions as reduce_dw<4>, a quarter of the
 // load instructions.  Round 2: the 384^2 reductions took 149 us each (37.7 MB of partials: 250 GB/s) with scalar loads.
-__device__ __forceinline__ void reduce_dw_vec4(const WgradReduceParams& rp, f32x4* sm4) {
+__device__ __forceinline__ void reduce_dw_vec4(const WgradReduceParams& rp, f32x4* sm4, unsigned bid, unsigned nb) {
     constexpr int G = 4, E = 64;
     const long total4 = ((long)rp.n_valid * rp.k_valid) / 4;
     const int kq = rp.k_valid / 4;
     const int tid = threadIdx.x, el = tid % E, g = tid / E;
     const long tsz = (long)rp.tn_rows * rp.tk_cols;
     const long sstride = (long)rp.tiles_n * rp.tiles_k * tsz;
-    for (long e0 = (long)blockIdx.x * E; e0 < total4; e0 += (long)gridDim.x * E) {
+    for (long e0 = (long)bid * E; e0 < total4; e0 += (long)nb * E) {
         const long e = e0 + el;
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
         int n = 0, k = 0;
@@ -1281,15 +1269,15 @@ __device__ __forceinline__ void reduce_dw_vec4(const WgradReduceParams& rp, f32x
     }
 }
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceParams rp) {
-    __shared__ f32x4 sm4[256];
+// One reduction, run by blocks bid = 0 .. nb - 1 of 256 threads (a launch of its own, or a block range of the batched launch).
+__device__ __forceinline__ void wgrad_reduce_body(const WgradReduceParams& rp, unsigned bid, unsigned nb, f32x4* sm4) {
     float* sm = (float*)sm4;
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x, gsz = (long)gridDim.x * blockDim.x;
+    const long gid = (long)bid * 256 + threadIdx.x, gsz = (long)nb * 256;
     if (rp.dW) {
         const long total = (long)rp.n_valid * rp.k_valid;
-        if (total >= 16384 && (rp.k_valid & 3) == 0 && (rp.tk_cols & 3) == 0) reduce_dw_vec4(rp, sm4);
-        else if (total >= 16384) reduce_dw<4>(rp, sm);
-        else reduce_dw<16>(rp, sm);
+        if (total >= 16384 && (rp.k_valid & 3) == 0 && (rp.tk_cols & 3) == 0) reduce_dw_vec4(rp, sm4, bid, nb);
+        else if (total >= 16384) reduce_dw<4>(rp, sm, bid, nb);
+        else reduce_dw<16>(rp, sm, bid, nb);
     }
     // Rider sums: a few hundred shares per output, summed by ONE thread in share order (deterministic).  The loads are
     // issued 16 at a time and added in order: a serial chain of 256 dependent-latency loads took ~125 us per 384-row
@@ -1331,6 +1319,45 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReducePara
             rp.vec_out[e] = ordered_sum(rp.vec_part + e, (long)rp.tiles_k * rp.tk_cols, rp.splits * rp.vs_q);
 }
 
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceParams rp) {
+    __shared__ f32x4 sm4[256];
+    wgrad_reduce_body(rp, blockIdx.x, gridDim.x, sm4);
+}
+
+// Every queued reduction of a WgradDefer in one launch (gnr_wgrad.h): block b belongs to the job j with first[j] <= b <
+// first[j + 1] and runs that job exactly as its own launch would have -- same block count, same order of additions.
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgradReduceBatch rb) {
+    __shared__ f32x4 sm4[256];
+    int j = 0;
+    while (j + 1 < rb.n && blockIdx.x >= rb.first[j + 1]) ++j;
+    const unsigned bid = blockIdx.x - rb.first[j], nb = rb.first[j + 1] - rb.first[j];
+    if (rb.kind[j] == 0) wgrad_reduce_body(rb.r[j], bid, nb, sm4);
+    else wgrad16_reduce_body(rb.r16[j], bid);
+}
+
+void wgrad_defer_flush(WgradDefer* d, hipStream_t st) {
+    if (d->batch.n > 0)
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(d->batch.first[d->batch.n]), dim3(256), 0, st, d->batch);
+    d->batch.n = 0;
+    d->cursor = 0;
+}
+float* wgrad_defer_take(WgradDefer* d, size_t floats, hipStream_t st) {
+    floats = (floats + 63) & ~(size_t)63;
+    if (floats > d->arena_floats) return nullptr;
+    if (d->batch.n >= WG_DEFER_MAX || d->cursor + floats > d->arena_floats) wgrad_defer_flush(d, st);
+    float* q = d->arena + d->cursor;
+    d->cursor += floats;
+    return q;
+}
+void wgrad_defer_push(WgradDefer* d, const WgradReduceParams& rp, unsigned blocks) {
+    const int j = d->batch.n++;
+    d->batch.kind[j] = 0; d->batch.r[j] = rp; d->batch.first[j + 1] = d->batch.first[j] + blocks;
+}
+void wgrad_defer_push16(WgradDefer* d, const Wgrad16ReduceParams& rp, unsigned blocks) {
+    const int j = d->batch.n++;
+    d->batch.kind[j] = 1; d->batch.r16[j] = rp; d->batch.first[j + 1] = d->batch.first[j] + blocks;
+}
+
 constexpr int WG_MAX_BLOCKS = 1024;       // splits * tiles bound: ~2 rounds of 2 workgroups per CU
 constexpr int WG_MAX_TILE = WG_TN * WG_TK;    // floats; every tile configuration stays below it
 constexpr int WG_RIDER_ROWS = 192;            // largest tile edge
@@ -1338,6 +1365,10 @@ constexpr int WG_RIDER_ROWS = 192;            // largest tile edge
 size_t wgrad_scratch_floats() {
     return (size_t)WG_MAX_BLOCKS * WG_MAX_TILE + 2 * (size_t)WG_MAX_BLOCKS * WG_RIDER_ROWS;
 }
+// Scratch for the queued reductions of one weight set / one upsampler backward (gnr_wgrad.h): a 384 x 384 layer's GEMM takes
+// 256 tiles of 192 x 192 + its rider shares = 9.8 M floats, so four single-GEMM scratches (152 M floats, 610 MB) hold all 13-14
+// GEMMs of a weight set at once; anything beyond is handled by an early flush.
+size_t wgrad_arena_floats() { return 4 * wgrad_scratch_floats(); }
 
 // fp32 tile configurations: {rows, cols, relative cost per MFMA slot (LDS reads per MFMA, 3-wave workgroups)}
 struct TileCfg { int tn, tk; float cost; };
@@ -1367,7 +1398,8 @@ static int choose_tile(int n_valid, int k_valid, bool vec) {
 static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, int batch,
                               long chunks_per_image, float* dW, int ldw, int col_off, int enc_map, float* colsum_out,
                               int colsum_ld, const float* vec, float* vec_out, float* scratch, hipStream_t stream,
-                              bool bf16x3, long pixels_per_image, int n_crop, int k_crop, bool small_tiles = false) {
+                              bool bf16x3, long pixels_per_image, int n_crop, int k_crop, bool small_tiles = false,
+                              WgradDefer* defer = nullptr) {
     WgradParams wp{};
     wp.A = A; wp.B = B; wp.lda = lda; wp.ldb = ldb; wp.n_valid = n_valid; wp.k_valid = k_valid;
     if (pixels_per_image > 0) {       // channels-first images [B][C][P]
@@ -1444,14 +1476,23 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
     wp.batch = batch; wp.spi = (int)spi;
     wp.chunks_per_image = chunks_per_image;
     wp.chunks_per_split = (chunks_per_image + spi - 1) / spi;
+    const int splits = batch * (int)spi;
+    const unsigned blocks = img2w ? (unsigned)(8 * (((long)splits * tiles + 7) / 8)) : (unsigned)(8 * ((splits + 7) / 8) * tiles);
+    // scratch of this GEMM: [partial tiles][column-sum shares][vector shares].  Alone it owns `scratch` with the fixed
+    // offsets of wgrad_scratch_floats(); queued (gnr_wgrad.h) it takes what it needs from the caller's arena.
+    size_t part_floats = (size_t)WG_MAX_BLOCKS * WG_MAX_TILE;
+    if (defer) {
+        const size_t need = ((size_t)blocks * TN * TK + 63) & ~(size_t)63;
+        float* q = wgrad_defer_take(defer, need + 2 * (size_t)WG_MAX_BLOCKS * WG_RIDER_ROWS, stream);
+        if (q) { scratch = q; part_floats = need; }
+        else defer = nullptr;                 // an arena below one GEMM's need (callers size it with wgrad_scratch_floats(): never)
+    }
     wp.partial = scratch;
-    float* cs_part = scratch + (size_t)WG_MAX_BLOCKS * WG_MAX_TILE;
+    float* cs_part = scratch + part_floats;
     float* vec_part = cs_part + (size_t)WG_MAX_BLOCKS * WG_RIDER_ROWS;
     wp.colsum_part = cs_part;
     wp.vec = with_vec ? vec : nullptr;
     wp.vec_part = vec_part;
-    const int splits = batch * (int)spi;
-    const unsigned blocks = img2w ? (unsigned)(8 * (((long)splits * tiles + 7) / 8)) : (unsigned)(8 * ((splits + 7) / 8) * tiles);
     if (pipe_xk && bf16x3) {
         if (pipe_xk == 1) hipLaunchKernelGGL((wgrad3_tr_kernel<1, false>), dim3(blocks), dim3(512), 0, stream, wp);
         else if (wp.vec) hipLaunchKernelGGL((wgrad3_tr_kernel<3, true>), dim3(blocks), dim3(512), 0, stream, wp);
@@ -1493,36 +1534,37 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
     const long per_block = vec4 ? 256 : (total >= 16384 ? 64 : 16);   // elements per block, see reduce_dw / reduce_dw_vec4
     long rblocks = (total + per_block - 1) / per_block;
     if (rblocks < 8) rblocks = 8;                               // the rider sums below run grid-stride too
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rblocks), dim3(256), 0, stream, rp);
+    if (defer) wgrad_defer_push(defer, rp, (unsigned)rblocks);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rblocks), dim3(256), 0, stream, rp);
 }
 
 void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, int batch,
                   long chunks_per_image, float* dW, int ldw, int col_off, int enc_map, float* colsum_out,
                   int colsum_ld, const float* vec, float* vec_out, float* scratch, hipStream_t stream, bool bf16x3,
-                  int n_crop = -1, int k_crop = -1, bool small_tiles = false) {
+                  int n_crop = -1, int k_crop = -1, bool small_tiles = false, WgradDefer* defer = nullptr) {
     launch_wgrad_impl(A, lda, n_valid, B, ldb, k_valid, batch, chunks_per_image, dW, ldw, col_off, enc_map, colsum_out,
                       colsum_ld, vec, vec_out, scratch, stream, bf16x3, 0, n_crop < 0 ? n_valid : n_crop,
-                      k_crop < 0 ? k_valid : k_crop, small_tiles);
+                      k_crop < 0 ? k_valid : k_crop, small_tiles, defer);
 }
 
 // dW[n_valid x k_valid] = sum over images and pixels of A[b][n][p] * B[b][k][p] for channels-first fp32 images
 // ([B][lda][P] and [B][ldb][P], P % 32 == 0); colsum_out[b * colsum_ld + n] = sum_p A[b][n][p], or with colsum_ld == 0
 // colsum_out[n] = the sum over the images too.  Exact fp32 MFMA.
 bool launch_wgrad16_img(const float* A, int M, const float* B, int K, int batch, long P, float* dW, int ldw, float* bias_out,
-                        float* scratch, size_t scratch_floats, hipStream_t st);
+                        float* scratch, size_t scratch_floats, hipStream_t st, WgradDefer* defer);
 
 void launch_wgrad_img(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, int batch,
                       long pixels_per_image, float* dW, int ldw, float* colsum_out, int colsum_ld, float* scratch,
-                      hipStream_t stream) {
+                      hipStream_t stream, WgradDefer* defer) {
     // round 4: the wide products (both sides >= 100 channels) go to the register-fed kernel with 16-granular tiles
     // (gnr_wgrad16.hip); the narrow high-resolution ones stay with the LDS-staged kernels below
 #ifndef GNR_WG_NO16
     if (lda == n_valid && ldb == k_valid && (colsum_ld == 0 || !colsum_out) &&
-        launch_wgrad16_img(A, n_valid, B, k_valid, batch, pixels_per_image, dW, ldw, colsum_out, scratch, wgrad_scratch_floats(), stream))
+        launch_wgrad16_img(A, n_valid, B, k_valid, batch, pixels_per_image, dW, ldw, colsum_out, scratch, wgrad_scratch_floats(), stream, defer))
         return;
 #endif
     launch_wgrad_impl(A, lda, n_valid, B, ldb, k_valid, batch, pixels_per_image / CHUNK, dW, ldw, 0, 0, colsum_out,
-                      colsum_ld, nullptr, nullptr, scratch, stream, false, pixels_per_image, n_valid, k_valid);
+                      colsum_ld, nullptr, nullptr, scratch, stream, false, pixels_per_image, n_valid, k_valid, false, defer);
 }
 
 // per-image sum of a per-sample vector: out[b] = sum_{s in image b} v[s]   (density bias gradient)

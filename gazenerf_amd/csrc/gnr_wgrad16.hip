@@ -23,6 +23,7 @@
 #include <cstdint>
 
 #include "gnr_device.h"
+#include "gnr_wgrad.h"
 
 namespace gnr {
 
@@ -127,39 +128,16 @@ __global__ __launch_bounds__(64 * W16_WPB, W16_OCC) void wgrad16_kernel(const Wg
             for (int nt = 0; nt < NT; ++nt) dst[(long)(16 * mt + e) * k_pad + 16 * nt] = acc[mt][nt][e];
 }
 
-struct Wgrad16ReduceParams {
-    const float* partial; int splits; long n_pad, k_pad;
-    int M, K; float* dW; int ldw; float* bias;
-};
 
 // dW[n][k] = sum_s partial[s][n][k] (s ascending: fixed order), bias[n] = the last padded column.  One thread per output, k fastest.
-__global__ __launch_bounds__(256) void wgrad16_reduce_kernel(const Wgrad16ReduceParams rp) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const int kw = rp.K + (rp.bias ? 1 : 0);
-    if (idx >= (long)rp.M * kw) return;
-    const int n = (int)(idx / kw), k = (int)(idx - (long)n * kw);
-    const float* p = rp.partial + (long)n * rp.k_pad + (k < rp.K ? k : rp.k_pad - 1);
-    const long ss = rp.n_pad * rp.k_pad;
-    float acc = 0.0f;
-    int s = 0;
-    for (; s + 8 <= rp.splits; s += 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = p[(long)(s + u) * ss];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc += v[u];
-    }
-    for (; s < rp.splits; ++s) acc += p[(long)s * ss];
-    if (k < rp.K) rp.dW[(long)n * rp.ldw + k] = acc;
-    else rp.bias[n] = acc;
-}
+__global__ __launch_bounds__(256) void wgrad16_reduce_kernel(const Wgrad16ReduceParams rp) { wgrad16_reduce_body(rp, blockIdx.x); }
 
 }  // namespace
 
 // Returns false when the product is left to launch_wgrad_img's other kernels (narrow or HBM-bound shapes, odd pixel counts,
 // not enough scratch).  bias_out: [M] summed over the images, or NULL.
 bool launch_wgrad16_img(const float* A, int M, const float* B, int K, int batch, long P, float* dW, int ldw, float* bias_out,
-                        float* scratch, size_t scratch_floats, hipStream_t st) {
+                        float* scratch, size_t scratch_floats, hipStream_t st, WgradDefer* defer) {
     // Only where the 192 x 192 tiles of the LDS-staged kernel are badly filled: measured per 7 images (us, this kernel / the
     // old path) 516 x 258: 272 / 366, 258 x 129: 90 / 128, 129 x 258: 86 / 129, 516 x 258 at 64 x 64: 79 / 101 -- but
     // 1032 x 516 (fill 0.80): 288 / 273-285, and the tile-friendly, HBM-bound 256 x 128 at 256 x 256 (128 x 128 tiles): 315 / 256.
@@ -183,10 +161,15 @@ bool launch_wgrad16_img(const float* A, int M, const float* B, int K, int batch,
     long spi = 1024 * W16_OCC / (tiles * batch);
     if (spi < 1) spi = 1;
     if (spi > kb_img / 4) spi = kb_img / 4 > 0 ? kb_img / 4 : 1;                 // >= 128 pixels per split
+    if (defer && defer->arena_floats < scratch_floats) scratch_floats = defer->arena_floats;      // queued reduction (gnr_wgrad.h): partials from the caller's arena
     while (spi > 1 && (size_t)(batch * spi * area) > scratch_floats) --spi;
     if ((size_t)(batch * spi * area) > scratch_floats) return false;
     wp.kbs = (int)((kb_img + spi - 1) / spi);
     wp.spi = (int)((kb_img + wp.kbs - 1) / wp.kbs);
+    if (defer) {
+        scratch = wgrad_defer_take(defer, (size_t)batch * wp.spi * area, st);
+        if (!scratch) return false;
+    }
     wp.partial = scratch;
     const long witems = (long)batch * wp.spi * tiles, wg_items = (witems + W16_WPB - 1) / W16_WPB;
     const unsigned blocks = (unsigned)(8 * ((wg_items + 7) / 8));
@@ -196,7 +179,8 @@ bool launch_wgrad16_img(const float* A, int M, const float* B, int K, int batch,
     rp.partial = scratch; rp.splits = batch * wp.spi; rp.n_pad = (long)wp.mg * 16 * MT; rp.k_pad = (long)wp.kg * 16 * NT;
     rp.M = M; rp.K = K; rp.dW = dW; rp.ldw = ldw; rp.bias = bias_out;
     const long total = (long)M * kw;
-    hipLaunchKernelGGL(wgrad16_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, rp);
+    if (defer) wgrad_defer_push16(defer, rp, (unsigned)((total + 255) / 256));
+    else hipLaunchKernelGGL(wgrad16_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, rp);
     return true;
 }
 
