@@ -1485,7 +1485,10 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
         const size_t need = ((size_t)blocks * TN * TK + 63) & ~(size_t)63;
         float* q = wgrad_defer_take(defer, need + 2 * (size_t)WG_MAX_BLOCKS * WG_RIDER_ROWS, stream);
         if (q) { scratch = q; part_floats = need; }
-        else defer = nullptr;                 // an arena below one GEMM's need (callers size it with wgrad_scratch_floats(): never)
+        else {                                // an arena below one GEMM's need (callers size it with wgrad_arena_floats(): never) --
+            wgrad_defer_flush(defer, stream); // run what is queued, then this GEMM owns `scratch` like a launch of its own
+            defer = nullptr;
+        }
     }
     wp.partial = scratch;
     float* cs_part = scratch + part_floats;
