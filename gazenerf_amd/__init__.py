@@ -10,12 +10,14 @@ Public surface:
                                                            reference network: hot path -> merge -> upsampler x4)
     losses                                                 image losses + per-sample fitting step (SURVEY 8(f) N4,
                                                            the terms without a pretrained network)
+    gan                                                    PatchGAN discriminator, its loss / generator term / update step
+                                                           (the GAN terms need no pretrained network)
     data                                                   dataset-row contract, collate, prepare_batch: the reference's
                                                            sample -> op-input step
     synth                                                  synthetic input recipe
     build.build()                                          compile libgnr.so for gfx950
 """
-from . import data, losses, synth  # noqa: F401
+from . import data, gan, losses, synth  # noqa: F401
 from .render import PackedWeightCache, importance_resample, render_two_stream, render_two_stream_tiled, sample_zvals  # noqa: F401
 from .merge import merge_featmaps  # noqa: F401
 from .upsample import NeuralRendererAMD, neural_render  # noqa: F401

@@ -2,8 +2,9 @@
 (the parts that need no pretrained network).
 
 Restated from losses/gazenerf_loss.py:294-470 (``calc_data_loss`` / ``calc_total_loss`` with
-``use_vgg_loss=False, use_angular_loss=False, use_patch_gan_loss=False``: the perceptual, gaze-angular and
-GAN terms need VGG / gaze-estimator weights that are not available offline) and trainer/base.py:92-124,
+``use_vgg_loss=False, use_angular_loss=False``: the perceptual and gaze-angular terms need VGG / gaze-estimator
+weights that are not available offline; the PatchGAN term needs none -- ``gazenerf_amd.gan`` -- and is added when a
+discriminator is passed) and trainer/base.py:92-124,
 trainer/gazenerf_trainer.py:338-405 (``eulurangle2Rmat``, ``build_code_and_cam``).  Plain PyTorch on the GPU:
 these are a few reductions over [B,3,512,512] images, not a hot path.  Masked means are computed as
 sum(mask * err) / count instead of boolean indexing (same value up to summation order, no host sync).
@@ -39,8 +40,9 @@ def _masked_mean(err, mask_c1):
 
 
 def data_losses(pred: Dict[str, torch.Tensor], gt_rgb, masks, bg_value: float = 1.0, use_l1: bool = False,
-                epoch: int = 0):
-    """gazenerf_loss.py:294-358 without the VGG / angular / GAN terms."""
+                epoch: int = 0, discriminator=None, batch_num: int = 0):
+    """gazenerf_loss.py:294-403 without the VGG / angular terms; with ``discriminator`` (a ``gan.PatchGAN`` whose
+    parameters the caller has frozen, as the trainer does) the generator's PatchGAN term of :396-401."""
     pen = (lambda d: d.abs()) if use_l1 else (lambda d: d * d)
     res = {
         "bg_loss": torch.mean((pred["bg_img"] - bg_value) ** 2),
@@ -50,16 +52,19 @@ def data_losses(pred: Dict[str, torch.Tensor], gt_rgb, masks, bg_value: float = 
     }
     if epoch > -1:
         res["head_loss"] = _masked_mean(pen(pred["merge_img"] - gt_rgb), masks["head"])
+    if discriminator is not None:
+        from .gan import generator_term
+        res["gen_patch_gan_loss"] = generator_term(discriminator, pred["merge_img"], epoch, batch_num)
     return res
 
 
 def total_loss(pred, gt_rgb, face_mask, full_eye_mask, left_eye_mask, right_eye_mask, opt_codes,
                delta_cam: Optional[Dict[str, torch.Tensor]] = None, bg_value: float = 1.0, use_l1: bool = False,
-               epoch: int = 0):
+               epoch: int = 0, discriminator=None, batch_num: int = 0):
     """gazenerf_loss.py:405-470: data terms + 0.001 |delta cam|^2 + code regularisers (0.001 iden, 1.0 expr,
     0.001 appea, 0.01 bg).  ``pred`` is the network's ``coarse_dict``."""
     masks = region_masks(face_mask, full_eye_mask, left_eye_mask, right_eye_mask)
-    loss = data_losses(pred, gt_rgb, masks, bg_value, use_l1, epoch)
+    loss = data_losses(pred, gt_rgb, masks, bg_value, use_l1, epoch, discriminator, batch_num)
     total = sum(loss.values())
     if delta_cam is not None:
         loss["delta_eular"] = torch.mean(delta_cam["delta_eulur"] ** 2)
@@ -110,12 +115,21 @@ class Fitter:
         return shape_code, appea_code, base["gaze"], R, T, opt_codes, delta
 
     def step(self, rows: slice, xy, base, gt_rgb, face_mask, full_eye_mask, left_eye_mask, right_eye_mask,
-             t_rand=None, epoch: int = 0):
+             t_rand=None, epoch: int = 0, gan=None, batch_num: int = 0):
+        """``gan``: a ``gazenerf_amd.gan.DiscriminatorStep`` (``use_patch_gan_loss``): the discriminator is updated on
+        (ground truth, detached prediction) first, then frozen while the generator term joins the total loss
+        (gazenerf_trainer.py:487-528)."""
         shape_code, appea_code, gaze, R, T, opt_codes, delta = self.build_code_and_cam(rows, base)
         pred = self.net("train", xy, None, None, shape_code, appea_code, gaze, R, T, base["inv_inmat"], t_rand=t_rand)
+        extra = {}
+        if gan is not None:
+            extra = gan.step(gt_rgb, face_mask, pred["coarse_dict"]["merge_img"])
         losses = total_loss(pred["coarse_dict"], gt_rgb, face_mask, full_eye_mask, left_eye_mask, right_eye_mask,
-                            opt_codes, delta, epoch=epoch)
+                            opt_codes, delta, epoch=epoch, discriminator=gan.discriminator if gan is not None else None,
+                            batch_num=batch_num)
         self.optimizer.zero_grad()
         losses["total_loss"].backward()
         self.optimizer.step()
-        return {k: float(v.detach()) for k, v in losses.items()}
+        out = {k: float(v.detach()) for k, v in losses.items()}
+        out.update({k: float(v) for k, v in extra.items()})
+        return out

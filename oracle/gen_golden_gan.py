@@ -1,0 +1,124 @@
+"""ORACLE tooling -- test infrastructure, NOT product code.
+
+Fixture for the PatchGAN terms of SURVEY.md 8(f) N4: the reference's own ``PatchGAN`` (models/discriminator.py:4-43),
+``discriminator_loss`` / ``generator_loss`` (losses/gazenerf_loss.py:22-37) and the generator term inside
+``GazeNeRFLoss.calc_data_loss`` (:396-401, ``use_patch_gan_loss=True``) evaluated here on seeded inputs and hashed
+parameters (gazenerf_amd.gan.hash_patchgan_state: nothing but inputs and expected outputs is stored).  torchvision / cv2 /
+the gaze-estimator package are import-time dependencies of gazenerf_loss.py only; they are replaced by empty modules, and
+``transforms.Resize`` by the identity -- the fixture images ARE 224 x 224, so the (unpinned) resize is the identity on both
+sides.  Writes tests/golden/g13_patchgan.npz.
+
+    python oracle/gen_golden_gan.py
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("GNR_REFERENCE", "/root/reference")
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+
+def main():
+    sys.dont_write_bytecode = True
+    for name in ("cv2", "torchvision", "gaze_estimation", "gaze_estimation.xgaze_baseline_vgg", "wandb", "imageio",
+                 "skimage", "skimage.metrics", "piq", "kornia", "kornia.filters", "h5py", "lpips", "face_recognition"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    tv = sys.modules["torchvision"]
+    tr = types.ModuleType("torchvision.transforms")
+    ident = lambda *a, **k: (lambda x: x)
+    tr.Compose, tr.ToPILImage, tr.ToTensor, tr.Normalize, tr.Resize = (lambda fs: (lambda x: x)), ident, ident, ident, ident
+    tv.transforms = tr
+    sys.modules["torchvision.transforms"] = tr
+    sys.modules["gaze_estimation.xgaze_baseline_vgg"].gaze_network = object
+    sys.path.insert(0, REF)
+    os.chdir(REF)
+    from losses.gazenerf_loss import GazeNeRFLoss, discriminator_loss, generator_loss
+    from models.discriminator import PatchGAN as RefPatchGAN
+
+    from gazenerf_amd import gan as G
+    from gazenerf_amd import losses as L
+
+    torch.set_num_threads(1)                     # one summation order for the convolutions on every host
+    NDF, B, S = 8, 2, 224
+    state = G.hash_patchgan_state(seed=3, ndf=NDF)
+    ref = RefPatchGAN(input_nc=3, ndf=NDF)
+    assert list(ref.state_dict().keys()) == list(state.keys())          # the state-dict surface is the reference's
+    ref.load_state_dict(state, strict=True)
+    ours = G.PatchGAN(input_nc=3, ndf=NDF)
+    ours.load_state_dict(ref.state_dict(), strict=True)
+    ref.train(); ours.train()
+
+    case = G.synth_gan_case(seed=21, batch=B, side=S)       # hashed inputs: the fixture stores expected outputs only
+    real_img = case["real_img"]
+    fake_img = case["fake_img"].clone().requires_grad_(True)
+    arrays = {}
+
+    # discriminator side: logits, loss, parameter gradients, BatchNorm running statistics after the two forwards
+    real, fake = ref(real_img), ref(fake_img.detach())
+    dl = discriminator_loss(real=real, fake=fake, device="cpu")
+    gl = generator_loss(fake=fake, device="cpu")
+    dl.backward()
+    o_real, o_fake = ours(real_img), ours(fake_img.detach())
+    odl = G.discriminator_loss(o_real, o_fake)
+    odl.backward()
+    for name, a, b in (("real", real, o_real), ("fake", fake, o_fake)):
+        e = float((a - b).detach().abs().max())
+        print("  logits %-5s %s max-abs diff %.2e" % (name, tuple(a.shape), e))
+        assert e <= 1e-6
+    assert abs(float(dl) - float(odl)) <= 1e-7 and abs(float(gl) - float(G.generator_loss(o_fake))) <= 1e-7
+    arrays.update(logits_real=real.detach(), logits_fake=fake.detach(), disc_loss=np.float64(float(dl)), gen_loss=np.float64(float(gl)))
+    for (k, q), (_, qo) in zip(ref.named_parameters(), ours.named_parameters()):
+        e = float((q.grad - qo.grad).norm() / q.grad.norm())
+        assert e <= 1e-6, k
+        if k in ("conv1.weight", "conv1.bias", "norm2.weight", "norm3.bias", "conv5.weight", "conv5.bias"):
+            arrays["dgrad_" + k] = q.grad.clone()
+    arrays["norm1_running_mean"] = ref.norm1.running_mean.clone()
+    arrays["norm3_running_var"] = ref.norm3.running_var.clone()
+    print("  disc_loss %.8f gen_loss %.8f" % (float(dl), float(gl)))
+
+    # generator side: the reference's calc_total_loss with use_patch_gan_loss=True (discriminator frozen, as in the trainer)
+    for q in ref.parameters():
+        q.requires_grad = False
+    for q in ours.parameters():
+        q.requires_grad = False
+    pred = {k: case[k] for k in ("merge_img_face", "merge_img_eyes", "bg_img")}
+    pred["merge_img"] = fake_img
+    gt, face, leye, reye, full_eye = (case[k] for k in ("gt", "face", "leye", "reye", "full_eye"))
+    codes = {"bg": None, "iden": case["code_iden"], "expr": case["code_expr"], "appea": case["code_appea"]}
+    loss = GazeNeRFLoss(eye_loss_importance=1.0, vgg_importance=1.0, use_vgg_loss=False, use_l1_loss=False,
+                        use_patch_gan_loss=True, device="cpu")
+    loss.device = "cpu"            # the reference sets self.device only beside its VGG loss (gazenerf_loss.py:229-231); the GAN term reads it
+    for tag, (epoch, batch_num) in {"ramp": (0, 5000), "full": (1, 10)}.items():
+        fake_img.grad = None
+        rl = loss.calc_total_loss(delta_cam_info=None, opt_code_dict=codes, pred_dict={"coarse_dict": pred}, gt_rgb=gt,
+                                  face_mask_tensor=face, full_eye_mask_tensor=full_eye, left_eye_mask_tensor=leye,
+                                  right_eye_mask_tensor=reye, cam_ind=None, ldms=None, epoch=epoch, batch_num=batch_num,
+                                  discriminator=ref)
+        rl["total_loss"].backward()
+        gref = fake_img.grad.clone()
+        fake_img.grad = None
+        ol = L.total_loss(pred, gt, face, full_eye, leye, reye, codes, None, epoch=epoch, discriminator=ours, batch_num=batch_num)
+        ol["total_loss"].backward()
+        for k in ("gen_patch_gan_loss", "total_loss"):
+            print("  %s %-20s ref %.8f ours %.8f" % (tag, k, float(rl[k]), float(ol[k])))
+            assert abs(float(rl[k]) - float(ol[k])) <= 1e-6 * max(1.0, abs(float(rl[k]))), k
+            arrays["%s_%s" % (tag, k)] = np.float64(float(rl[k]))
+        e = float((gref - fake_img.grad).norm() / gref.norm())
+        print("  %s d total / d merge_img rel-L2 diff %.2e" % (tag, e))
+        assert e <= 1e-6
+        arrays["%s_grad_merge_img" % tag] = gref[:, :, ::8, ::8].clone()      # strided subset: 28 x 28 per plane
+        arrays["%s_epoch_batch" % tag] = np.array([epoch, batch_num])
+    np.savez_compressed(os.path.join(GOLD, "g13_patchgan.npz"), **{k: (v.detach().numpy() if torch.is_tensor(v) else v) for k, v in arrays.items()})
+    print("  wrote tests/golden/g13_patchgan.npz (%.0f KB)" % (os.path.getsize(os.path.join(GOLD, "g13_patchgan.npz")) / 1024))
+
+
+if __name__ == "__main__":
+    main()

@@ -141,6 +141,37 @@ def test_hip_vs_oracle_live(feat_nc, side, img, min_feat, batch):
         assert _rel_l2(dp[k].cpu(), pg[k].grad) <= 1e-3, k
 
 
+@pytest.mark.gpu
+def test_stacked_training_batch_equals_the_per_image_runs():
+    """The 7 stacked maps of a B = 2 training step (3B + 1) at full size against seven single-image calls: same images and
+    input gradients, weight gradients = the sum over the images.  At this size the nine split-K reductions of the backward
+    (gnr_wgrad.h) do not fit the scratch at once -- the queue is flushed early and the scratch reused -- while a single image
+    goes through in one batch: both orders of the queue are checked against each other."""
+    dev = _dev()
+    from gazenerf_amd import neural_render
+    B, nb, mf = 7, 3, 32
+    params = synth.hash_renderer_params(seed=11, feat_nc=258, n_blocks=nb, min_feat=mf, weight_scale=2.0)
+    x = synth.synth_featmap(B, 258, 64, seed=4)
+
+    def run(xs):
+        xg = xs.to(dev).clone().requires_grad_(True)
+        pg = {k: v.to(dev).clone().requires_grad_(True) for k, v in params.items()}
+        img = neural_render(xg, pg, n_blocks=nb, min_feat=mf)
+        w = torch.linspace(0.5, 1.5, img[0].numel(), device=dev).reshape(img[0].shape)
+        (img * w).sum().backward()
+        return img.detach(), xg.grad, {k: v.grad.double() for k, v in pg.items()}
+
+    img, dx, dp = run(x)
+    acc = None
+    for b in range(B):
+        i1, d1, p1 = run(x[b:b + 1])
+        assert float((i1[0] - img[b]).abs().max()) <= 1e-6
+        assert _rel_l2(d1[0].cpu(), dx[b].cpu()) <= 1e-6
+        acc = p1 if acc is None else {k: acc[k] + p1[k] for k in acc}
+    for k in dp:
+        assert _rel_l2(dp[k].cpu().float(), acc[k].cpu().float()) <= 2e-5, k
+
+
 def _variant_run(dev):
     out = {}
     for tag, (feat_nc, side, nb, mf, batch) in {"a": (258, 64, 1, 32, 1), "b": (64, 32, 2, 16, 2)}.items():
