@@ -27,7 +27,13 @@ import torch.nn.functional as F
 
 class PatchGAN(nn.Module):
     """models/discriminator.py:4-43.  kernel 6, padding 1; strides 2, 2, 2, 1, 1; BatchNorm after conv2-4 (those
-    convolutions carry no bias); LeakyReLU(0.2); one-channel logit map ([B,1,20,20] for a 224x224 input)."""
+    convolutions carry no bias); LeakyReLU(0.2); one-channel logit map ([B,1,20,20] for a 224x224 input).
+
+    Gradients through four LeakyReLUs are only piecewise smooth: a pre-activation within rounding distance of zero takes the
+    other slope under a different summation order, and ONE such element moves the upstream weight gradients by ~0.7 % (rel-L2)
+    -- MIOpen's Winograd backward on the MI355X against oneDNN on the CPU, but equally an im2col + GEMM restatement on the CPU
+    against oneDNN (tools/gan_diag.py, profiles/r4_patchgan_gradient_flip.txt).  Not an accuracy defect of either; the fixture
+    inputs are chosen with a margin around zero and the GPU test allows for a flip."""
 
     def __init__(self, input_nc: int = 3, ndf: int = 64):
         super().__init__()
@@ -154,3 +160,19 @@ def synth_gan_case(seed: int = 0, batch: int = 2, side: int = 224) -> Dict[str, 
     for name, n in (("iden", 100), ("expr", 79), ("appea", 127)):
         out["code_" + name] = torch.from_numpy((0.2 * (hash_uniform(batch * n, _key("gan.code." + name, seed)) - 0.5)).astype(np.float32).reshape(batch, n))
     return out
+
+
+def min_abs_preactivation(d: PatchGAN, state, case) -> float:
+    """Smallest |input| of the discriminator's four LeakyReLUs over the real and the generated batch, in fp64: the margin
+    the fixture generator requires (a value within fp32 rounding of zero makes every gradient upstream of it depend on the
+    summation order)."""
+    d = PatchGAN(d.conv1.in_channels, d.conv1.out_channels)
+    d.load_state_dict(state)
+    d = d.double().train()
+    lo = [float("inf")]
+    hook = lambda m, inp: lo.__setitem__(0, min(lo[0], float(inp[0].detach().abs().min())))
+    h = d.act.register_forward_pre_hook(hook)
+    with torch.no_grad():
+        d(case["real_img"].double()); d(case["fake_img"].double())
+    h.remove()
+    return lo[0]

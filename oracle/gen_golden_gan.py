@@ -56,7 +56,13 @@ def main():
     ours.load_state_dict(ref.state_dict(), strict=True)
     ref.train(); ours.train()
 
-    case = G.synth_gan_case(seed=21, batch=B, side=S)       # hashed inputs: the fixture stores expected outputs only
+    # hashed inputs: the fixture stores expected outputs only.  Input seed 53 = the one of 21..60 whose smallest |LeakyReLU input|
+    # (fp64) is widest, 6.9e-6: gradients through a LeakyReLU input within fp32 rounding of zero depend on the summation order
+    # (seed 21 has one at 2.3e-8 -- its upstream gradients differ by 0.7 % between two exact fp32 implementations)
+    case = G.synth_gan_case(seed=53, batch=B, side=S)
+    margin = G.min_abs_preactivation(G.PatchGAN(3, NDF), state, case)
+    print("  smallest |LeakyReLU input| %.2e" % margin)
+    assert margin >= 5e-6
     real_img = case["real_img"]
     fake_img = case["fake_img"].clone().requires_grad_(True)
     arrays = {}
