@@ -2,10 +2,10 @@
 (the parts that need no pretrained network).
 
 Restated from losses/gazenerf_loss.py:294-470 (``calc_data_loss`` / ``calc_total_loss`` with
-``use_angular_loss=False``: the gaze-angular term needs the gaze estimator's weights and cv2's face normalisation, neither
-available offline; the PatchGAN term needs no pretrained network -- ``gazenerf_amd.gan`` -- and is added when a
+every switch of the reference: the PatchGAN term needs no pretrained network -- ``gazenerf_amd.gan`` -- and is added when a
 discriminator is passed; the VGG-perceptual terms are added when a ``gazenerf_amd.perceptual.VGGPerceptualLoss`` is passed
--- its ImageNet weights are the caller's to supply) and trainer/base.py:92-124,
+-- its ImageNet weights are the caller's to supply; the gaze-angular term when a ``perceptual.GazeAngularLoss`` is passed --
+the gaze estimator's trained weights are the caller's too) and trainer/base.py:92-124,
 trainer/gazenerf_trainer.py:338-405 (``eulurangle2Rmat``, ``build_code_and_cam``).  Plain PyTorch on the GPU:
 these are a few reductions over [B,3,512,512] images, not a hot path.  Masked means are computed as
 sum(mask * err) / count instead of boolean indexing (same value up to summation order, no host sync).
@@ -41,8 +41,9 @@ def _masked_mean(err, mask_c1):
 
 
 def data_losses(pred: Dict[str, torch.Tensor], gt_rgb, masks, bg_value: float = 1.0, use_l1: bool = False,
-                epoch: int = 0, discriminator=None, batch_num: int = 0, vgg=None, vgg_importance: float = 1.0):
-    """gazenerf_loss.py:294-403 without the angular term; with ``vgg`` (a ``perceptual.VGGPerceptualLoss``) the three
+                epoch: int = 0, discriminator=None, batch_num: int = 0, vgg=None, vgg_importance: float = 1.0,
+                gaze=None, eye_loss_importance: float = 1.0):
+    """gazenerf_loss.py:294-403; with ``gaze`` (a ``perceptual.GazeAngularLoss``) the angular term of :383-391; with ``vgg`` (a ``perceptual.VGGPerceptualLoss``) the three
     perceptual terms of :360-381; with ``discriminator`` (a ``gan.PatchGAN`` whose parameters the caller has frozen, as the
     trainer does) the generator's PatchGAN term of :396-401.  The entries are in the reference's order (their sum is)."""
     pen = (lambda d: d.abs()) if use_l1 else (lambda d: d * d)
@@ -57,6 +58,9 @@ def data_losses(pred: Dict[str, torch.Tensor], gt_rgb, masks, bg_value: float = 
     if vgg is not None:
         from .perceptual import vgg_terms
         res.update(vgg_terms(vgg, pred, gt_rgb, masks, bg_value, vgg_importance))
+    if gaze is not None and epoch > -1:
+        from .perceptual import angular_term
+        res["angular"] = angular_term(gaze, pred, gt_rgb, masks, bg_value, eye_loss_importance)
     if discriminator is not None:
         from .gan import generator_term
         res["gen_patch_gan_loss"] = generator_term(discriminator, pred["merge_img"], epoch, batch_num)
@@ -65,11 +69,13 @@ def data_losses(pred: Dict[str, torch.Tensor], gt_rgb, masks, bg_value: float = 
 
 def total_loss(pred, gt_rgb, face_mask, full_eye_mask, left_eye_mask, right_eye_mask, opt_codes,
                delta_cam: Optional[Dict[str, torch.Tensor]] = None, bg_value: float = 1.0, use_l1: bool = False,
-               epoch: int = 0, discriminator=None, batch_num: int = 0, vgg=None, vgg_importance: float = 1.0):
+               epoch: int = 0, discriminator=None, batch_num: int = 0, vgg=None, vgg_importance: float = 1.0,
+               gaze=None, eye_loss_importance: float = 1.0):
     """gazenerf_loss.py:405-470: data terms + 0.001 |delta cam|^2 + code regularisers (0.001 iden, 1.0 expr,
     0.001 appea, 0.01 bg).  ``pred`` is the network's ``coarse_dict``."""
     masks = region_masks(face_mask, full_eye_mask, left_eye_mask, right_eye_mask)
-    loss = data_losses(pred, gt_rgb, masks, bg_value, use_l1, epoch, discriminator, batch_num, vgg, vgg_importance)
+    loss = data_losses(pred, gt_rgb, masks, bg_value, use_l1, epoch, discriminator, batch_num, vgg, vgg_importance, gaze,
+                       eye_loss_importance)
     total = sum(loss.values())
     if delta_cam is not None:
         loss["delta_eular"] = torch.mean(delta_cam["delta_eulur"] ** 2)
@@ -120,7 +126,8 @@ class Fitter:
         return shape_code, appea_code, base["gaze"], R, T, opt_codes, delta
 
     def step(self, rows: slice, xy, base, gt_rgb, face_mask, full_eye_mask, left_eye_mask, right_eye_mask,
-             t_rand=None, epoch: int = 0, gan=None, batch_num: int = 0):
+             t_rand=None, epoch: int = 0, gan=None, batch_num: int = 0, vgg=None, vgg_importance: float = 1.0,
+             gaze=None, eye_loss_importance: float = 1.0):
         """``gan``: a ``gazenerf_amd.gan.DiscriminatorStep`` (``use_patch_gan_loss``): the discriminator is updated on
         (ground truth, detached prediction) first, then frozen while the generator term joins the total loss
         (gazenerf_trainer.py:487-528)."""
@@ -131,7 +138,8 @@ class Fitter:
             extra = gan.step(gt_rgb, face_mask, pred["coarse_dict"]["merge_img"])
         losses = total_loss(pred["coarse_dict"], gt_rgb, face_mask, full_eye_mask, left_eye_mask, right_eye_mask,
                             opt_codes, delta, epoch=epoch, discriminator=gan.discriminator if gan is not None else None,
-                            batch_num=batch_num)
+                            batch_num=batch_num, vgg=vgg, vgg_importance=vgg_importance, gaze=gaze,
+                            eye_loss_importance=eye_loss_importance)
         self.optimizer.zero_grad()
         losses["total_loss"].backward()
         self.optimizer.step()

@@ -1,6 +1,7 @@
-"""SURVEY.md 8(f) N4, the VGG-perceptual terms: gazenerf_amd.perceptual against values captured from the reference's own
-``VGGPerceptualLoss`` / ``GazeNeRFLoss(use_vgg_loss=True, use_patch_gan_loss=True)`` run on this repository's restatement of
-torchvision's ``vgg16().features`` layout with hashed weights (oracle/gen_golden_vgg.py).  The loss arithmetic is pinned, the
+"""SURVEY.md 8(f) N4, the VGG-perceptual and gaze-angular terms: gazenerf_amd.perceptual against values captured from the
+reference's own ``VGGPerceptualLoss``, ``GazePerceptualLoss.forward`` + ``gaze_network`` and ``GazeNeRFLoss.calc_total_loss`` with
+every term switched on, run on this repository's restatement of torchvision's ``vgg16().features`` layout with hashed weights
+(oracle/gen_golden_vgg.py).  The loss arithmetic is pinned, the
 architecture is restated from torchvision's published configuration (not importable offline), the ImageNet weights are the
 caller's to supply."""
 import pytest
@@ -18,6 +19,16 @@ def _vgg(dev="cpu"):
     f = P.vgg16_features()
     f.load_state_dict(P.hash_vgg16_state(VGG_SEED))
     return P.VGGPerceptualLoss(resize=True, features=f).to(dev)
+
+
+def _gaze(dev="cpu"):
+    f = P.vgg16_features_full()
+    f.load_state_dict(P.hash_vgg16_state(VGG_SEED, full=True))
+    net = P.GazeNetwork(f)
+    head = P.hash_gaze_head_state(seed=2)
+    head["FC3.weight"] = head["FC3.weight"] * 0.5            # as the generator: estimates a few degrees apart, tanh unsaturated
+    net.load_state_dict(head, strict=False)
+    return P.GazeAngularLoss(model=net).to(dev)
 
 
 def _rel(a, b):
@@ -69,10 +80,26 @@ def _check_module(dev, tol, tol_grad):
     assert abs(float(v(x0[:, :1], y[:, :1])) - g["module_gray"]) <= tol * abs(g["module_gray"])
 
 
+def _check_gaze(dev, tol, tol_grad):
+    g = load_golden("g14_vgg")
+    case = {k: t.to(dev) for k, t in G.synth_gan_case(seed=SEED_X).items()}
+    gz = _gaze(dev)
+    with torch.no_grad():
+        gaze, head = gz.model((case["real_img"] - gz.mean) / gz.std)
+    assert float((gaze.cpu() - g["gaze_pitchyaw"]).abs().max()) <= tol and float((head.cpu() - g["head_pitchyaw"]).abs().max()) <= tol
+    x = case["fake_img"].clone().requires_grad_(True)
+    out = gz(x, case["real_img"])
+    assert abs(float(out) - g["angular_deg"]) <= 50 * tol * g["angular_deg"]      # degrees: acos amplifies the estimates' rounding
+    out.backward()
+    e = _rel(x.grad[:, :, ::8, ::8], g["angular_grad"])
+    assert e <= tol_grad, e
+
+
 def _check_total(dev, tol, tol_grad):
     g = load_golden("g14_vgg")
     case = {k: t.to(dev) for k, t in G.synth_gan_case(seed=SEED_X).items()}
     v = _vgg(dev)
+    gz = _gaze(dev)
     d = G.PatchGAN(3, 8)
     d.load_state_dict(G.hash_patchgan_state(seed=3, ndf=8))
     d = d.to(dev).train()
@@ -82,11 +109,11 @@ def _check_total(dev, tol, tol_grad):
     pred["merge_img"] = case["fake_img"].clone().requires_grad_(True)
     codes = {"bg": None, "iden": case["code_iden"], "expr": case["code_expr"], "appea": case["code_appea"]}
     out = L.total_loss(pred, case["gt"], case["face"], case["full_eye"], case["leye"], case["reye"], codes, None, use_l1=True,
-                       epoch=1, discriminator=d, batch_num=3, vgg=v, vgg_importance=0.7)
+                       epoch=1, discriminator=d, batch_num=3, vgg=v, vgg_importance=0.7, gaze=gz, eye_loss_importance=31.0)
     want = [k[6:] for k in g if k.startswith("total_") and not k.startswith("total_grad_")]
     # the reference sums its dictionary in insertion order: the terms must come in ITS order
     assert [k for k in out if k in want] == ["bg_loss", "eyes_loss", "face_loss", "nonhead_loss", "head_loss", "vgg_face_loss",
-                                              "vgg_eyes_loss", "vgg", "gen_patch_gan_loss", "iden_code", "expr_code",
+                                              "vgg_eyes_loss", "vgg", "angular", "gen_patch_gan_loss", "iden_code", "expr_code",
                                               "appea_code", "bg_code", "total_loss"]
     for k in want:
         assert abs(float(out[k]) - g["total_" + k]) <= tol * max(1.0, abs(g["total_" + k])), k
@@ -101,9 +128,33 @@ def test_module_vs_reference_fixture():
     _check_module("cpu", 1e-5, 1e-4)
 
 
-def test_total_loss_with_perceptual_and_gan_terms_vs_reference_fixture():
+def test_gaze_network_and_angular_loss_vs_reference_fixture():
+    torch.set_num_threads(1)
+    _check_gaze("cpu", 1e-6, 1e-4)
+
+
+def test_gaze_network_has_the_reference_checkpoints_names():
+    keys = list(P.GazeNetwork().state_dict().keys())
+    assert keys[:2] == ["vgg16.0.weight", "vgg16.0.bias"] and keys[-6:] == ["FC1.weight", "FC1.bias", "FC2.weight", "FC2.bias", "FC3.weight", "FC3.bias"]
+    assert len(keys) == 26 + 6 and len(P.vgg16_features_full()) == 31
+    a = torch.tensor([[0.1, -0.2], [0.0, 0.0]])
+    v = P.pitchyaw_to_vector(a)
+    assert float((v.norm(dim=1) - 1).abs().max()) <= 1e-6 and torch.allclose(v[1], torch.tensor([0.0, 0.0, 1.0]))
+    assert float(P.angular_distance_deg(v, v).abs().max()) <= 0.1            # acos at 1: sqrt(eps)-sized, in degrees
+    assert abs(float(P.angular_distance_deg(v[:1], -v[:1])) - 180.0) <= 0.1
+
+
+def test_total_loss_with_every_term_vs_reference_fixture():
     torch.set_num_threads(1)
     _check_total("cpu", 1e-5, 1e-4)
+    # the angular term only exists from epoch 0 on (gazenerf_loss.py:383), like head_loss
+    case = G.synth_gan_case(seed=SEED_X, side=32)
+    pred = {k: case[k] for k in ("merge_img_face", "merge_img_eyes", "bg_img")}
+    pred["merge_img"] = case["fake_img"]
+    codes = {"bg": None, "iden": case["code_iden"], "expr": case["code_expr"], "appea": case["code_appea"]}
+    out = L.total_loss(pred, case["gt"], case["face"], case["full_eye"], case["leye"], case["reye"], codes, None, epoch=-1,
+                       gaze=P.GazeAngularLoss())
+    assert "angular" not in out and "head_loss" not in out
 
 
 @pytest.mark.gpu
@@ -111,4 +162,5 @@ def test_perceptual_terms_on_gpu_vs_reference_fixture():
     """Through MIOpen on the MI355X: loss values 1e-4 relative; the image gradients pass ten ReLUs and three max-pools whose
     kinks another summation order crosses here and there (millions of elements, each worth ~1e-3 of the norm at most): 2e-2."""
     _check_module(torch.device("cuda:0"), 1e-4, 2e-2)
+    _check_gaze(torch.device("cuda:0"), 1e-4, 5e-2)
     _check_total(torch.device("cuda:0"), 1e-4, 2e-2)
