@@ -127,8 +127,9 @@ class Fitter:
 
     def step(self, rows: slice, xy, base, gt_rgb, face_mask, full_eye_mask, left_eye_mask, right_eye_mask,
              t_rand=None, epoch: int = 0, gan=None, batch_num: int = 0, vgg=None, vgg_importance: float = 1.0,
-             gaze=None, eye_loss_importance: float = 1.0):
-        """``gan``: a ``gazenerf_amd.gan.DiscriminatorStep`` (``use_patch_gan_loss``): the discriminator is updated on
+             gaze_loss=None, eye_loss_importance: float = 1.0):
+        """``vgg`` / ``gaze_loss``: ``perceptual.VGGPerceptualLoss`` / ``perceptual.GazeAngularLoss`` modules (``use_vgg_loss`` /
+        ``use_angular_loss``).  ``gan``: a ``gazenerf_amd.gan.DiscriminatorStep`` (``use_patch_gan_loss``): the discriminator is updated on
         (ground truth, detached prediction) first, then frozen while the generator term joins the total loss
         (gazenerf_trainer.py:487-528)."""
         shape_code, appea_code, gaze, R, T, opt_codes, delta = self.build_code_and_cam(rows, base)
@@ -138,7 +139,7 @@ class Fitter:
             extra = gan.step(gt_rgb, face_mask, pred["coarse_dict"]["merge_img"])
         losses = total_loss(pred["coarse_dict"], gt_rgb, face_mask, full_eye_mask, left_eye_mask, right_eye_mask,
                             opt_codes, delta, epoch=epoch, discriminator=gan.discriminator if gan is not None else None,
-                            batch_num=batch_num, vgg=vgg, vgg_importance=vgg_importance, gaze=gaze,
+                            batch_num=batch_num, vgg=vgg, vgg_importance=vgg_importance, gaze=gaze_loss,
                             eye_loss_importance=eye_loss_importance)
         self.optimizer.zero_grad()
         losses["total_loss"].backward()

@@ -135,8 +135,8 @@ def test_patchgan_on_gpu_vs_reference_fixture():
 
 
 @pytest.mark.gpu
-def test_fitter_step_with_the_patchgan_terms():
-    """trainer/gazenerf_trainer.py:487-528 around the whole network: discriminator update on (ground truth, detached
+def test_fitter_step_with_every_loss_term():
+    """trainer/gazenerf_trainer.py:487-528 around the whole network with use_vgg_loss, use_angular_loss and use_patch_gan_loss: discriminator update on (ground truth, detached
     prediction), then the generator step with the PatchGAN term in its total loss; D stays frozen during the latter."""
     from gazenerf_amd import GazeNeRFNetAMD, synth
     dev = torch.device("cuda:0")
@@ -153,12 +153,15 @@ def test_fitter_step_with_the_patchgan_terms():
     gt = torch.rand(B, 3, S, S, device=dev) * face + (1.0 - face)
     fit = L.Fitter(net, n_rows=2, lr=1e-3)
     gan = G.DiscriminatorStep(dev, lr=1e-3, ndf=16)
+    from gazenerf_amd import perceptual as P
+    vgg, gaze_loss = P.VGGPerceptualLoss().to(dev), P.GazeAngularLoss().to(dev)       # random features: the code path, not the reference's loss
     d0 = [q.detach().clone() for q in gan.discriminator.parameters()]
     out = None
     for i in range(3):
         t_rand = synth.synth_jitter(B, 32 * 32, 32, seed=i).to(dev)
-        out = fit.step(slice(0, B), p["xy"], base, gt, face, full_eye, leye, reye, t_rand=t_rand, epoch=1, gan=gan, batch_num=i)
-    assert {"gen_patch_gan_loss", "disc_loss", "total_loss"} <= set(out)
+        out = fit.step(slice(0, B), p["xy"], base, gt, face, full_eye, leye, reye, t_rand=t_rand, epoch=1, gan=gan, batch_num=i,
+                       vgg=vgg, vgg_importance=0.5, gaze_loss=gaze_loss, eye_loss_importance=31.0)
+    assert {"gen_patch_gan_loss", "disc_loss", "total_loss", "vgg_face_loss", "vgg_eyes_loss", "vgg", "angular"} <= set(out)
     assert out["gen_patch_gan_loss"] > 0 and all(v == v for v in out.values())
     assert any(float((a - b).abs().max()) > 0 for a, b in zip(d0, gan.discriminator.parameters()))
     assert all(not q.requires_grad for q in gan.discriminator.parameters())      # frozen again after the generator step
