@@ -76,6 +76,10 @@ def parse():
     ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("GNR_BENCH_SCALING", "weak"),
                     help="cfg2b: weak = one image per GPU; strong = ONE image, rays sharded over the GPUs")
     ap.add_argument("--gather", action="store_true", help="strong scaling, fwd: all_gather the feature maps to every rank inside the step")
+    ap.add_argument("--ref-loss", action="store_true",
+                    help="cfg4: the reference trainer's DEFAULT loss switches (train.py:38-42: use_vgg_loss, use_l1_loss) -- adds the three "
+                         "VGG-perceptual terms (gazenerf_amd.perceptual; randomly initialised extractor: same FLOPs as the ImageNet one)")
+    ap.add_argument("--gan-loss", action="store_true", help="cfg4: + use_patch_gan_loss (discriminator update, then the generator term)")
     ap.add_argument("--no-one-call", action="store_true", help="skip the extra timing of the one-call (in-op tiled) training path")
     ap.add_argument("--pg-timeout", type=float, default=180.0, help="seconds before a stuck rendezvous / collective aborts")
     ap.add_argument("--force-dist", action="store_true", default=os.environ.get("GNR_BENCH_FORCE_DIST", "") == "1",
@@ -643,6 +647,14 @@ def run_cfg4(ctx):
     reducer = GradAllReducer([nr, face, eyes], world, force_collective=bool(dist))
     reducer.arm_overlap()
     opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.999), fused=True)
+    vgg = gan = None
+    if args.ref_loss:
+        from gazenerf_amd.perceptual import VGGPerceptualLoss
+        vgg = VGGPerceptualLoss(resize=True).to(dev)
+    if args.gan_loss:
+        from gazenerf_amd.gan import DiscriminatorStep
+        gan = DiscriminatorStep(dev, lr=1e-4)          # rank-local, as in the reference (its discriminator is not under DDP either)
+    batch_no = [0]
     clock = AllReduceClock(torch)
     timers = {k: StageTimer(k, pool=64) for k in ("fwd_mlp", "dgrad", "wgrad")}
 
@@ -658,7 +670,12 @@ def run_cfg4(ctx):
             t.arm()
         pred = net("train", p["xy"], None, None, p["shape_code"], p["appea_code"], p["gaze"], p["R"], p["T"], p["Kinv"],
                    t_rand=t_rand)["coarse_dict"]
-        loss = losses.total_loss(pred, gt, face_mask, full_eye, left_eye, right_eye, opt_codes)["total_loss"]
+        if gan is not None:
+            gan.step(gt, face_mask, pred["merge_img"])
+        loss = losses.total_loss(pred, gt, face_mask, full_eye, left_eye, right_eye, opt_codes, use_l1=args.ref_loss, epoch=1,
+                                 discriminator=gan.discriminator if gan is not None else None, batch_num=batch_no[0],
+                                 vgg=vgg, vgg_importance=1.0)["total_loss"]
+        batch_no[0] += 1
         loss.backward()
         if dist:
             clock(reducer.all_reduce)
@@ -718,7 +735,11 @@ def run_cfg4(ctx):
                    "rays_per_step_per_gpu": B * n_rays, "samples_per_ray": n_p, "trainable_floats": n_train,
                    "parallelism": "dp%d (images sharded; 3 flat buckets: NeuralRenderer (launched from autograd hooks, in "
                                   "flight during the hot path's backward), face MLP, eyes MLP)" % world,
-                   "precision": args.precision},
+                   "precision": args.precision,
+                   "loss": ("masked L1 image terms + the three VGG-perceptual terms (the reference trainer's default switches; "
+                            "randomly initialised VGG-16 extractor through MIOpen)" if args.ref_loss else
+                            "masked L2 image terms (no pretrained-network term)") +
+                           (" + PatchGAN: discriminator update and generator term" if args.gan_loss else "") + " + code regularisers"},
         "roofline": {"bound": "mfma", "kernel": dom["kernel"], "stage": dom["stage"], "achieved": dom["achieved"], "peak": peak,
                      "unit": "TFLOP/s", "frac": dom["frac"], "avg_launch_ms": dom["avg_ms"], "launches_timed": dom["launches_timed"],
                      "flop_per_launch": dom["flop_per_launch"], "traffic": None,
