@@ -619,7 +619,7 @@ def run_cfg4(ctx):
     trainable parameter's gradient, Adam."""
     args, rank, world, dev, dist, torch = (ctx[k] for k in ("args", "rank", "world", "dev", "dist", "torch"))
     from gazenerf_amd import GazeNeRFNetAMD, losses, synth
-    from gazenerf_amd.hiptime import StageTimer
+    from gazenerf_amd.hiptime import ClockProbe, StageTimer
     from gazenerf_amd.parallel import GradAllReducer
 
     B, S, n_p = 2, 64, 64
@@ -683,6 +683,14 @@ def run_cfg4(ctx):
 
     dt = timed_loop(ctx, step, reset)
     stage_ms = {k: t.collect() for k, t in timers.items()}
+    # two more, untimed, steps with the shader-clock probe armed (as in the cfg2b legs): at this launch size every stage starts right
+    # after lower-power kernels and pays the power management's transition dip -- the probe shows it
+    reset(False)
+    with ClockProbe(dev) as probe:
+        step()
+        step()
+        torch.cuda.synchronize()
+    clocks = probe.mhz()
     if rank != 0:
         return None
     ms = dt / args.steps * 1e3
@@ -721,6 +729,9 @@ def run_cfg4(ctx):
         stages.append({"stage": key, "kernel": kernel, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                        "frac": ach / peak, "avg_ms": a, "launches_timed": len(stage_ms[key]), "flop_per_launch": flop,
                        "share_of_step": a * mult / ms})
+        if key in clocks:
+            stages[-1]["clock_mhz"] = clocks[key]
+            stages[-1]["frac_at_clock"] = ach / (peak * clocks[key] / PEAK_CLOCK_MHZ)
     dom = max(stages, key=lambda s: s["share_of_step"])
     hot_flop = 3 * m * 2 * FLOP_PER_SAMPLE_STREAM
     res = {
