@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--rays", type=int, default=16384)
     ap.add_argument("--precision", default="fp32")
     ap.add_argument("--nosave", action="store_true", help="fwd: the inference kernel (fwd16_kernel<false>), no dumps")
+    ap.add_argument("--gap-us", type=float, default=0.0, help="fwd: synchronize and leave the GPU idle this long before every forward")
+    ap.add_argument("--pre", choices=("none", "gemm", "copy"), default="none",
+                    help="alt: a full-chip torch kernel right in front of every forward (fp32 GEMM ~0.3 ms / 1 GB copy ~0.35 ms)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     x3 = a.precision == "bf16x3"
@@ -45,9 +48,24 @@ def main():
     for t in timers.values():
         t.reset(True)
 
+    ga = torch.randn(2048, 2048, device=dev)
+    gb = torch.randn(2048, 4096, device=dev)
+    ca = torch.empty(128 << 20, device=dev)
+    cb = torch.empty(128 << 20, device=dev)
+
     def one():
         for t in timers.values():
             t.arm()
+        if a.gap_us > 0:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            while (time.perf_counter() - t1) * 1e6 < a.gap_us:
+                pass
+        if a.pre == "gemm":
+            for _ in range(2):
+                torch.mm(ga, gb)
+        elif a.pre == "copy":
+            cb.copy_(ca)
         if a.stage in ("fwd", "alt"):
             # (the caching allocator hands the same workspace back every time)
             lib_res, ws2 = render._run_forward(prob, streams, not a.nosave, False, False, x3)
@@ -74,7 +92,8 @@ def main():
             out.append("%s %.3f ms (n=%d) %s MHz" % (k, sum(ms) / len(ms), len(ms), round(clocks.get(k, 0))))
     if a.nosave:
         a.stage += " (inference kernel)"
-    print("stage_loop %s %s %d rays: %d calls in %.1f s; %s" % (a.stage, a.precision, a.rays, n, a.seconds, "; ".join(out)), flush=True)
+    extra = (" gap %.0f us" % a.gap_us if a.gap_us else "") + (" pre=%s" % a.pre if a.pre != "none" else "")
+    print("stage_loop %s%s %s %d rays: %d calls in %.1f s; %s" % (a.stage, extra, a.precision, a.rays, n, a.seconds, "; ".join(out)), flush=True)
 
 
 if __name__ == "__main__":
