@@ -29,7 +29,8 @@ def main():
     ap.add_argument("--nosave", action="store_true", help="fwd: the inference kernel (fwd16_kernel<false>), no dumps")
     ap.add_argument("--gap-us", type=float, default=0.0, help="fwd: synchronize and leave the GPU idle this long before every forward")
     ap.add_argument("--pre", choices=("none", "gemm", "copy"), default="none",
-                    help="alt: a full-chip torch kernel right in front of every forward (fp32 GEMM ~0.3 ms / 1 GB copy ~0.35 ms)")
+                    help="a full-chip torch kernel right in front of every forward (fp32 GEMM ~0.15 ms each / 0.5 GB copy ~0.2 ms each)")
+    ap.add_argument("--pre-reps", type=int, default=2, help="how many of them (e.g. 250 GEMMs ~ 40 ms of hipBLASLt MFMA work in place of a backward)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     x3 = a.precision == "bf16x3"
@@ -62,10 +63,11 @@ def main():
             while (time.perf_counter() - t1) * 1e6 < a.gap_us:
                 pass
         if a.pre == "gemm":
-            for _ in range(2):
+            for _ in range(a.pre_reps):
                 torch.mm(ga, gb)
         elif a.pre == "copy":
-            cb.copy_(ca)
+            for _ in range(max(1, a.pre_reps // 2)):
+                cb.copy_(ca)
         if a.stage in ("fwd", "alt"):
             # (the caching allocator hands the same workspace back every time)
             lib_res, ws2 = render._run_forward(prob, streams, not a.nosave, False, False, x3)
@@ -92,7 +94,7 @@ def main():
             out.append("%s %.3f ms (n=%d) %s MHz" % (k, sum(ms) / len(ms), len(ms), round(clocks.get(k, 0))))
     if a.nosave:
         a.stage += " (inference kernel)"
-    extra = (" gap %.0f us" % a.gap_us if a.gap_us else "") + (" pre=%s" % a.pre if a.pre != "none" else "")
+    extra = (" gap %.0f us" % a.gap_us if a.gap_us else "") + (" pre=%s x %d" % (a.pre, a.pre_reps) if a.pre != "none" else "")
     print("stage_loop %s%s %s %d rays: %d calls in %.1f s; %s" % (a.stage, extra, a.precision, a.rays, n, a.seconds, "; ".join(out)), flush=True)
 
 
