@@ -103,6 +103,90 @@ __global__ __launch_bounds__(256) void conv16_pack_kernel(const Conv16PackJobs j
     jobs.dst[J.dst_off + i] = (row < J.M && k < J.K) ? J.W[(long)m * J.rs + (long)k * J.cs] : 0.0f;
 }
 
+// The plain epilogue (bias, LeakyReLU, mask, accumulate, store) with the optional RGB rider: register e of acc[mt][t] is channel
+// m0 + 16 mt + 4 g + e at pixel n + t of image b.  Shared by conv16_kernel and conv16_blur_lds_kernel.
+template <int MT, int NT>
+__device__ __forceinline__ void conv16_plain_epilogue(const Conv16Params& cp, f32x4 (&acc)[MT][NT], int b, int n, int m0, int g,
+                                                      const float* rgbw) {
+    typedef typename Pix<NT>::T pv;
+    // the RGB branch on the block output (slices == 1): per lane the dot over its channels, then over the four lane groups
+    float ra[3][NT];
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) ra[o][t] = 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = m0 + 16 * mt + 4 * g + e;
+            if (m >= cp.M) continue;
+            pv v;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) v[t] = acc[mt][t][e];
+            if (cp.bias && !(GNR_C16_ABL & 32)) v += cp.bias[m];
+            if (cp.leaky) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) v[t] = v[t] > 0.0f ? v[t] : LEAK16 * v[t];
+            }
+            if (cp.mask_ref && !(GNR_C16_ABL & 32)) {
+                const pv mk = *(const pv*)(cp.mask_ref + (long)b * cp.mask_batch + (long)m * cp.P + n);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) v[t] *= mk[t] > 0.0f ? 1.0f : LEAK16;
+            }
+            float* dst = cp.C + (((GNR_C16_ABL & 128) ? 0x3FFFCL : -1L) & ((long)b * cp.c_batch + (long)m * cp.P + n));
+            if (cp.accumulate && !(GNR_C16_ABL & 32)) v += *(const pv*)dst;
+            if ((GNR_C16_ABL & 64) && v[0] != 1.2345f) continue;
+            *(pv*)dst = v;
+            if (cp.rgb_w) {
+#pragma unroll
+                for (int o = 0; o < 3; ++o) {
+                    const float wo = rgbw[o * cp.M + m];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) ra[o][t] = fmaf(wo, v[t], ra[o][t]);
+                }
+            }
+        }
+    if (cp.rgb_w) {
+        // Sum over the four lane groups (rows of 16 lanes) with the gfx950 row / half swaps: for four values a, b, c, d
+        //   v_permlane16_swap(a, b) -> [a0 b0 a2 b2], [a1 b1 a3 b3]  (rows; sum = a01 b01 a23 b23)
+        //   v_permlane32_swap(sum_ab, sum_cd) -> [a01 b01 c01 d01], [a23 b23 c23 d23]  (sum: row g = total of value g)
+        // -- three swaps and three adds per four values, and row g of the wave ends up with value 4 k + g of group k:
+        // every lane finishes ONE pixel of up to three outputs (24 ds_bpermute + one lane group doing 12 sigmoids before).
+        auto sw16 = [](float x, float y) {
+            auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
+            const unsigned r0 = r[0], r1 = r[1];       // (bit_cast of a vector ELEMENT reads element 0 with this hipcc: scalars first)
+            return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+        };
+        auto sw32 = [](float x, float y) {
+            auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
+            const unsigned r0 = r[0], r1 = r[1];       // (bit_cast of a vector ELEMENT reads element 0 with this hipcc: scalars first)
+            return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+        };
+        constexpr int NV = 3 * NT, NG = (NV + 3) / 4;
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            float v4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v4[q] = 4 * k + q < NV ? ra[(4 * k + q) / NT][(4 * k + q) % NT] : 0.0f;
+            const float tot = sw32(sw16(v4[0], v4[1]), sw16(v4[2], v4[3]));
+            const int idx = 4 * k + g;
+            if (idx < NV) {
+                const int o = idx / NT, t = idx - o * NT;
+                const long off = ((long)b * 3 + o) * cp.P + n + t;
+                float r = tot + cp.rgb_bias[o];
+                if (cp.rgb_accumulate) r += cp.rgb[off];
+                cp.rgb[off] = r;
+                if (cp.rgb_img) {
+                    r = 1.0f / (1.0f + expf(-r));
+                    cp.rgb_img[off] = r;
+                }
+                if (cp.rgb_out) cp.rgb_out[off] = r;
+            }
+        }
+    }
+}
+
 template <int MT, int NT, bool SHUF, bool BLUR>
 __global__ __launch_bounds__(64 * WPB, 2) void conv16_kernel(const Conv16Params cp) {
     typedef typename Pix<NT>::T pv;
@@ -336,83 +420,154 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv16_kernel(const Conv16Params 
             }
         }
     } else {
-        // the RGB branch on the block output (slices == 1): per lane the dot over its channels, then over the four lane groups
-        float ra[3][NT];
+        conv16_plain_epilogue<MT, NT>(cp, acc, b, n, m0, g, rgbw);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// conv16_blur_lds_kernel (round 4, late): the blur-fused feat_layers GEMM with its operand staged through LDS.
+// The register-fed BLUR instances of conv16_kernel are bound by the vector L1, not by the matrix pipe or by latency: every wave
+// requests the three image rows its stencil needs (12 KB per k-block) plus two 64-lane gathers for the halo columns, twelve waves
+// per CU -- more L1 cycles than MFMA cycles (profiles/r4_n1_pmc_fwdbwd_b7.txt: mfma_busy 0.16-0.42).  Here a
+// workgroup owns 4 image rows x 64 columns (wave w: row y0 + w, a lane 4 consecutive pixels as before): per k-block its 256
+// threads bring 16 channels x 6 rows (the tile + one halo row above and below) x 64 columns and the two halo columns into LDS
+// ONCE -- 24 KB and 192 gather lines where the four waves requested 48 KB and 384 -- and every wave applies the stencil
+// (rows first, then the three taps: the SAME expressions as conv16_kernel, so the operand values are bit-identical) to its
+// three rows from LDS.  Global loads of block kb + 1 are in flight in 25 staging registers during the MFMAs of block kb; two
+// workgroup barriers per k-block (one LDS buffer: 27.6 KB, four workgroups per CU).  One row slice only (M <= 64: the RGB rider
+// stays on the epilogue), W % 64 == 0, H % 4 == 0; everything else keeps the register-fed kernel.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int BL_ROWS = 4, BL_TR = BL_ROWS + 2, BL_RS = 72;      // tile rows, rows incl. halo, floats per LDS row (halo 3 | 64 pixels 4..67 | halo 68)
+template <int MT>
+__global__ __launch_bounds__(64 * WPB, (MT <= 2 ? 4 : 3)) void conv16_blur_lds_kernel(const Conv16Params cp) {
+    constexpr int NT = 4;
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, g = lane >> 4;
+    const int W = cp.W, H = cp.H;
+    const unsigned tiles_x = (unsigned)W >> 6, tiles_y = (unsigned)H >> 2;
+    const unsigned items = (unsigned)cp.batch * tiles_y * tiles_x;
+    const unsigned per_xcd = (items + 7u) >> 3;
+    const unsigned item = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (item >= items) return;
+    const int b = (int)(item / (tiles_y * tiles_x));
+    const unsigned rem = item - (unsigned)b * (tiles_y * tiles_x);
+    const int y0 = 4 * (int)(rem / tiles_x), x0 = 64 * (int)(rem - (rem / tiles_x) * tiles_x);
+    const int y = y0 + wave;
+    const int n = y * W + x0 + NT * li;                            // this lane's 4 consecutive pixels inside image b
+    const int nkb = cp.plan.nkb;
+
+    __shared__ float rgbw[3 * 16 * MT];
+    __shared__ float tile[16 * BL_TR * BL_RS];
+    if (cp.rgb_w)
+        for (int i = tid; i < 3 * cp.M; i += 64 * WPB) rgbw[i] = cp.rgb_w[i];       // visible after the first barrier below
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)cp.At, 0, nkb * (MT * 1024), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(cp.B + (long)b * cp.b_batch), 0, (int)((long)cp.K * cp.P * 4), 0x00020000);
+    const unsigned voffA = (unsigned)lane * 16u;
+    const unsigned rowB = (unsigned)cp.P * 4u;
+
+    float wl[NT], wr[NT], yl, yc, yr;
+    {
+        float wc;
+        blur_taps16(y, H, yl, yc, yr);
 #pragma unroll
-        for (int o = 0; o < 3; ++o)
+        for (int e = 0; e < NT; ++e) blur_taps16(x0 + NT * li + e, W, wl[e], wc, wr[e]);
+    }
+    // staging: thread t brings 16-byte piece t % 16 of the row segments t / 16 + 16 j (segment = channel * 6 + tile row) and, for
+    // t < 192, one halo column element.  Rows / columns outside the image are clamped onto a valid one: their taps are zero.
+    unsigned vst[6], lst[6], vh, lh;
+    {
+        const int piece = tid & 15;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) ra[o][t] = 0.0f;
+        for (int j = 0; j < 6; ++j) {
+            const int seg = (tid >> 4) + 16 * j, ch = seg / BL_TR, r = seg - ch * BL_TR;
+            int iy = y0 - 1 + r;
+            iy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
+            vst[j] = ((unsigned)ch * (unsigned)cp.P + (unsigned)(iy * W + x0 + 4 * piece)) * 4u;
+            lst[j] = (unsigned)((ch * BL_TR + r) * BL_RS + 4 + 4 * piece);
+        }
+        const int side = tid >= 96 ? 1 : 0, idx = tid - 96 * side, ch = idx / BL_TR, r = idx - ch * BL_TR;
+        int iy = y0 - 1 + r;
+        iy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
+        int ix = side ? x0 + 64 : x0 - 1;
+        ix = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+        vh = tid < 192 ? ((unsigned)ch * (unsigned)cp.P + (unsigned)(iy * W + ix)) * 4u : 0xFFFFFF00u;
+        lh = (unsigned)((ch * BL_TR + r) * BL_RS + (side ? 68 : 3));
+    }
+    f32x4 stg[6];
+    float sth;
+    auto load_stage = [&](int kb) {
+        const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)kb * 16u * rowB));
+#pragma unroll
+        for (int j = 0; j < 6; ++j) stg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, vst[j], (int)sb, 0));
+        sth = load1(rsB, vh, sb);
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *(f32x4*)&tile[lst[j]] = stg[j];
+        if (tid < 192) tile[lh] = sth;
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[mt][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 Aq[2][MT];
+    auto load_a = [&](int kb, f32x4 (&A)[MT]) {
+        const unsigned sa = (unsigned)__builtin_amdgcn_readfirstlane(kb * (MT * 1024));
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
+            A[mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, voffA, (int)(sa + (unsigned)mt * 1024u), 0));
+    };
+    // lane group g takes k = 16 kb + 4 s + g at step s (the packed A operand's order): channel 4 s + g of the staged block,
+    // tile rows wave .. wave + 2 = image rows y - 1, y, y + 1
+    const float* my = &tile[(g * BL_TR + wave) * BL_RS + 4 + 4 * li];
+    auto compute = [&](const f32x4 (&A)[MT]) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int m = m0 + 16 * mt + 4 * g + e;
-                if (m >= cp.M) continue;
-                pv v;
+        for (int s = 0; s < 4; ++s) {
+            const float* base = my + s * (4 * BL_TR * BL_RS);
+            const f32x4 c0 = *(const f32x4*)base, c1 = *(const f32x4*)(base + BL_RS), c2 = *(const f32x4*)(base + 2 * BL_RS);
+            float col[NT + 2];
+            col[0] = yl * base[-1] + yc * base[BL_RS - 1] + yr * base[2 * BL_RS - 1];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) v[t] = acc[mt][t][e];
-                if (cp.bias && !(GNR_C16_ABL & 32)) v += cp.bias[m];
-                if (cp.leaky) {
+            for (int e = 0; e < NT; ++e) col[e + 1] = yl * c0[e] + yc * c1[e] + yr * c2[e];
+            col[NT + 1] = yl * base[NT] + yc * base[BL_RS + NT] + yr * base[2 * BL_RS + NT];
+            f32x4 Bo;
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) v[t] = v[t] > 0.0f ? v[t] : LEAK16 * v[t];
-                }
-                if (cp.mask_ref && !(GNR_C16_ABL & 32)) {
-                    const pv mk = *(const pv*)(cp.mask_ref + (long)b * cp.mask_batch + (long)m * cp.P + n);
+            for (int e = 0; e < NT; ++e) Bo[e] = wl[e] * col[e] + 0.5f * col[e + 1] + wr[e] * col[e + 2];
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) v[t] *= mk[t] > 0.0f ? 1.0f : LEAK16;
-                }
-                float* dst = cp.C + (((GNR_C16_ABL & 128) ? 0x3FFFCL : -1L) & ((long)b * cp.c_batch + (long)m * cp.P + n));
-                if (cp.accumulate && !(GNR_C16_ABL & 32)) v += *(const pv*)dst;
-                if ((GNR_C16_ABL & 64) && v[0] != 1.2345f) continue;
-                *(pv*)dst = v;
-                if (cp.rgb_w) {
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int o = 0; o < 3; ++o) {
-                        const float wo = rgbw[o * cp.M + m];
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) ra[o][t] = fmaf(wo, v[t], ra[o][t]);
-                    }
-                }
-            }
-        if (cp.rgb_w) {
-            // Sum over the four lane groups (rows of 16 lanes) with the gfx950 row / half swaps: for four values a, b, c, d
-            //   v_permlane16_swap(a, b) -> [a0 b0 a2 b2], [a1 b1 a3 b3]  (rows; sum = a01 b01 a23 b23)
-            //   v_permlane32_swap(sum_ab, sum_cd) -> [a01 b01 c01 d01], [a23 b23 c23 d23]  (sum: row g = total of value g)
-            // -- three swaps and three adds per four values, and row g of the wave ends up with value 4 k + g of group k:
-            // every lane finishes ONE pixel of up to three outputs (24 ds_bpermute + one lane group doing 12 sigmoids before).
-            auto sw16 = [](float x, float y) {
-                auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
-                const unsigned r0 = r[0], r1 = r[1];       // (bit_cast of a vector ELEMENT reads element 0 with this hipcc: scalars first)
-                return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
-            };
-            auto sw32 = [](float x, float y) {
-                auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
-                const unsigned r0 = r[0], r1 = r[1];       // (bit_cast of a vector ELEMENT reads element 0 with this hipcc: scalars first)
-                return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
-            };
-            constexpr int NV = 3 * NT, NG = (NV + 3) / 4;
-#pragma unroll
-            for (int k = 0; k < NG; ++k) {
-                float v4[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v4[q] = 4 * k + q < NV ? ra[(4 * k + q) / NT][(4 * k + q) % NT] : 0.0f;
-                const float tot = sw32(sw16(v4[0], v4[1]), sw16(v4[2], v4[3]));
-                const int idx = 4 * k + g;
-                if (idx < NV) {
-                    const int o = idx / NT, t = idx - o * NT;
-                    const long off = ((long)b * 3 + o) * cp.P + n + t;
-                    float r = tot + cp.rgb_bias[o];
-                    if (cp.rgb_accumulate) r += cp.rgb[off];
-                    cp.rgb[off] = r;
-                    if (cp.rgb_img) {
-                        r = 1.0f / (1.0f + expf(-r));
-                        cp.rgb_img[off] = r;
-                    }
-                    if (cp.rgb_out) cp.rgb_out[off] = r;
-                }
-            }
+                for (int t = 0; t < NT; ++t) acc[mt][t] = mfma16c(A[mt][s], Bo[t], acc[mt][t]);
         }
+    };
+    auto swap_stage = [&](int next) {          // LDS <- block `next` (staged), staging <- block next + 1
+        __syncthreads();
+        store_stage();
+        if (next + 1 < nkb) load_stage(next + 1);
+        __syncthreads();
+    };
+
+    load_stage(0);
+    load_a(0, Aq[0]);
+    store_stage();
+    if (nkb > 1) load_stage(1);
+    __syncthreads();
+    int kb = 0;
+    for (; kb + 1 < nkb; kb += 2) {
+        load_a(kb + 1, Aq[1]);
+        compute(Aq[0]);
+        swap_stage(kb + 1);
+        if (kb + 2 < nkb) load_a(kb + 2, Aq[0]);
+        compute(Aq[1]);
+        if (kb + 2 < nkb) swap_stage(kb + 2);
     }
+    if (nkb & 1) compute(Aq[0]);
+
+    conv16_plain_epilogue<MT, NT>(cp, acc, b, n, 0, g, rgbw);
 }
 
 // du = Wf^T g with the adjoint of the PixelShuffleUpsample tail in the epilogue (round 4; until then the GEMM wrote du
@@ -914,6 +1069,14 @@ int launch_conv16(const Conv16Params& cp, hipStream_t st) {
     }
     const long items = (long)cp.batch * cp.P / (16 * WPB * cp.plan.NT) * cp.plan.slices;
     const unsigned blocks = (unsigned)(8 * ((items + 7) / 8));
+    // blur-fused feat_layers GEMM with one row slice of <= 64 channels on whole 4 x 64 tiles: the LDS-staged kernel (a pinned
+    // tile -- gnr_set_conv16_tile -- keeps the register-fed instance: the test hook compares the two)
+    if (cp.blur && !cp.shuffle && cp.plan.NT == 4 && cp.plan.slices == 1 && (cp.plan.MT == 2 || cp.plan.MT == 4) &&
+        cp.W % 64 == 0 && cp.H % BL_ROWS == 0 && (long)cp.W * cp.H == cp.P && !g_forced_tile.load()) {
+        if (cp.plan.MT == 2) hipLaunchKernelGGL((conv16_blur_lds_kernel<2>), dim3(blocks), dim3(64 * WPB), 0, st, cp);
+        else hipLaunchKernelGGL((conv16_blur_lds_kernel<4>), dim3(blocks), dim3(64 * WPB), 0, st, cp);
+        return 0;
+    }
     const int key = cp.plan.MT * 10 + cp.plan.NT;
     switch (key) {
         case 132: launch_variant<13, 2>(cp, blocks, st); break;
