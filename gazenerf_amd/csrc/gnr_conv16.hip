@@ -438,9 +438,13 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv16_kernel(const Conv16Params 
 // stays on the epilogue), W % 64 == 0, H % 4 == 0; everything else keeps the register-fed kernel.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int BL_ROWS = 4, BL_TR = BL_ROWS + 2, BL_RS = 72;      // tile rows, rows incl. halo, floats per LDS row (halo 3 | 64 pixels 4..67 | halo 68)
+#ifndef GNR_BLUR_LDS_DEPTH
+#define GNR_BLUR_LDS_DEPTH 1        // k-blocks of global loads in flight per thread (staging register sets).  2 was measured: 148 / 202
+                                    // VGPRs, three / two waves per SIMD, 255 / 156 us against 238 / 139 -- occupancy beats prefetch depth here
+#endif
 template <int MT>
-__global__ __launch_bounds__(64 * WPB, (MT <= 2 ? 4 : 3)) void conv16_blur_lds_kernel(const Conv16Params cp) {
-    constexpr int NT = 4;
+__global__ __launch_bounds__(64 * WPB, (GNR_BLUR_LDS_DEPTH == 1 ? (MT <= 2 ? 4 : 3) : (MT <= 2 ? 3 : 2))) void conv16_blur_lds_kernel(const Conv16Params cp) {
+    constexpr int NT = 4, DEPTH = GNR_BLUR_LDS_DEPTH;
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, g = lane >> 4;
@@ -496,19 +500,23 @@ __global__ __launch_bounds__(64 * WPB, (MT <= 2 ? 4 : 3)) void conv16_blur_lds_k
         vh = tid < 192 ? ((unsigned)ch * (unsigned)cp.P + (unsigned)(iy * W + ix)) * 4u : 0xFFFFFF00u;
         lh = (unsigned)((ch * BL_TR + r) * BL_RS + (side ? 68 : 3));
     }
-    f32x4 stg[6];
-    float sth;
-    auto load_stage = [&](int kb) {
+    f32x4 stg[DEPTH][6];
+    float sth[DEPTH];
+    auto load_stage = [&](auto set, int kb) {          // rows >= K: beyond the descriptor's bound -- zeros, no request
+        constexpr int S = decltype(set)::value;
         const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)kb * 16u * rowB));
 #pragma unroll
-        for (int j = 0; j < 6; ++j) stg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, vst[j], (int)sb, 0));
-        sth = load1(rsB, vh, sb);
+        for (int j = 0; j < 6; ++j) stg[S][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, vst[j], (int)sb, 0));
+        sth[S] = load1(rsB, vh, sb);
     };
-    auto store_stage = [&]() {
+    auto store_stage = [&](auto set) {
+        constexpr int S = decltype(set)::value;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) *(f32x4*)&tile[lst[j]] = stg[j];
-        if (tid < 192) tile[lh] = sth;
+        for (int j = 0; j < 6; ++j) *(f32x4*)&tile[lst[j]] = stg[S][j];
+        if (tid < 192) tile[lh] = sth[S];
     };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, DEPTH - 1>;
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -544,26 +552,29 @@ __global__ __launch_bounds__(64 * WPB, (MT <= 2 ? 4 : 3)) void conv16_blur_lds_k
                 for (int t = 0; t < NT; ++t) acc[mt][t] = mfma16c(A[mt][s], Bo[t], acc[mt][t]);
         }
     };
-    auto swap_stage = [&](int next) {          // LDS <- block `next` (staged), staging <- block next + 1
+    // LDS <- block `next` (in staging set `set`), that set <- block next + DEPTH
+    auto swap_stage = [&](auto set, int next) {
         __syncthreads();
-        store_stage();
-        if (next + 1 < nkb) load_stage(next + 1);
+        store_stage(set);
+        if (next + DEPTH < nkb) load_stage(set, next + DEPTH);
         __syncthreads();
     };
 
-    load_stage(0);
+    load_stage(I0{}, 0);
     load_a(0, Aq[0]);
-    store_stage();
-    if (nkb > 1) load_stage(1);
+    if constexpr (DEPTH == 2) load_stage(I1{}, 1);
+    store_stage(I0{});
+    if (DEPTH < nkb) load_stage(I0{}, DEPTH);
     __syncthreads();
+    // DEPTH 1: set 0 always holds the next block.  DEPTH 2: before an even block kb, set 1 holds kb + 1 and set 0 holds kb + 2.
     int kb = 0;
     for (; kb + 1 < nkb; kb += 2) {
         load_a(kb + 1, Aq[1]);
         compute(Aq[0]);
-        swap_stage(kb + 1);
+        swap_stage(I1{}, kb + 1);
         if (kb + 2 < nkb) load_a(kb + 2, Aq[0]);
         compute(Aq[1]);
-        if (kb + 2 < nkb) swap_stage(kb + 2);
+        if (kb + 2 < nkb) swap_stage(I0{}, kb + 2);
     }
     if (nkb & 1) compute(Aq[0]);
 
@@ -1072,7 +1083,8 @@ int launch_conv16(const Conv16Params& cp, hipStream_t st) {
     // blur-fused feat_layers GEMM with one row slice of <= 64 channels on whole 4 x 64 tiles: the LDS-staged kernel (a pinned
     // tile -- gnr_set_conv16_tile -- keeps the register-fed instance: the test hook compares the two)
     if (cp.blur && !cp.shuffle && cp.plan.NT == 4 && cp.plan.slices == 1 && (cp.plan.MT == 2 || cp.plan.MT == 4) &&
-        cp.W % 64 == 0 && cp.H % BL_ROWS == 0 && (long)cp.W * cp.H == cp.P && !g_forced_tile.load()) {
+        cp.W % 64 == 0 && cp.H % BL_ROWS == 0 && (long)cp.W * cp.H == cp.P && !g_forced_tile.load() &&
+        items >= 512) {          // below two workgroups per CU its barriers are exposed (one 256 x 256 image: 30.7 us against 27.3)
         if (cp.plan.MT == 2) hipLaunchKernelGGL((conv16_blur_lds_kernel<2>), dim3(blocks), dim3(64 * WPB), 0, st, cp);
         else hipLaunchKernelGGL((conv16_blur_lds_kernel<4>), dim3(blocks), dim3(64 * WPB), 0, st, cp);
         return 0;
