@@ -98,16 +98,11 @@ __device__ __forceinline__ int enc16_slot_rt(int idx, int g) {
 
 // ---- weight stream: rows of 1 KiB (64 lanes x float4 = the A fragments of 4 MFMAs), batches of 4 ---------------
 constexpr int WB16 = 4;
-#ifndef GNR_DUMP_BURST
-#define GNR_DUMP_BURST_DEFAULT 8
-#else
-#define GNR_DUMP_BURST_DEFAULT GNR_DUMP_BURST
-#endif
 // dump stores per burst (1 = one store every NROW / NREG rows).  Round 3 (half-row stores): 1 was best.  Round 4, whole-line
 // stores (S16): bursts of 4-12 measure 0.5-0.9 % faster on the training forward and 0.2 % on the dgrad chain
 // (profiles/r4_dump_burst.txt: the store queue takes a burst of full lines without stalling the issue, and fewer, longer
 // interruptions of the MFMA stream cost less than many short ones); 8 is the default.
-constexpr int DUMP_BURST = GNR_DUMP_BURST_DEFAULT;
+constexpr int DUMP_BURST = 8;
 struct WStream16 {
     __amdgpu_buffer_rsrc_t rs;
     unsigned voff;               // lane * 16 (constant)
@@ -126,15 +121,7 @@ __device__ __forceinline__ void wbatch16(WStream16& w, f32x4 (&g)[WB16]) {
 // (plain C: the fully unrolled chain turns the running offset into per-batch scalar constants; hipcc keeps ~300 of
 // them live and spills those through v_writelane / v_readlane -- ~600 VALU instructions per kernel against the 1150
 // v_add of a VGPR offset.  Making the value opaque with an asm, even an empty one, costs thousands of VGPR spills.)
-#ifdef GNR_VOFF_STREAM      // A/B switch: the running offset in the VGPR (one v_add per batch)
-__device__ __forceinline__ void wadvance16(WStream16& w) { w.voff += WB16 * 1024u; }
-#else
-#ifdef GNR_W_HOT       /* timing experiment (wrong results): the weight stream wraps inside a 1 MiB window -> L2-resident */
-__device__ __forceinline__ void wadvance16(WStream16& w) { w.soff = (w.soff + WB16 * 1024u) & 0xFFFFFu; }
-#else
 __device__ __forceinline__ void wadvance16(WStream16& w) { w.soff += WB16 * 1024u; }
-#endif
-#endif
 __device__ __forceinline__ void wstream16_init(WStream16& w, const float* packed, int lane) {
     w.rs = __builtin_amdgcn_make_buffer_rsrc((void*)packed, 0, 0x7ffffff0, 0x00020000);
     w.voff = (unsigned)lane * 16u;
@@ -148,7 +135,6 @@ __device__ __forceinline__ void wstream16_init(WStream16& w, const float* packed
 // the FIRST round that land in an odd wave slot sleep ~25 us once; every later workgroup inherits the offset of the slot
 // it takes over.  (HW_ID bits 3:0 = wave slot within the SIMD.)
 __device__ __forceinline__ void dephase_first_round(unsigned linear_block) {
-#ifndef GNR_NO_DEPHASE
     if (linear_block < 512u) {                          // 2 workgroups x 256 CUs
         unsigned hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -157,9 +143,6 @@ __device__ __forceinline__ void dephase_first_round(unsigned linear_block) {
             for (int i = 0; i < 8; ++i) __builtin_amdgcn_s_sleep(127);      // 8 x 127 x 64 cycles ~ 27 us at 2.4 GHz
         }
     }
-#else
-    (void)linear_block;
-#endif
 }
 
 // ---- dump destination: buffer stores with a wave-uniform descriptor ---------------------------------------------

@@ -270,12 +270,12 @@ __device__ __forceinline__ QDump qdump(float* dst, int C, long chunk, int j, int
     return q;
 }
 
-// GNR_DUMP_BRANCH (per translation unit): test qd.base at run time as well.  The branch splits the unrolled layer code
+// CHAIN3_DUMP_BRANCH (a per-translation-unit setting of the product, not an experiment switch): test qd.base at run time as well.  The branch splits the unrolled layer code
 // into basic blocks, which pins the hand-made instruction order better than sched_barrier does (pure MFMAs still move
 // across those before machine scheduling): measured on bwd3_chain_kernel 6.5 ms with the branch, 6.9 ms without; on
 // fwd3_kernel<true> the same branch cost 190 spilled registers and 1.3 ms.  Compiler behaviour, re-measure on upgrades.
-#ifndef GNR_DUMP_BRANCH
-#define GNR_DUMP_BRANCH 0
+#ifndef CHAIN3_DUMP_BRANCH
+#define CHAIN3_DUMP_BRANCH 0
 #endif
 
 struct XfLateNone {
@@ -294,7 +294,7 @@ __device__ __forceinline__ void convert_quad(f32x16& src, int r, BTile& dst, int
     unsigned h0, l0, h1, l1;
     split_pair(v.x, v.y, h0, l0);
     split_pair(v.z, v.w, h1, l1);
-    if (DUMP && !(ABL & 32) && (!GNR_DUMP_BRANCH || qd.base)) {     // the training dump: the split itself (quads with bit 2 set: halves swapped)
+    if (DUMP && !(ABL & 32) && (!CHAIN3_DUMP_BRANCH || qd.base)) {     // the training dump: the split itself (quads with bit 2 set: halves swapped)
         u32x4* p = (u32x4*)(qd.base + (8 * t + 2 * (r >> 2)) * 512 + (((r >> 2) & 1) ? qd.s1 : qd.s0));
         dump_store(p, (r >> 3) ? u32x4{l0, l1, h0, h1} : u32x4{h0, h1, l0, l1});
     }
@@ -326,7 +326,7 @@ __device__ __forceinline__ void conv_mid(ConvQuad& c) {
 template <bool DUMP>
 __device__ __forceinline__ void conv_finish(const ConvQuad& c, int r, BTile& dst, int t, const QDump& qd) {
     const unsigned l1 = lo_pair(c.v.z, c.v.w, c.h1);
-    if (DUMP && !(ABL & 32) && (!GNR_DUMP_BRANCH || qd.base)) {
+    if (DUMP && !(ABL & 32) && (!CHAIN3_DUMP_BRANCH || qd.base)) {
         u32x4* p = (u32x4*)(qd.base + (8 * t + 2 * (r >> 2)) * 512 + (((r >> 2) & 1) ? qd.s1 : qd.s0));
         dump_store(p, (r >> 3) ? u32x4{c.l0, l1, c.h0, c.h1} : u32x4{c.h0, c.h1, c.l0, l1});
     }

@@ -438,13 +438,11 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv16_kernel(const Conv16Params 
 // stays on the epilogue), W % 64 == 0, H % 4 == 0; everything else keeps the register-fed kernel.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int BL_ROWS = 4, BL_TR = BL_ROWS + 2, BL_RS = 72;      // tile rows, rows incl. halo, floats per LDS row (halo 3 | 64 pixels 4..67 | halo 68)
-#ifndef GNR_BLUR_LDS_DEPTH
-#define GNR_BLUR_LDS_DEPTH 1        // k-blocks of global loads in flight per thread (staging register sets).  2 was measured: 148 / 202
+constexpr int BL_DEPTH = 1;         // k-blocks of global loads in flight per thread (staging register sets).  2 was measured: 148 / 202
                                     // VGPRs, three / two waves per SIMD, 255 / 156 us against 238 / 139 -- occupancy beats prefetch depth here
-#endif
 template <int MT>
-__global__ __launch_bounds__(64 * WPB, (GNR_BLUR_LDS_DEPTH == 1 ? (MT <= 2 ? 4 : 3) : (MT <= 2 ? 3 : 2))) void conv16_blur_lds_kernel(const Conv16Params cp) {
-    constexpr int NT = 4, DEPTH = GNR_BLUR_LDS_DEPTH;
+__global__ __launch_bounds__(64 * WPB, (BL_DEPTH == 1 ? (MT <= 2 ? 4 : 3) : (MT <= 2 ? 3 : 2))) void conv16_blur_lds_kernel(const Conv16Params cp) {
+    constexpr int NT = 4, DEPTH = BL_DEPTH;
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, g = lane >> 4;

@@ -58,11 +58,7 @@ __global__ __launch_bounds__(256, 2) void fwd16_kernel(const FwdParams fp) {
     // second, so the chip streams ONE 5.4 MB weight set at a time through its 4 MB L2s instead of two (the dgrad
     // kernel, one set per launch, fetched a third less per set and tolerated the dump stores; this kernel did not).
     // Price: geometry + encoding are computed once per weight set (~0.4 %).
-#ifdef GNR_FWD16_BOTH_STREAMS          // A/B switch: both weight sets per wave (one pass over the grid)
-    const int s_lo = 0, s_hi = fp.n_streams;
-#else
     const int s_lo = blockIdx.y, s_hi = s_lo + 1;
-#endif
     dephase_first_round(blockIdx.y * gridDim.x + blockIdx.x);
     // the weight stream starts now: its first rows land while the geometry / encoding is computed
     WStream16 w;
@@ -253,11 +249,7 @@ void launch_fwd16(const FwdParams& fp, hipStream_t stream) {
     // > 64 KiB of dynamic LDS needs an opt-in per device: set it on every launch (cheap, and correct for
     // several devices / threads per process -- a process-wide 'done' flag would not be)
     (void)hipFuncSetAttribute((const void*)(fp.save ? fwd16_kernel<true> : fwd16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD16_LDS_BYTES);
-#ifdef GNR_FWD16_BOTH_STREAMS
-    const dim3 g3(grid);
-#else
     const dim3 g3(grid, (unsigned)fp.n_streams);
-#endif
     if (fp.save)
         hipLaunchKernelGGL(fwd16_kernel<true>, g3, dim3(256), FWD16_LDS_BYTES, stream, fp);
     else

@@ -15,11 +15,8 @@
 // only compile in a build that declares itself experimental -- gazenerf_amd/build.py adds -DGNR_EXPERIMENTAL_BUILD whenever
 // extra flags are given, gnr_build_info() then reports them, and the Python binding refuses such a library unless asked.
 #if !defined(GNR_EXPERIMENTAL_BUILD) &&                                                                                     \
-    (defined(GNR_W_HOT) || defined(GNR_WG_HOT) || defined(GNR_NODUMP_TIMING) || defined(GNR_TEMPORAL_DUMP_TIMING) ||        \
-     defined(GNR_ABL16) || defined(GNR_C16_ABL) || defined(GNR_PIPE_ABL) || defined(GNR_TR_ABL) || defined(GNR_ABLATE) ||   \
-     defined(GNR_FWD16_BOTH_STREAMS) || defined(GNR_VOFF_STREAM) || defined(GNR_NO_DEPHASE) || defined(GNR_DUMP_BURST) ||   \
-     defined(GNR_WG_RIDERS) || defined(GNR_WG_NOPIPE) || defined(GNR_WG_NOIMG2W) || defined(GNR_WG_NO2W) ||                 \
-     defined(GNR_DUMP_BRANCH) || defined(GNR_DUMP_QUAD))
+    (defined(GNR_NODUMP_TIMING) || defined(GNR_TEMPORAL_DUMP_TIMING) || defined(GNR_ABL16) || defined(GNR_C16_ABL) ||       \
+     defined(GNR_PIPE_ABL) || defined(GNR_TR_ABL) || defined(GNR_ABLATE) || defined(GNR_WG_RIDERS))
 #error "GNR_* timing switches need -DGNR_EXPERIMENTAL_BUILD (python -m gazenerf_amd.build adds it when GNR_EXTRA_HIPCC_FLAGS is set)"
 #endif
 #include <hip/hip_runtime.h>

@@ -768,6 +768,8 @@ struct UpSaved {                        // kept for the backward
     float* a1[UP_MAX];                  // [B][2C][P]
     unsigned char* sign2[UP_MAX];       // [B][C][P]    four pre-activation sign bits per (out-channel quad, pixel)
     float* pack;                        // packed A operands of every GEMM of the call in flight (forward, then backward)
+    size_t pack_floats;                 // its carved size: the plans are made again after the carve (gnr_set_conv16_tile is
+                                        // process-wide and may change in between) and must fit
     float* u[UP_MAX];                   // [B][C][4P]   shuffled map (pre-blur): read by the backward's dWf GEMM, never written by it
     float* net[UP_MAX];                 // [B][C'][4P]  block output
     float* img;                         // [B][3][Pn]
@@ -793,7 +795,8 @@ static size_t up_carve(const GnrUpsampleProblem* p, const UpDims& d, char* base,
     }
     const size_t Pn = (size_t)d.side[d.n_blocks] * d.side[d.n_blocks];
     z.img = (float*)take(B * 3 * Pn * 4);
-    z.pack = (float*)take((pk_f > pk_b ? pk_f : pk_b) * 4);
+    z.pack_floats = pk_f > pk_b ? pk_f : pk_b;
+    z.pack = (float*)take(z.pack_floats * 4);
     z.vtmp = (float*)take(vmax);
     z.rgb_a = (float*)take(B * 3 * Pn * 4);
     z.rgb_b = (float*)take(B * 3 * Pn * 4);
@@ -907,7 +910,8 @@ int gnr_upsample_fwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, f
     }
     BlockPlans bp[UP_MAX];
     Conv16PackJobs jobs;
-    plan_fwd(d, B, w, bp, &jobs);
+    if (plan_fwd(d, B, w, bp, &jobs) > s.pack_floats)
+        return fail("gnr_upsample_fwd: gnr_set_conv16_tile changed while the call was being planned");
     jobs.dst = s.pack;
     launch_conv16_pack(jobs, st);                 // every weight matrix of the call, one launch
     const float* net = p->x;
@@ -1004,7 +1008,8 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
 
     BlockPlans bp[UP_MAX];
     Conv16PackJobs jobs;
-    plan_bwd(d, B, w, bp, &jobs);
+    if (plan_bwd(d, B, w, bp, &jobs) > s.pack_floats)
+        return fail("gnr_upsample_bwd: gnr_set_conv16_tile changed while the call was being planned");
     jobs.dst = s.pack;
     launch_conv16_pack(jobs, st);                 // every transposed weight matrix of the call, one launch
 

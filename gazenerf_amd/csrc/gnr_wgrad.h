@@ -31,7 +31,7 @@ struct WgradReduceParams {
 
 struct Wgrad16ReduceParams {
     const float* partial; int splits; long n_pad, k_pad;
-    int M, K; float* dW; int ldw; float* bias;
+    int M, K; float* dW; int ldw; float* bias;      // dW NULL: only the bias column is kept; bias NULL: no bias column
 };
 
 constexpr int WG_DEFER_MAX = 16;           // reductions per batched launch (kernel arguments: 16 x (120 + 64) bytes)
@@ -84,7 +84,7 @@ __device__ __forceinline__ void wgrad16_reduce_body(const Wgrad16ReduceParams& r
         for (int u = 0; u < 8; ++u) acc += v[u];
     }
     for (; s < rp.splits; ++s) acc += p[(long)s * ss];
-    if (k < rp.K) rp.dW[(long)n * rp.ldw + k] = acc;
+    if (k < rp.K) { if (rp.dW) rp.dW[(long)n * rp.ldw + k] = acc; }      // NULL == not wanted (include/gnr.h)
     else rp.bias[n] = acc;
 }
 #endif

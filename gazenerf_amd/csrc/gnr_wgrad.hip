@@ -46,7 +46,6 @@ namespace gnr {
 //                  fastest -- a single round of workgroups ends with its slowest member, and in this two-workgroups-
 //                  per-CU kernel a few VALU adds between the MFMAs cost nothing: 384^2 layer 2.65 / 2.77 / 2.92 /
 //                  2.99 ms for modes 3 / 1 / 2 / 0)
-//   GNR_WG_NOPIPE  route chunk-channel-major operands to wgrad_kernel too (instead of wgrad_pipe_kernel)
 //   GNR_PIPE_ABL   timing experiments on wgrad_pipe_kernel, see there
 #ifndef GNR_WG_RIDERS
 #define GNR_WG_RIDERS 3
@@ -401,11 +400,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradParams wp
         const bool isa = j < PA;
         const unsigned i = (unsigned)(isa ? wave * PA + j : wave * PB + (j - PA));
         const unsigned l = lds0 + (unsigned)buf * BUF_BYTES + (isa ? 0u : (unsigned)(TN * CHUNK * 4)) + i * 1024u;
-#ifdef GNR_WG_HOT      /* timing experiment (wrong results): every request re-reads one of the first 8 chunks -> operands L2-resident */
-        const unsigned so = (unsigned)(k & 7) * (isa ? chunk_a : chunk_b) + poff[j];
-#else
         const unsigned so = (unsigned)k * (isa ? chunk_a : chunk_b) + poff[j];
-#endif
         unsigned keep;
         if (isa)
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
@@ -682,11 +677,7 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
         const bool isa = 8 * j < PA;                              // static after unrolling (PA = 24: j < 3): no branch
         const unsigned i = isa ? gp : gp - PA;
         const unsigned l = lds0 + (unsigned)buf * BUF_BYTES + (isa ? 0u : (unsigned)(TN * CHUNK * 4)) + i * 1024u;
-#ifdef GNR_WG_HOT      /* timing experiment (wrong results): every request re-reads one of the first 8 chunks -> operands L2-resident */
-        const unsigned so = (unsigned)(k & 7) * (isa ? kstride_a : kstride_b) + poff[j];
-#else
         const unsigned so = (unsigned)k * (isa ? kstride_a : kstride_b) + poff[j];
-#endif
         unsigned keep;
         if (isa)
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
@@ -969,11 +960,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3_tr_kernel(const WgradParams wp)
                 const bool isa = j < QA / 2;
                 const unsigned i = (unsigned)(isa ? j : j - QA / 2);
                 const unsigned l = lds0 + (unsigned)buf * BUF_BYTES + (isa ? 0u : (unsigned)A_BYTES) + i * 1024u;
-        #ifdef GNR_WG_HOT      /* timing experiment (wrong results): every request re-reads one of the first 8 chunks -> operands L2-resident */
-        const unsigned so = (unsigned)(k & 7) * (isa ? chunk_a : chunk_b) + i * 1024u;
-#else
         const unsigned so = (unsigned)k * (isa ? chunk_a : chunk_b) + i * 1024u;
-#endif
                 if (isa)
                     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" :: "v"(voff), "s"(rsa), "s"(l), "s"(so) : "memory");
                 else
@@ -1417,11 +1404,9 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
     // chunk-channel-major fp32 operands of the MLP's shapes go to the pipelined one-workgroup-per-CU kernel
     // (192-row tiles; K = 64 for the encoding columns); everything else to the two-workgroups-per-CU kernel
     int pipe_xk = 0;
-#ifndef GNR_WG_NOPIPE
     if (!bf16x3 && pixels_per_image == 0 && n_valid <= 384 && (k_valid == 64 || k_valid == 192 || k_valid == 384) &&
         (!with_vec || (n_valid > 192 && k_valid == 384)))        // the density rider needs the 2 x 2 tile grid
         pipe_xk = k_valid == 64 ? 1 : 3;
-#endif
     // small_tiles: a product far below the 192-row tile (the 66 rows RGB_layer_2 has beyond its first 192) goes to
     // wgrad_kernel's per-shape tiles instead of a 192 x 192 tile that would be two-thirds padding
     if (small_tiles && !bf16x3 && !with_vec) pipe_xk = 0;
@@ -1437,19 +1422,13 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
     // channels-first images (the upsampler's 1x1 convolutions): the same pipelined kernel through its image addressing
     // when the 192 x 192 tiles are reasonably full (measured against wgrad_kernel's per-shape tiles: DESIGN.md 3.5)
     bool img2w = false;
-#ifndef GNR_WG_NOIMG2W
     if (!bf16x3 && pixels_per_image > 0 && !with_vec && pixels_per_image % CHUNK == 0) {
         const int tn = (n_valid + 191) / 192, tk = (k_valid + 191) / 192;
         const double fill = (double)n_valid * k_valid / ((double)tn * tk * 192.0 * 192.0);
         img2w = fill >= 0.45 && tk <= 3;
     }
     if (img2w) pipe_xk = 3;
-#endif
-#ifdef GNR_WG_NO2W
-    const bool two_wave = false;
-#else
     const bool two_wave = !bf16x3 && pipe_xk == 3;
-#endif
     const int cfg = pipe_xk ? 0 : choose_tile(n_valid, k_valid, with_vec);
     const int TN = pipe_xk ? 192 : kTileCfgs[cfg].tn, TK = pipe_xk ? 64 * pipe_xk : kTileCfgs[cfg].tk;
     wp.tiles_n = (n_valid + TN - 1) / TN;
@@ -1559,13 +1538,12 @@ bool launch_wgrad16_img(const float* A, int M, const float* B, int K, int batch,
 void launch_wgrad_img(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, int batch,
                       long pixels_per_image, float* dW, int ldw, float* colsum_out, int colsum_ld, float* scratch,
                       hipStream_t stream, WgradDefer* defer) {
+    if (!dW && !colsum_out) return;            // include/gnr.h: a NULL gradient pointer == not wanted -- nothing to compute
     // round 4: the wide products (both sides >= 100 channels) go to the register-fed kernel with 16-granular tiles
     // (gnr_wgrad16.hip); the narrow high-resolution ones stay with the LDS-staged kernels below
-#ifndef GNR_WG_NO16
     if (lda == n_valid && ldb == k_valid && (colsum_ld == 0 || !colsum_out) &&
         launch_wgrad16_img(A, n_valid, B, k_valid, batch, pixels_per_image, dW, ldw, colsum_out, scratch, wgrad_scratch_floats(), stream, defer))
         return;
-#endif
     launch_wgrad_impl(A, lda, n_valid, B, ldb, k_valid, batch, pixels_per_image / CHUNK, dW, ldw, 0, 0, colsum_out,
                       colsum_ld, nullptr, nullptr, scratch, stream, false, pixels_per_image, n_valid, k_valid, false, defer);
 }

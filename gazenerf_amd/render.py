@@ -535,7 +535,9 @@ def render_two_stream_tiled(batch_xy, R, T, Kinv, shape_code, gaze, appea_code, 
 
     ``loss_fn(out, sl) -> scalar`` must return this tile's SHARE of the total loss (normalise by the total ray count,
     not the tile's, if the loss is a mean); any other tensors it touches (targets, masks) are sliced with ``sl`` by the
-    caller.  Gradients end up where ``loss.backward()`` would put them -- ``.grad`` of leaf inputs, upstream of non-leaf
+    caller.  ``loss_fn`` must not run a shared NON-LEAF graph on every tile (e.g. a target produced by another network
+    with ``requires_grad``): the first tile's ``backward()`` frees that graph and the second raises "backward through the
+    graph a second time" -- detach such tensors, or make them leaves, before the call.  Gradients end up where ``loss.backward()`` would put them -- ``.grad`` of leaf inputs, upstream of non-leaf
     ones -- summed over the tiles in a fixed order (deterministic).  Returns ``(total_loss_detached, outputs or None)``; ``return_outputs=True`` also returns the
     detached outputs of the whole image, concatenated along the ray axis.
 
@@ -544,8 +546,11 @@ def render_two_stream_tiled(batch_xy, R, T, Kinv, shape_code, gaze, appea_code, 
     n_r = batch_xy.shape[2]
     if ray_tile is None:
         streams = 1 if eyes_params is None else 2
+        # the problem the op itself would plan with (the view-direction option adds the per-ray bias and its gradient to
+        # the saved workspace)
         dummy = _Problem(batch_xy, R, T, Kinv, shape_code, gaze, appea_code, n_samples, kw.get("world_z1", 2.5),
-                         kw.get("world_z2", -3.5), None, None, kw.get("hidden", 384), kw.get("feat_nc", 258))
+                         kw.get("world_z2", -3.5), None, None, kw.get("hidden", 384), kw.get("feat_nc", 258),
+                         vd_dims=kw.get("vd_dims", 0), ray_bias=(ray_bias_face, ray_bias_eyes))
         ray_tile = plan_ray_tiles(dummy, streams, kw.get("ws_budget_bytes")) or n_r
     if ray_tile < 1:
         raise ValueError("ray_tile must be >= 1")

@@ -119,18 +119,24 @@ class _UpsampleFn(torch.autograd.Function):
         n_blocks = ctx.cfg["n_blocks"]
         dev = xc.device
         g = g_img.contiguous()
-        dx = torch.empty_like(xc)
-        grads = {k: torch.empty_like(v) for k, v in params.items()}
+        # a NULL gradient pointer == not wanted (include/gnr.h): a frozen renderer (latent-code fitting, the reference's
+        # optimize_gaze_direction, gazenerf_trainer.py:1152-1164) skips every weight-gradient GEMM, frozen inputs skip d_x
+        want = ctx.needs_input_grad[1:]
+        dx = torch.empty_like(xc) if want[0] else None
+        grads = {k: torch.empty_like(v) for (k, v), need in zip(params.items(), want[1:]) if need}
         with torch.cuda.device(dev):
             nbytes = lib.gnr_upsample_workspace_bytes(C.byref(p), _lib.UP_WS_BWD)
             scratch = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
             w = _weights_struct(params, n_blocks)
             dw = _weights_struct(grads, n_blocks, _lib.GnrUpsampleWeightGrads)
-            rc = lib.gnr_upsample_bwd(C.byref(p), C.byref(w), C.c_void_p(g.data_ptr()), C.c_void_p(dx.data_ptr()), C.byref(dw),
+            rc = lib.gnr_upsample_bwd(C.byref(p), C.byref(w), C.c_void_p(g.data_ptr()),
+                                      C.c_void_p(dx.data_ptr()) if dx is not None else None,
+                                      C.byref(dw) if grads else None,
                                       C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(scratch.data_ptr()),
                                       scratch.numel(), _stream_ptr(dev))
             _lib.check(rc, lib)
-        return (None, dx.reshape(x.shape)) + tuple(grads[n].reshape(t.shape) for n, t in zip(names, flat))
+        return (None, dx.reshape(x.shape) if dx is not None else None) + \
+            tuple(grads[n].reshape(t.shape) if n in grads else None for n, t in zip(names, flat))
 
 
 def neural_render(x, params: Dict[str, torch.Tensor], n_blocks: int = 3, min_feat: int = 32, final_actvn: bool = True):
@@ -161,6 +167,17 @@ class GraphedUpsample:
     def clear(self):
         self.entries.clear()
 
+    # the cache holds CUDAGraph objects and ctypes structs of device pointers: a copy / pickle of the owning module starts
+    # with an empty cache (and captures again on its first inference call)
+    def __deepcopy__(self, memo):
+        return GraphedUpsample(self.max_entries)
+
+    def __getstate__(self):
+        return {"max_entries": self.max_entries}
+
+    def __setstate__(self, state):
+        self.__init__(state.get("max_entries", 4))
+
     def __call__(self, x, params: Dict[str, torch.Tensor], n_blocks: int, min_feat: int, final_actvn: bool, copy_output: bool = True):
         names = renderer_param_names(n_blocks)
         flat = [params[n] for n in names]
@@ -181,7 +198,13 @@ class GraphedUpsample:
     def _capture(self, x, flat, cfg):
         lib = _lib.load()
         dev = x.device
-        x_static = torch.empty_like(x, memory_format=torch.contiguous_format)
+        # the static buffers outlive this call: allocated outside inference mode, so that a later replay under plain
+        # torch.no_grad() may still copy_ into them (an inference tensor refuses in-place updates outside inference mode)
+        with torch.inference_mode(False), torch.no_grad():
+            return self._capture_impl(lib, dev, x, flat, cfg)
+
+    def _capture_impl(self, lib, dev, x, flat, cfg):
+        x_static = torch.empty(x.shape, dtype=x.dtype, device=dev)
         x_static.copy_(x)
         p, xc, params, names = _prep_upsample(cfg, x_static, flat)
         for n, t, f in zip(names, [params[n] for n in names], flat):

@@ -342,7 +342,9 @@ const char* gnr_build_info(void);
  * feat_layers GEMM exists for 2x4, 4x4, 9x2; with another pair pinned the stencil runs as its own kernel.  The backward's
  * du GEMM with the fused un-shuffle epilogue (channel counts that are multiples of 4, sides that are multiples of 32) has its
  * own instances 2x8, 3x8, 4x8: pinning one of those leaves every other GEMM to the cost model; with a plain pair pinned the
- * un-shuffle runs as its own kernel behind the plain GEMM. */
+ * un-shuffle runs as its own kernel behind the plain GEMM.  Which kernels run therefore depends on the arguments AND on this
+ * pin; it must not be changed while a gnr_upsample_* call is in flight on another thread, nor between a forward and the
+ * workspace-size query it was sized by (a call whose plan no longer fits its workspace returns an error). */
 int gnr_set_conv16_tile(int row_tiles, int pixel_tiles);
 
 #ifdef __cplusplus

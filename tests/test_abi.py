@@ -55,7 +55,7 @@ def test_build_info_ties_the_binary_to_the_tree(lib_built, monkeypatch):
         _lib.check_build_info("src=0123456789abcdef;flags=;experimental=0", "libgnr.so")
     with pytest.raises(RuntimeError, match="built from other sources"):
         _lib.check_build_info("src=unknown;flags=;experimental=0", "libgnr.so")     # a hand-made build
-    exp = "src=%s;flags=-DGNR_W_HOT=1@gnr_fwd16.hip;experimental=1" % bi["src"]
+    exp = "src=%s;flags=-DGNR_NODUMP_TIMING=1@gnr_fwd16.hip;experimental=1" % bi["src"]
     monkeypatch.delenv("GNR_ALLOW_EXPERIMENTAL_LIB", raising=False)
     with pytest.raises(RuntimeError, match="timing-experiment build"):
         _lib.check_build_info(exp, "libgnr.so")
@@ -68,15 +68,35 @@ def test_build_info_ties_the_binary_to_the_tree(lib_built, monkeypatch):
 
 
 def test_timing_switches_do_not_compile_without_the_experimental_macro(tmp_path):
-    """csrc/gnr_internal.h: a wrong-results switch (here GNR_W_HOT) is a compile error unless the build declares itself
+    """csrc/gnr_internal.h: a wrong-results switch (here GNR_NODUMP_TIMING) is a compile error unless the build declares itself
     experimental -- which build.py does, and reports in gnr_build_info(), whenever extra flags are given."""
     import subprocess
     src = os.path.join(ROOT, "gazenerf_amd", "csrc", "gnr_prep.hip")
-    base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-DGNR_W_HOT=1"]
+    base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-DGNR_NODUMP_TIMING=1"]
     r = subprocess.run(base + [src], capture_output=True, text=True)
     assert r.returncode != 0 and "GNR_EXPERIMENTAL_BUILD" in r.stderr
     r = subprocess.run(base + ["-DGNR_EXPERIMENTAL_BUILD=1", src], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_every_compile_time_switch_is_in_the_experimental_guard():
+    """a `#ifdef GNR_*` switch missing from gnr_internal.h's guard list would let a hand build with it report
+    experimental=0.  The list is checked against a grep of the sources, so a new switch cannot be forgotten."""
+    import re
+    csrc = os.path.join(ROOT, "gazenerf_amd", "csrc")
+    guard = open(os.path.join(csrc, "gnr_internal.h")).read()
+    guard = guard[guard.index("#if !defined(GNR_EXPERIMENTAL_BUILD)"):guard.index("#error")]
+    listed = set(re.findall(r"defined\((GNR_\w+)\)", guard)) - {"GNR_EXPERIMENTAL_BUILD"}
+    not_switches = {"GNR_BUILD_INFO", "GNR_SOURCE_HASH", "GNR_EXPERIMENTAL_BUILD", "GNR_H_"}
+    used = set()
+    for name in os.listdir(csrc):
+        if name.endswith((".hip", ".h", ".cpp")):
+            for line in open(os.path.join(csrc, name)):
+                if re.match(r"\s*#\s*(if|ifdef|ifndef|elif)\b", line):
+                    used |= set(re.findall(r"\bGNR_\w+", line))
+    used -= not_switches
+    assert used == listed, (sorted(used - listed), sorted(listed - used))
+    assert len(listed) <= 12
 
 
 def test_the_library_reads_no_environment_variable(lib_built):
