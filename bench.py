@@ -196,6 +196,63 @@ def cpu_baseline(mode, n_samples, budget_s):
     return res
 
 
+
+# ------------------------------------------------------------------------------------------------ host side of a rank
+def parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def pin_rank_to_cpus(torch, dev_index, local_rank, world):
+    """One rank per GPU shares the host with world - 1 others: give every rank its own contiguous block of CPUs, taken
+    from the ones local to ITS GPU (sysfs `local_cpulist` of the device's PCI function) where the node says which those
+    are, otherwise from the process's affinity mask.  Without it the launch threads of eight ranks migrate over the whole
+    mask (and the cgroup of a bench box grants 16 cores for all of them).  -> what was done, for the JSON line."""
+    if world <= 1 or not hasattr(os, "sched_setaffinity") or os.environ.get("GNR_BENCH_NO_AFFINITY") == "1":
+        return None
+    mask = sorted(os.sched_getaffinity(0))
+    cand, basis = mask, "affinity mask (%d CPUs)" % len(mask)
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        with open("/sys/bus/pci/devices/%s/local_cpulist" % bdf) as f:
+            local = sorted(parse_cpulist(f.read()) & set(mask))
+        if len(local) >= world:
+            cand, basis = local, "local_cpulist of GPU %s within the affinity mask (%d CPUs)" % (bdf, len(local))
+    except (OSError, AttributeError, ValueError):
+        pass
+    i = local_rank % world
+    lo, hi = len(cand) * i // world, len(cand) * (i + 1) // world
+    mine = cand[lo:hi] or cand
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError as e:
+        return {"pinned": False, "error": str(e)}
+    torch.set_num_threads(max(1, min(len(mine), 4)))        # the step is launch code: a rank needs no OpenMP team of 256
+    return {"pinned": True, "cpus": "%d-%d" % (mine[0], mine[-1]) if mine == list(range(mine[0], mine[-1] + 1)) else mine,
+            "n_cpus": len(mine), "basis": basis}
+
+
+def print_topology(world):
+    """Rank 0, N > 1: the xGMI topology of the node into stderr (stdout carries the one JSON line)."""
+    import shutil
+    exe = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
+    if not exe:
+        sys.stderr.write("bench.py: rocm-smi not found: no topology printed\n")
+        return
+    try:
+        r = subprocess.run([exe, "--showtopo"], capture_output=True, text=True, timeout=60)
+        sys.stderr.write("bench.py: rocm-smi --showtopo (world size %d)\n%s\n" % (world, r.stdout[-6000:]))
+    except (OSError, subprocess.SubprocessError) as e:
+        sys.stderr.write("bench.py: rocm-smi --showtopo failed: %s\n" % e)
+    sys.stderr.flush()
+
+
 # ------------------------------------------------------------------------------------------------ helpers
 def pmc_traffic(kernel, rays_per_launch, n_samples):
     """HBM-side bytes per launch of `kernel` from a committed rocprofv3 --pmc capture (separate FETCH_SIZE /
@@ -246,6 +303,7 @@ def main():
         raise SystemExit("bench.py: --scaling strong shards the rays of ONE cfg2b image; cfg4 shards images (weak)")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    affinity = pin_rank_to_cpus(torch, dev_index, local_rank, world)
     dist = None
     backend = None
     try:
@@ -262,6 +320,12 @@ def main():
             # backend "nccl" is RCCL on ROCm; GNR_BENCH_BACKEND=gloo is a test-only override (two ranks on
             # one GPU cannot form an RCCL communicator)
             backend = os.environ.get("GNR_BENCH_BACKEND", "nccl")
+            if rank == 0 and world > 1:
+                print_topology(world)
+            if backend == "nccl" and rank == 0:
+                # RCCL's version banner (and nothing else) into stderr of rank 0: stdout carries the one JSON line
+                os.environ.setdefault("NCCL_DEBUG", "VERSION")
+                os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
             timeout = datetime.timedelta(seconds=args.pg_timeout)      # a rank that never arrives fails the job, not hangs it
             if backend == "nccl":
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=timeout)
@@ -273,11 +337,12 @@ def main():
             dist.all_reduce(probe)
             if int(probe.item()) != world:
                 raise RuntimeError("pre-flight all-reduce returned %s, expected %d" % (probe.item(), world))
-        ctx = dict(args=args, rank=rank, world=world, dev=dev, dist=dist, backend=backend, torch=torch)
+        ctx = dict(args=args, rank=rank, world=world, dev=dev, dist=dist, backend=backend, torch=torch, host={})
         res = run_cfg4(ctx) if args.config == "cfg4" else run_cfg2b(ctx)
         if rank == 0:
             from gazenerf_amd import _lib
             res["build"] = _lib.build_info()          # gnr_build_info(): source hash (checked against the tree at load), flags
+            res["host"] = dict(ctx["host"], cpu_affinity=affinity, cores_available="%d (%s)" % available_cores())
             if dist:
                 res["distributed"] = {"backend": backend, "world_size_formed": dist.get_world_size(),
                                       "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None,
@@ -313,19 +378,29 @@ def timed_loop(ctx, step, reset):
     torch.cuda.synchronize()
     reset(True)
     t0 = time.perf_counter()
+    enq = 0.0
     for _ in range(args.steps):
-        step()
+        e0 = time.perf_counter()
+        step()                               # enqueues only: no host synchronisation inside a step
+        enq += time.perf_counter() - e0
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt, enq], device=dev, dtype=torch.float64)
         if ctx["backend"] != "nccl":
             tt = tt.cpu()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt, enq = float(tt[0].item()), float(tt[1].item())
+    # host_enqueue_ms_per_step: wall time of the step's host code up to its last launch (max over ranks).  Well below
+    # ms_per_step = the GPU is the bottleneck and the host runs ahead; equal to it = the rank is launch-bound (or the HIP
+    # queue is full and the host waits on the GPU -- both show up as the same number, which is why it is reported per leg
+    # beside the kernel-time sums)
+    ctx["host"].setdefault("host_enqueue_ms_per_step", []).append(
+        {"leg": ctx.get("leg", "main"), "ms": enq / args.steps * 1e3, "ms_per_step": dt / args.steps * 1e3,
+         "share": enq / dt if dt > 0 else None})
     return dt
 
 
@@ -433,6 +508,7 @@ def run_cfg2b(ctx):
             clock(reducer.all_reduce)
 
     def leg(precision):
+        ctx["leg"] = precision
         dt = timed_loop(ctx, lambda: step(precision), reset)
         stage_ms = {k: t.collect() for k, t in timers.items()}
         info = dist_info(ctx, reducer, clock) if fwdbwd else None
@@ -527,20 +603,26 @@ def run_cfg2b(ctx):
                 stages[-1]["clock_mhz"] = clocks[key]
                 stages[-1]["frac_at_clock"] = ach / (peak * clocks[key] / PEAK_CLOCK_MHZ)
         if fwdbwd and stage_ms.get("comp_bwd"):
-            # HBM-bound compositing pass (CalcRayColor backward): algorithmic bytes per sample = 288 saved features +
-            # sigma_raw + delta read, w_i + dL/dsigma written; per ray 288 upstream + 3 scalars
-            nbytes = m * (288 * 4 + 8 + 8) + rays_per_launch * (288 * 4 + 4 + 8)
+            # HBM-bound compositing pass (CalcRayColor backward, utils/model_utils.py:498-534).  ALGORITHMIC bytes (SURVEY.md
+            # 8(d)): per sample the 258 saved features + sigma_raw + delta read, w_i + dL/dsigma written; per ray 258 upstream
+            # gradients + 3 scalars.  The layout pads the feature axis to 288 (18 tiles of 16): the padded figure is
+            # reported beside it, and `frac` is the algorithmic one.
+            per = lambda ch: m * (ch * 4 + 8 + 8) + rays_per_launch * (ch * 4 + 4 + 8)
+            nbytes, nbytes_pad = per(258), per(288)
             a = mean(stage_ms["comp_bwd"])
-            gbs = nbytes / (a * 1e-3) / 1e9
+            gbs, gbs_pad = nbytes / (a * 1e-3) / 1e9, nbytes_pad / (a * 1e-3) / 1e9
             tr, src = pmc_traffic("gnr::comp_bwd_kernel", rays_per_launch, n_p)
             stages.append({"stage": "comp_bwd", "what": "compositing backward (timed on the first stream; once per stream)",
                            "kernel": "gnr::comp_bwd_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "peak_measured_stream": HBM_STREAM_GBS,
                            "frac_of_measured_stream": gbs / HBM_STREAM_GBS,
-                           "peak_basis": "frac: the 8.0 TB/s HBM3E spec; frac_of_measured_stream: the 6.29 TB/s a float4 copy "
-                                         "achieves on this chip (MI355X_MICROARCH.md chip-level table)",
+                           "achieved_incl_padding": gbs_pad, "frac_incl_padding": gbs_pad / HBM_PEAK_GBS,
+                           "peak_basis": "frac: algorithmic bytes (258 feature channels) against the 8.0 TB/s HBM3E spec; "
+                                         "frac_of_measured_stream: against the 6.29 TB/s a float4 copy achieves on this chip "
+                                         "(MI355X_MICROARCH.md chip-level table); *_incl_padding: the 288-channel layout's bytes",
                            "avg_ms": a, "launches_timed": len(stage_ms["comp_bwd"]),
-                           "bytes_per_launch": nbytes, "traffic": tr, "traffic_source": src,
+                           "bytes_per_launch": nbytes, "bytes_per_launch_incl_padding": nbytes_pad, "traffic": tr,
+                           "traffic_over_algorithmic": tr / nbytes if tr else None, "traffic_source": src,
                            "share_of_step": a * 2 * launches_per_step / ms})
         step_flop = (3 if fwdbwd else 1) * n_local * n_p * 2 * FLOP_PER_SAMPLE_STREAM      # this rank's share
         step_ach = step_flop / (ms * 1e-3) / 1e12

@@ -108,7 +108,10 @@ __global__ __launch_bounds__(256) void comp_bwd_kernel(const CompBwdParams cp) {
             // 0.68 of the 8 TB/s spec); four accumulator chains as before, so the summation order is unchanged
             float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
             static_assert(FEAT_PAD % 16 == 0, "unroll");
-            for (int n = 0; n < FEAT_PAD; n += 16) {
+            // round 5: only the 16-channel groups that hold real channels (258 -> 272 of the layout's 288; the upstream
+            // gradient of a padded channel is zero, so the skipped terms were fmaf(f, 0, v) = v: same bits, 5.6 % fewer bytes)
+            const int nf = (p.feat_nc + 15) & ~15;
+            for (int n = 0; n < nf; n += 16) {
                 float f[16];
 #pragma unroll
                 for (int u = 0; u < 16; ++u) f[u] = __builtin_nontemporal_load(fr + (n + u) * CHUNK);

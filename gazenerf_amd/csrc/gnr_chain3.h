@@ -77,6 +77,9 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // Timing experiments only (results are wrong with any bit set): build with -DGNR_ABLATE=<bits>.
 //   1 no LDS-DMA requests   2 no barriers   4 no activation conversion   8 no ring reads   16 no vmcnt waits
 //   32 no activation dumps (training forward)   64 vmcnt waits ignore the dump stores (as in inference)
+//   128 NOT a timing experiment -- the demonstration behind the bf16x3 gradient gate (tests/test_parity_gpu.py NOISE_GATE,
+//       profiles/r5_grad_gate_dropped_term.txt): the W_lo x a_hi cross term is dropped from ONE layer, the 192 -> 384 one
+//       (RGB_layer_1^T of bwd3_chain_kernel; the forward has no layer of that shape)
 #ifndef GNR_ABLATE
 #define GNR_ABLATE 0
 #endif
@@ -357,6 +360,7 @@ template <int NT_IN, int NT_OUT, int INIT, bool WRITEBACK, int DUMPS, int SKIP =
 __device__ __forceinline__ void mm3_h(f32x16 (&prev)[NT_H], f32x16 (&acc)[NT_H], const float* out_bias, int h, WRing& w,
                                       Xf xf, const QDump qd = QDump{nullptr, 0, 0}, Late late = Late()) {
     constexpr bool DUMP = DUMPS != 0;
+    constexpr bool DROP_LO_HI = (ABL & 128) && NT_IN == NT_H2 && NT_OUT == NT_H;
     constexpr int PPT = NT_OUT;                 // row pairs per input tile (2 K-steps x NT_OUT rows / 2)
     constexpr int NP = NT_IN * PPT;
     static_assert(PPT >= 2, "at most two conversions per pair");
@@ -392,11 +396,11 @@ __device__ __forceinline__ void mm3_h(f32x16 (&prev)[NT_H], f32x16 (&acc)[NT_H],
             convert_quad<WRITEBACK, DUMP>(prev[tn], 4 * qa, nxt, tn, xf, late, qd);
             __builtin_amdgcn_sched_barrier(0);
         }
-        acc[n0] = mfma_bf(g[0][1], cur.h[u0], acc[n0]);
+        if (!DROP_LO_HI) acc[n0] = mfma_bf(g[0][1], cur.h[u0], acc[n0]);
         mid(2);
         if (nq == 1) conv_xf<WRITEBACK>(prev[tn], 4 * qa, tn, xf, cq);
         __builtin_amdgcn_sched_barrier(0);
-        acc[n1] = mfma_bf(g[1][1], cur.h[u1], acc[n1]);
+        if (!DROP_LO_HI) acc[n1] = mfma_bf(g[1][1], cur.h[u1], acc[n1]);
         mid(3);
         if (nq == 1) conv_mid(cq);
         __builtin_amdgcn_sched_barrier(0);

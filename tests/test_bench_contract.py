@@ -135,6 +135,45 @@ def test_one_call_entry_and_preflight_errors():
     assert r.returncode != 0
 
 
+# ----------------------------------------------------------------------------------------------- world size 8 (round 5)
+@pytest.mark.parametrize("what", ["cfg4", "strong"])
+def test_world_size_8_rehearsal_through_the_self_launcher(what):
+    """the launcher path had only ever run at world size 2.  Eight ranks on ONE GPU through
+    `bench.py --gpus 8` itself (gloo override: eight ranks cannot share a device under RCCL) -- rendezvous, port, timeouts,
+    one line from rank 0 only, n_gpus 8, every trainable float exchanged, per-rank CPU affinity and the host enqueue time
+    reported -- so the driver's first 8-GPU RCCL run measures instead of debugging.  Step being scaled:
+    trainer/gazenerf_trainer.py:478-534 (cfg4); the B = 1 render loop utils/render_utils.py:199-219 (strong)."""
+    if what == "cfg4":
+        d = _run([sys.executable, "bench.py", "--gpus", "8", "--config", "cfg4", "--steps", "2", "--warmup", "1"], env=TWO_ON_ONE)
+        assert d["config"]["trainable_floats"] == 5015714
+        ar = d["allreduce"]
+        assert ar["floats"] == 5015714 and ar["bytes"] == 4 * 5015714 and ar["buckets"] == 3 and ar["world_size_formed"] == 8
+        assert abs(d["value"] - 8 * 2 * 4096 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    else:
+        d = _run([sys.executable, "bench.py", "--gpus", "8", "--scaling", "strong", "--micro", "4096", "--steps", "1", "--warmup", "1",
+                  "--no-alt"], env=TWO_ON_ONE)
+        assert d["scaling"] == "strong" and d["config"]["rays_per_step_per_gpu"] == 512 * 512 // 8
+        assert d["allreduce"]["floats"] == 2 * 1518979 and d["allreduce"]["world_size_formed"] == 8
+        assert abs(d["value"] - 512 * 512 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+        assert {s["stage"]: s["launches_timed"] for s in d["stages"]}["fwd_mlp"] == 8        # 32768 rays per rank / 4096
+    assert d["n_gpus"] == 8 and "cpu_baseline" not in d and d["distributed"]["world_size_formed"] == 8
+    host = d["host"]
+    enq = host["host_enqueue_ms_per_step"][0]
+    assert 0 < enq["ms"] <= enq["ms_per_step"] * 1.001 and abs(enq["ms_per_step"] - d["ms_per_step"]) < 1e-6
+    aff = host["cpu_affinity"]                   # rank 0's block of the CPUs the job may use
+    assert aff is not None and (aff.get("pinned") is False or aff["n_cpus"] >= 1)
+
+
+def test_host_enqueue_time_is_reported_at_one_rank():
+    d = _run([sys.executable, "bench.py", "--side", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-one-call"])
+    legs = {e["leg"]: e for e in d["host"]["host_enqueue_ms_per_step"]}
+    assert set(legs) == {"fp32", "bf16x3"} and all(0 < e["ms"] <= e["ms_per_step"] * 1.001 for e in legs.values())
+    assert d["host"]["cpu_affinity"] is None           # one rank keeps the whole mask (the CPU baseline needs it)
+    hb = d["roofline_hbm"]                             # priced on the algorithm's 258 channels, the layout's 288 beside it
+    assert abs(hb["frac_incl_padding"] / hb["frac"] - hb["bytes_per_launch_incl_padding"] / hb["bytes_per_launch"]) < 1e-9
+    assert hb["bytes_per_launch"] == 4096 * 64 * (258 * 4 + 16) + 4096 * (258 * 4 + 12)
+
+
 # ----------------------------------------------------------------------------------------------- RCCL (round 4)
 def test_a_one_rank_rccl_communicator_forms_and_carries_the_gradient_buckets():
     """VERDICT round 3, missing #2: until round 4 no test had ever taken the `nccl` branch of bench.py -- every multi-rank

@@ -828,52 +828,78 @@ def test_backward_error_is_within_the_reference_fp32_noise_mask_stable(precision
     assert not bad, bad
 
 
-N_NOISE_DRAWS = 8
-# per tensor over the draws: median of err_hip / err_ref32 (the review's gate), and the tail: per-tensor max, share of all
-# (tensor, draw) ratios above 3.  Tail gates from the measured distribution, profiles/r4_grad_noise_draws.txt: the
-# reference's OWN second fp32 draw (channel-permuted network, no HIP code) reaches 4.3 on the density head; the fp32 kernels
-# 3.75 (0.5 % of the ratios above 3); bf16x3 -- whose 3-term products carry ~16 mantissa bits, so more pre-activations sit
-# within its noise of zero -- 12.2 in one draw of one layer pair (1.9 % above 3).
+N_NOISE_DRAWS = 16
+# per tensor over the draws: median of err_hip / err_ref32 (the review's gate), and the tail.
+# fp32 kernels: per-tensor max against a yardstick that involves no HIP code + share of all (tensor, draw) ratios above 3
+# (measured, profiles/r4_grad_noise_draws.txt: the reference's OWN second fp32 draw -- channel-permuted network -- reaches 4.3
+# on the density head; the fp32 kernels 3.75, 0.5 % of the ratios above 3).
+# bf16x3 (round 5): its 3-term products carry ~16 mantissa bits, so more pre-activations sit within
+# its noise of zero and ONE flipped mask moves a whole layer pair's tensors by a factor of ~12 in that draw (observed once in
+# 8 draws).  Round 4 let that through with "max <= 20, 5 % of the ratios above 3", which would also pass a kernel that
+# occasionally drops a layer's contribution on one tensor.  Now, per tensor over 16 draws: AT MOST ONE draw above
+# `outlier` = 5 (or above 1.25 x the yardstick's own worst ratio on that tensor, where the yardstick itself exceeds 5), that one
+# draw bounded by `outlier_cap`, and every other draw below it.  profiles/r5_grad_noise_draws.txt is the distribution;
+# profiles/r5_grad_gate_dropped_term.txt shows the gate failing when ONE cross term (W_lo x a_hi) is dropped from ONE layer of
+# bwd3_chain_kernel (an experimental build, -DGNR_ABLATE=128: a diagnostic, not CI).
 NOISE_GATE = {"fp32": dict(median=1.25, max_floor=3.0, max_vs_null=1.25, share_above_3=0.02),
-              "bf16x3": dict(median=1.5, max_floor=20.0, max_vs_null=1.25, share_above_3=0.05)}
+              "bf16x3": dict(median=1.5, outlier=5.0, outlier_vs_null=1.25, outliers_allowed=1, outlier_cap=20.0)}
+
+
+def noise_gate_failures(ratios, precisions=None):
+    """ratios[who][tensor] = [err_who / err_ref32 per draw], who in PRECISIONS + ["null"] -> list of violated gates."""
+    import statistics
+    null_worst = max(max(rs) for rs in ratios["null"].values())
+    bad = []
+    for pr in (precisions or PRECISIONS):
+        gate = NOISE_GATE[pr]
+        for k, rs in ratios[pr].items():
+            med, mx = statistics.median(rs), max(rs)
+            line = "%s %s: median %.2f max %.2f (%s)" % (pr, k, med, mx, " ".join("%.2f" % r for r in rs))
+            if med > gate["median"]:
+                bad.append(line + " -- median gate %.2f" % gate["median"])
+            if "outlier" in gate:
+                thr = max(gate["outlier"], gate["outlier_vs_null"] * max(ratios["null"][k]))
+                above = sum(r > thr for r in rs)
+                if above > gate["outliers_allowed"] or mx > gate["outlier_cap"]:
+                    bad.append(line + " -- %d draw(s) above %.2f (allowed %d), cap %.1f" % (above, thr, gate["outliers_allowed"],
+                                                                                             gate["outlier_cap"]))
+            else:
+                max_gate = max(gate["max_floor"], gate["max_vs_null"] * null_worst)
+                if mx > max_gate:
+                    bad.append(line + " -- max gate %.2f" % max_gate)
+        if "share_above_3" in gate:
+            allr = [r for rs in ratios[pr].values() for r in rs]
+            share = sum(r > 3.0 for r in allr) / len(allr)
+            if share > gate["share_above_3"]:
+                bad.append("%s: %.3f of all ratios above 3 (gate %.2f)" % (pr, share, gate["share_above_3"]))
+    return bad
+
+
+def noise_ratios(n_draws, dev):
+    ratios = {pr: {} for pr in PRECISIONS + ["null"]}
+    for draw in range(n_draws):
+        for k, (e_ref, e_hip) in _noise_errors(False, draw, PRECISIONS, dev, with_null=True).items():
+            for pr in ratios:
+                # eps: the floor where the reference's own noise is ~1e-6 (the layers above the last ReLU mask)
+                eps = GRAD_EPS.get(pr, GRAD_EPS["fp32"])
+                ratios[pr].setdefault(k, []).append(max(e_hip[pr] - eps, 0.0) / max(e_ref, 1e-30))
+    return ratios
 
 
 def test_backward_error_follows_the_reference_fp32_noise_distribution():
     """The unstable problem (opaque head + train jitter: ReLU masks flip under fp32 noise).  Where masks flip the error IS
     the set of flipped samples -- a discrete draw per arithmetic, and with 2 x 24 rays one flip moves a tensor's error by a
     factor of a few.  Round 3 asserted "same distribution, another draw" with ONE draw and a loosened factor (2.5); this
-    test measures it.  8 independent problems (cameras, rays, codes, jitter, weights); per tensor (all 53) the ratio
+    test measures it.  16 independent problems (cameras, rays, codes, jitter, weights); per tensor (all 53) the ratio
     err_hip / err_ref32, both against the oracle in fp64:
       * median over the draws <= 1.25 (fp32 kernels) / 1.5 (bf16x3)  -- observed worst 1.13 / 0.94: the kernels are, if
         anything, closer to fp64 than the reference's fp32 autograd.  A backward that drops a 1 % term is off by 10-2000 x the
         noise in EVERY draw and fails here;
       * the tail against a yardstick that involves no HIP code: the reference's own fp32 autograd on a channel-permuted
-        copy of the network (same function, other summation order = its own second draw).  Per-tensor max <= 1.25 x the
-        yardstick's worst ratio (floor 3; bf16x3: floor 20, see NOISE_GATE), and at most 2 % / 5 % of all (tensor, draw)
-        ratios above 3."""
-    import statistics
-    dev = _dev()
-    ratios = {pr: {} for pr in PRECISIONS + ["null"]}
-    for draw in range(N_NOISE_DRAWS):
-        for k, (e_ref, e_hip) in _noise_errors(False, draw, PRECISIONS, dev, with_null=True).items():
-            for pr in ratios:
-                # eps: the floor where the reference's own noise is ~1e-6 (the layers above the last ReLU mask)
-                eps = GRAD_EPS.get(pr, GRAD_EPS["fp32"])
-                ratios[pr].setdefault(k, []).append(max(e_hip[pr] - eps, 0.0) / max(e_ref, 1e-30))
-    null_worst = max(max(rs) for rs in ratios["null"].values())
-    bad = []
-    for pr in PRECISIONS:
-        gate = NOISE_GATE[pr]
-        max_gate = max(gate["max_floor"], gate["max_vs_null"] * null_worst)
-        for k, rs in ratios[pr].items():
-            med, mx = statistics.median(rs), max(rs)
-            if med > gate["median"] or mx > max_gate:
-                bad.append("%s %s: median %.2f max %.2f, gates %.2f / %.2f (%s)" % (pr, k, med, mx, gate["median"], max_gate,
-                                                                                    " ".join("%.2f" % r for r in rs)))
-        allr = [r for rs in ratios[pr].values() for r in rs]
-        share = sum(r > 3.0 for r in allr) / len(allr)
-        if share > gate["share_above_3"]:
-            bad.append("%s: %.3f of all ratios above 3 (gate %.2f)" % (pr, share, gate["share_above_3"]))
+        copy of the network (same function, other summation order = its own second draw).  fp32 kernels: per-tensor max
+        <= 1.25 x the yardstick's worst ratio (floor 3) and at most 2 % of all (tensor, draw) ratios above 3; bf16x3: per
+        tensor at most one draw above 5 (see NOISE_GATE)."""
+    bad = noise_gate_failures(noise_ratios(N_NOISE_DRAWS, _dev()))
     assert not bad, bad
 
 

@@ -316,3 +316,82 @@ def test_bad_inputs_are_rejected():
         neural_render(torch.zeros(1, 12, 8, 8, device=dev), params, n_blocks=1, min_feat=4)
     with pytest.raises(ValueError):
         neural_render(torch.zeros(1, 13, 16, 16, device=dev), params, n_blocks=1, min_feat=4)
+
+
+@pytest.mark.gpu
+def test_frozen_parameters_and_frozen_input_pass_null_gradient_pointers():
+    """include/gnr.h documents every GnrUpsampleWeightGrads entry -- and `dw`, `d_x` themselves -- as
+    "NULL == not wanted", but the register-fed weight-gradient path (wgrad16) stored through a NULL dW.  The autograd op now
+    passes NULL for whatever does not require a gradient, on the reference's default network (258/129/64/32 channels:
+    the 129 x 258 and 516 x 258 products take the wgrad16 path): the remaining gradients are bit-identical to the full call."""
+    import ctypes as C
+    from gazenerf_amd import _lib, neural_render
+    from gazenerf_amd.upsample import _prep_upsample, _weights_struct, renderer_param_names
+    dev = _dev()
+    params = synth.hash_renderer_params(seed=5)
+    x = synth.synth_featmap(2, 258, 64, seed=2).to(dev)
+
+    def run(need_x, need):
+        xg = x.clone().requires_grad_(need_x)
+        pg = {k: v.to(dev).clone().requires_grad_(need(k)) for k, v in params.items()}
+        img = neural_render(xg, pg)
+        _loss(img).backward()
+        return xg.grad, {k: v.grad for k, v in pg.items()}
+
+    gx_all, gp_all = run(True, lambda k: True)
+    gx, gp = run(True, lambda k: False)                                   # frozen renderer: d_x only, dw == NULL
+    assert torch.equal(gx, gx_all) and all(v is None for v in gp.values())
+    gx, gp = run(False, lambda k: True)                                   # d_x == NULL
+    assert gx is None and all(torch.equal(gp[k], gp_all[k]) for k in gp_all)
+    gx, gp = run(True, lambda k: k.endswith(".bias") or "layer_2" in k)   # weights NULL, their biases wanted, and a mix
+    assert torch.equal(gx, gx_all)
+    for k, v in gp.items():
+        if k.endswith(".bias") or "layer_2" in k:
+            assert torch.equal(v, gp_all[k]), k
+        else:
+            assert v is None, k
+
+    # the C ABI directly: dw == NULL and d_x == NULL together is a valid (empty) request
+    lib = _lib.load()
+    cfg = dict(n_blocks=3, min_feat=32, final_actvn=True)
+    names = renderer_param_names(3)
+    flat = [params[n].to(dev) for n in names]
+    p, xc, prm, _ = _prep_upsample(cfg, x, flat)
+    ws = torch.empty(int(lib.gnr_upsample_workspace_bytes(C.byref(p), _lib.UP_WS_FWD)), dtype=torch.uint8, device=dev)
+    sc = torch.empty(int(lib.gnr_upsample_workspace_bytes(C.byref(p), _lib.UP_WS_BWD)), dtype=torch.uint8, device=dev)
+    img = torch.empty(2, 3, 512, 512, device=dev)
+    w = _weights_struct(prm, 3)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(lib.gnr_upsample_fwd(C.byref(p), C.byref(w), C.c_void_p(img.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), st), lib)
+    g = torch.ones_like(img)
+    _lib.check(lib.gnr_upsample_bwd(C.byref(p), C.byref(w), C.c_void_p(g.data_ptr()), None, None, C.c_void_p(ws.data_ptr()),
+                                    ws.numel(), C.c_void_p(sc.data_ptr()), sc.numel(), st), lib)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_graph_cache_under_inference_mode_then_no_grad_and_module_copies():
+    """a graph captured under torch.inference_mode() kept inference tensors as its static buffers and
+    a later torch.no_grad() call failed at the in-place copy; deepcopy / pickle of a module that had captured raised."""
+    import copy
+    import io
+    from gazenerf_amd import NeuralRendererAMD
+    dev = _dev()
+    torch.manual_seed(0)
+    net = NeuralRendererAMD(feat_nc=64, featmap_size=32, img_size=128, min_feat=16).to(dev).eval()
+    x = synth.synth_featmap(1, 64, 32, seed=1).to(dev)
+    with torch.inference_mode():
+        a = net(x)
+    with torch.no_grad():
+        b = net(x)
+    assert net._graphed.captures == 1 and net._graphed.replays == 2 and torch.equal(a, b)
+    twin = copy.deepcopy(net)
+    with torch.no_grad():
+        c = twin(x)
+    assert twin._graphed.captures == 1 and torch.equal(c, b)
+    buf = io.BytesIO()
+    torch.save(net, buf)
+    buf.seek(0)
+    again = torch.load(buf, weights_only=False)
+    with torch.no_grad():
+        assert torch.equal(again(x), b)

@@ -24,7 +24,7 @@ def load(d):
 def last_iter(disp):
     ids = sorted(disp)
     names = [disp[i]["name"] for i in ids]
-    rgb = [k for k, n in enumerate(names) if "rgb_conv_kernel" in n]
+    rgb = [k for k, n in enumerate(names) if "rgb_conv" in n]        # rgb_conv_kernel / rgb_conv_split_kernel: first launch of a forward
     grids = {k: int(disp[ids[k]]["grid"]) for k in rgb}
     start = [k for k in rgb if grids[k] == min(grids.values())][-1] if rgb else 0
     return [disp[ids[k]] for k in range(start, len(ids))]
@@ -36,7 +36,7 @@ rows = last_iter(sq)
 fr = last_iter(fe) if fe else [None] * len(rows)
 wrr = last_iter(wr) if wr else [None] * len(rows)
 for d, f, w in zip(rows, fr, wrr):
-    if not any(t in d["name"] for t in ("conv16_kernel", "wgrad", "blur_kernel", "unshuffle")):
+    if "at::native" in d["name"] or "rocclr" in d["name"]:
         continue
     n = d["name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("gnr::", "").split("(")[0]
     wc = d.get("SQ_WAVE_CYCLES", 0)

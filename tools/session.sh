@@ -1,0 +1,87 @@
+#!/bin/bash
+# One GPU session on a gpurun box: named steps, run in the order given, everything under gpurun_out/<name>/.
+#   tools/session.sh <name> <step> [<step> ...]
+# (replaces the per-session scripts of rounds 1-4, kept under tools/history/).  Steps:
+#   tests            python -m pytest tests -m gpu -x -q                          -> pytest.log
+#   tests:<expr>     ... -k <expr>                                                -> pytest_k.log
+#   smoke            __graft_entry__.smoke()
+#   n1               upsampler alone under the kernel trace, B = 1 graph + B = 7  -> n1_launches.txt
+#   n1pmc            per-launch counters of the B = 7 forward+backward            -> n1_pmc.txt
+#   bench            python bench.py --steps 20 --warmup 5 (the driver's command) -> bench_default.json
+#   bench_fwd        python bench.py --mode fwd --steps 5 --warmup 2              -> bench_fwd.json
+#   cfg4, cfg4x3     python bench.py --config cfg4 [--precision bf16x3]           -> bench_cfg4[_bf16x3].json
+#   stats            rocprofv3 --kernel-trace --stats of the default bench        -> stats/kernel_stats.csv
+#   configs          tools/run_configs.py under rocprofv3 --kernel-trace --stats  -> configs.txt, configs_kernel_stats.csv
+#   sq               SQ counters of the hot-path kernels at the bench's tile      -> sq/summary.txt
+#   traffic          tools/pmc_capture.py (FETCH_SIZE / WRITE_SIZE per launch)    -> traffic.txt
+#   rccl1            the forced one-rank RCCL bench lines                         -> bench_forced_rccl_ws1*.json
+#   ws8              bench.py --gpus 8 on one GPU over gloo (cfg4 + strong)       -> bench_ws8_*.json
+#   noise            tests/diagnostics/grad_noise_draws.py                        -> grad_noise_draws.txt
+#   dropterm         the bf16x3 gate on a build with one cross term dropped       -> grad_gate_dropped_term.txt
+#   x3energy         J per step of the bf16x3 leg (tools/smi_sample.py)           -> x3_energy.txt
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+NAME=$1; shift
+O=$R/gpurun_out/$NAME
+mkdir -p $O
+export TMPDIR=/tmp
+cd $R
+jline() { python - "$1" <<'P'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[1].split('/')[-1], 'value %.1f' % d['value'], 'ms/step %.2f' % d['ms_per_step'], 'up', d.get('upsampler', {}).get('fwdbwd_ms'),
+          'frac %.3f' % d['roofline']['frac'], 'step_frac', d['roofline'].get('step_frac'), 'enq', [round(e['ms'], 2) for e in d.get('host', {}).get('host_enqueue_ms_per_step', [])], d.get('build'))
+except Exception as e:
+    print(sys.argv[1], 'ERR', e)
+P
+}
+for STEP in "$@"; do
+  echo "=== $STEP ($(date +%H:%M:%S))"
+  case $STEP in
+    tests) timeout 2400 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log; tail -5 $O/pytest.log;;
+    tests:*) timeout 1500 python -m pytest tests -m gpu -x -q -k "${STEP#tests:}" > $O/pytest_k.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_k.log; tail -15 $O/pytest_k.log;;
+    smoke) python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2;;
+    n1)
+      bash tools/n1_trace.sh $NAME/b1_graph --batch 1 --iters 9 --fwd-only > /dev/null 2>&1
+      bash tools/n1_trace.sh $NAME/b7 --batch 7 --iters 5 > /dev/null 2>&1
+      { echo "# tools/session.sh $NAME n1 ($(python -c 'from gazenerf_amd import _lib; print(_lib.build_info())')): tools/n1_trace.sh <name> --batch 1 --iters 9 --fwd-only (HIP-graph replay) and --batch 7 --iters 5"
+        for n in b1_graph b7; do echo "== $n"; grep "N1 B" $O/$n/wall.log; grep -v "torch:" $O/$n/launches.txt; done; } > $O/n1_launches.txt
+      grep -E "N1 B|kernel time" $O/n1_launches.txt; rm -rf $O/*/prof;;
+    n1pmc)
+      bash tools/n1_pmc.sh $NAME/n1pmc --batch 7 --iters 2 > /dev/null 2>&1
+      { echo "# tools/session.sh $NAME n1pmc ($(python -c 'from gazenerf_amd import _lib; print(_lib.build_info())')): tools/n1_pmc.sh --batch 7 --iters 2 -- every launch of the LAST forward+backward;"
+        echo "# SQ counters, FETCH_SIZE (as counted: the gfx950 x2 for 16-B/lane streaming reads is not applied) and WRITE_SIZE from three separate --pmc passes, --kernel-trace only"
+        cat $O/n1pmc/pmc.txt; } > $O/n1_pmc.txt
+      rm -rf $O/n1pmc/sq $O/n1pmc/fetch $O/n1pmc/write; tail -n +3 $O/n1_pmc.txt | cut -c1-200;;
+    bench) timeout 1500 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; jline $O/bench_default.json;;
+    bench_fwd) timeout 900 python bench.py --mode fwd --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_fwd.json 2> $O/bench_fwd.err; jline $O/bench_fwd.json;;
+    cfg4) timeout 900 python bench.py --config cfg4 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_cfg4.json 2> $O/bench_cfg4.err; jline $O/bench_cfg4.json;;
+    cfg4x3) timeout 900 python bench.py --config cfg4 --steps 10 --warmup 3 --no-cpu-baseline --precision bf16x3 > $O/bench_cfg4_bf16x3.json 2> $O/bench_cfg4_bf16x3.err; jline $O/bench_cfg4_bf16x3.json;;
+    stats) bash tools/prof_stats.sh $NAME/stats > /dev/null 2>&1; rm -rf $O/stats/prof; head -12 $O/stats/kernel_stats.csv | cut -c1-160;;
+    configs)
+      ( cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfgprof -o run -- python $R/tools/run_configs.py --reps 3 > $O/configs.txt 2> $O/configs.err )
+      find $O/cfgprof -name "*kernel_stats.csv" -exec cp {} $O/configs_kernel_stats.csv \; ; rm -rf $O/cfgprof; cat $O/configs.txt | tail -20;;
+    sq) bash tools/pmc_ab.sh $NAME/sq X=1 > /dev/null 2>&1; rm -rf $O/sq/sq $O/sq/sq2 $O/sq/sqf $O/sq/fetch $O/sq/write; head -60 $O/sq/summary.txt | cut -c1-220;;
+    traffic) timeout 1500 python tools/pmc_capture.py $NAME/traffic > $O/traffic.txt 2>&1; tail -25 $O/traffic.txt | cut -c1-200;;
+    rccl1)
+      GNR_BENCH_FORCE_DIST=1 timeout 900 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt --no-one-call > $O/bench_forced_rccl_ws1.json 2> $O/bench_forced_rccl_ws1.err; jline $O/bench_forced_rccl_ws1.json
+      GNR_BENCH_FORCE_DIST=1 timeout 900 python bench.py --config cfg4 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_forced_rccl_ws1_cfg4.json 2> $O/bench_forced_rccl_ws1_cfg4.err; jline $O/bench_forced_rccl_ws1_cfg4.json;;
+    ws8)
+      GNR_BENCH_BACKEND=gloo GNR_BENCH_DEVICE=0 timeout 1200 python bench.py --gpus 8 --config cfg4 --steps 5 --warmup 2 > $O/bench_ws8_gloo_cfg4.json 2> $O/bench_ws8_gloo_cfg4.err; jline $O/bench_ws8_gloo_cfg4.json
+      GNR_BENCH_BACKEND=gloo GNR_BENCH_DEVICE=0 timeout 1200 python bench.py --gpus 8 --scaling strong --micro 4096 --steps 3 --warmup 1 --no-alt > $O/bench_ws8_gloo_strong.json 2> $O/bench_ws8_gloo_strong.err; jline $O/bench_ws8_gloo_strong.json
+      grep -v "^\[W\|^W0\|^\*\*\*" $O/bench_ws8_gloo_cfg4.err | head -60 > $O/bench_ws8_gloo_cfg4_stderr_head.txt;;
+    noise) timeout 2400 python tests/diagnostics/grad_noise_draws.py > $O/grad_noise_draws.txt 2> $O/grad_noise_draws.err; tail -8 $O/grad_noise_draws.txt | cut -c1-250;;
+    dropterm)
+      GNR_EXTRA_FILES="gnr_bwd3.hip" GNR_EXTRA_HIPCC_FLAGS="-DGNR_ABLATE=128" python -m gazenerf_amd.build --no-torch-ext > $O/dropterm_build.log 2>&1
+      { echo "# tools/session.sh $NAME dropterm: libgnr.so rebuilt with -DGNR_ABLATE=128 on gnr_bwd3.hip (the W_lo x a_hi cross term dropped from ONE layer of"
+        echo "# bwd3_chain_kernel, RGB_layer_1^T), then tests/diagnostics/grad_noise_draws.py: the gate of tests/test_parity_gpu.py must FAIL"
+        GNR_ALLOW_EXPERIMENTAL_LIB=1 timeout 2400 python tests/diagnostics/grad_noise_draws.py 2> $O/dropterm.err; } > $O/grad_gate_dropped_term.txt
+      python -m gazenerf_amd.build > $O/dropterm_rebuild.log 2>&1          # back to the product build
+      python -c "from gazenerf_amd import _lib; print('restored:', _lib.build_info())"
+      grep -c "FAIL\|  bf16x3" $O/grad_gate_dropped_term.txt; grep "^gate" $O/grad_gate_dropped_term.txt | cut -c1-60;;
+    x3energy) timeout 900 python tools/x3_energy.py > $O/x3_energy.txt 2> $O/x3_energy.err; tail -12 $O/x3_energy.txt;;
+    *) echo "unknown step $STEP";;
+  esac
+done
+echo "=== done ($(date +%H:%M:%S))"
