@@ -437,32 +437,39 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv16_kernel(const Conv16Params 
 // workgroup barriers per k-block (one LDS buffer: 27.6 KB, four workgroups per CU).  One row slice only (M <= 64: the RGB rider
 // stays on the epilogue), W % 64 == 0, H % 4 == 0; everything else keeps the register-fed kernel.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int BL_ROWS = 4, BL_TR = BL_ROWS + 2, BL_RS = 72;      // tile rows, rows incl. halo, floats per LDS row (halo 3 | 64 pixels 4..67 | halo 68)
+constexpr int BL_RS = 72;           // floats per LDS row (halo 3 | 64 pixels 4..67 | halo 68)
+#ifndef GNR_BLUR_ROWS
+#define GNR_BLUR_ROWS 4             // round-5 A/B: image rows per workgroup tile = waves per workgroup (4 or 8)
+#endif
+constexpr int BL_ROWS = GNR_BLUR_ROWS;
 constexpr int BL_DEPTH = 1;         // k-blocks of global loads in flight per thread (staging register sets).  2 was measured: 148 / 202
                                     // VGPRs, three / two waves per SIMD, 255 / 156 us against 238 / 139 -- occupancy beats prefetch depth here
-template <int MT>
-__global__ __launch_bounds__(64 * WPB, (BL_DEPTH == 1 ? (MT <= 2 ? 4 : 3) : (MT <= 2 ? 3 : 2))) void conv16_blur_lds_kernel(const Conv16Params cp) {
-    constexpr int NT = 4, DEPTH = BL_DEPTH;
+template <int MT, int ROWS>
+__global__ __launch_bounds__(64 * ROWS, (ROWS == 4 ? (MT <= 2 ? 4 : 3) : (MT <= 2 ? 4 : 2))) void conv16_blur_lds_kernel(const Conv16Params cp) {
+    constexpr int NT = 4, DEPTH = BL_DEPTH, TR = ROWS + 2, NTH = 64 * ROWS;
+    constexpr int SEGS = 16 * TR, NJ = (SEGS * 16 + NTH - 1) / NTH, NHALO = 2 * 16 * TR;      // 256-byte row segments, b128 pieces per thread, halo elements
+    static_assert(SEGS * 16 == NJ * NTH, "every thread stages the same number of pieces");
+    static_assert(NHALO <= NTH, "one halo element per thread");
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, g = lane >> 4;
     const int W = cp.W, H = cp.H;
-    const unsigned tiles_x = (unsigned)W >> 6, tiles_y = (unsigned)H >> 2;
+    const unsigned tiles_x = (unsigned)W >> 6, tiles_y = (unsigned)H / ROWS;
     const unsigned items = (unsigned)cp.batch * tiles_y * tiles_x;
     const unsigned per_xcd = (items + 7u) >> 3;
     const unsigned item = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if (item >= items) return;
     const int b = (int)(item / (tiles_y * tiles_x));
     const unsigned rem = item - (unsigned)b * (tiles_y * tiles_x);
-    const int y0 = 4 * (int)(rem / tiles_x), x0 = 64 * (int)(rem - (rem / tiles_x) * tiles_x);
+    const int y0 = ROWS * (int)(rem / tiles_x), x0 = 64 * (int)(rem - (rem / tiles_x) * tiles_x);
     const int y = y0 + wave;
     const int n = y * W + x0 + NT * li;                            // this lane's 4 consecutive pixels inside image b
     const int nkb = cp.plan.nkb;
 
     __shared__ float rgbw[3 * 16 * MT];
-    __shared__ float tile[16 * BL_TR * BL_RS];
+    __shared__ float tile[16 * TR * BL_RS];
     if (cp.rgb_w)
-        for (int i = tid; i < 3 * cp.M; i += 64 * WPB) rgbw[i] = cp.rgb_w[i];       // visible after the first barrier below
+        for (int i = tid; i < 3 * cp.M; i += NTH) rgbw[i] = cp.rgb_w[i];       // visible after the first barrier below
 
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)cp.At, 0, nkb * (MT * 1024), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
@@ -477,41 +484,41 @@ __global__ __launch_bounds__(64 * WPB, (BL_DEPTH == 1 ? (MT <= 2 ? 4 : 3) : (MT 
 #pragma unroll
         for (int e = 0; e < NT; ++e) blur_taps16(x0 + NT * li + e, W, wl[e], wc, wr[e]);
     }
-    // staging: thread t brings 16-byte piece t % 16 of the row segments t / 16 + 16 j (segment = channel * 6 + tile row) and, for
-    // t < 192, one halo column element.  Rows / columns outside the image are clamped onto a valid one: their taps are zero.
-    unsigned vst[6], lst[6], vh, lh;
+    // staging: thread t brings 16-byte piece t % 16 of the row segments t / 16 + (NTH / 16) j (segment = channel * TR + tile row)
+    // and, for t < NHALO, one halo column element.  Rows / columns outside the image are clamped onto a valid one: their taps are zero.
+    unsigned vst[NJ], lst[NJ], vh, lh;
     {
         const int piece = tid & 15;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int seg = (tid >> 4) + 16 * j, ch = seg / BL_TR, r = seg - ch * BL_TR;
+        for (int j = 0; j < NJ; ++j) {
+            const int seg = (tid >> 4) + (NTH / 16) * j, ch = seg / TR, r = seg - ch * TR;
             int iy = y0 - 1 + r;
             iy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
             vst[j] = ((unsigned)ch * (unsigned)cp.P + (unsigned)(iy * W + x0 + 4 * piece)) * 4u;
-            lst[j] = (unsigned)((ch * BL_TR + r) * BL_RS + 4 + 4 * piece);
+            lst[j] = (unsigned)((ch * TR + r) * BL_RS + 4 + 4 * piece);
         }
-        const int side = tid >= 96 ? 1 : 0, idx = tid - 96 * side, ch = idx / BL_TR, r = idx - ch * BL_TR;
+        const int side = tid >= NHALO / 2 ? 1 : 0, idx = tid - (NHALO / 2) * side, ch = idx / TR, r = idx - ch * TR;
         int iy = y0 - 1 + r;
         iy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
         int ix = side ? x0 + 64 : x0 - 1;
         ix = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
-        vh = tid < 192 ? ((unsigned)ch * (unsigned)cp.P + (unsigned)(iy * W + ix)) * 4u : 0xFFFFFF00u;
-        lh = (unsigned)((ch * BL_TR + r) * BL_RS + (side ? 68 : 3));
+        vh = tid < NHALO ? ((unsigned)ch * (unsigned)cp.P + (unsigned)(iy * W + ix)) * 4u : 0xFFFFFF00u;
+        lh = (unsigned)((ch * TR + r) * BL_RS + (side ? 68 : 3));
     }
-    f32x4 stg[DEPTH][6];
+    f32x4 stg[DEPTH][NJ];
     float sth[DEPTH];
     auto load_stage = [&](auto set, int kb) {          // rows >= K: beyond the descriptor's bound -- zeros, no request
         constexpr int S = decltype(set)::value;
         const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)kb * 16u * rowB));
 #pragma unroll
-        for (int j = 0; j < 6; ++j) stg[S][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, vst[j], (int)sb, 0));
+        for (int j = 0; j < NJ; ++j) stg[S][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, vst[j], (int)sb, 0));
         sth[S] = load1(rsB, vh, sb);
     };
     auto store_stage = [&](auto set) {
         constexpr int S = decltype(set)::value;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) *(f32x4*)&tile[lst[j]] = stg[S][j];
-        if (tid < 192) tile[lh] = sth[S];
+        for (int j = 0; j < NJ; ++j) *(f32x4*)&tile[lst[j]] = stg[S][j];
+        if (tid < NHALO) tile[lh] = sth[S];
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, DEPTH - 1>;
@@ -530,11 +537,11 @@ __global__ __launch_bounds__(64 * WPB, (BL_DEPTH == 1 ? (MT <= 2 ? 4 : 3) : (MT 
     };
     // lane group g takes k = 16 kb + 4 s + g at step s (the packed A operand's order): channel 4 s + g of the staged block,
     // tile rows wave .. wave + 2 = image rows y - 1, y, y + 1
-    const float* my = &tile[(g * BL_TR + wave) * BL_RS + 4 + 4 * li];
+    const float* my = &tile[(g * TR + wave) * BL_RS + 4 + 4 * li];
     auto compute = [&](const f32x4 (&A)[MT]) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const float* base = my + s * (4 * BL_TR * BL_RS);
+            const float* base = my + s * (4 * TR * BL_RS);
             const f32x4 c0 = *(const f32x4*)base, c1 = *(const f32x4*)(base + BL_RS), c2 = *(const f32x4*)(base + 2 * BL_RS);
             float col[NT + 2];
             col[0] = yl * base[-1] + yc * base[BL_RS - 1] + yr * base[2 * BL_RS - 1];
@@ -588,6 +595,13 @@ __global__ __launch_bounds__(64 * WPB, (BL_DEPTH == 1 ? (MT <= 2 ? 4 : 3) : (MT 
 //   dres(4 cb + e) = sum_q G(cb + q C/4, sub-pixel e)
 // sit in ONE lane (the same fixed order as unshuffle_bwd4_kernel: results are bit-identical to the two-kernel path), and
 // dpre2 = G * lrelu'(pre2) leaves as 8-byte stores (16 lanes = 128 contiguous bytes of one channel plane).
+#ifndef GNR_UNSHUF_NT
+#define GNR_UNSHUF_NT 0             // round-5 A/B: 1 = nontemporal stores of dpre2 / dres
+#endif
+__device__ __forceinline__ void ustore2(float* p, f32x2 v) {
+    if (GNR_UNSHUF_NT) __builtin_nontemporal_store(v, (f32x2*)p);
+    else *(f32x2*)p = v;
+}
 template <int MT, bool PERM>
 __global__ __launch_bounds__(64 * WPB, 2) void conv16_unshuffle_kernel(const Conv16Params cp) {
     constexpr int NT = 8;
@@ -688,13 +702,13 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv16_unshuffle_kernel(const Con
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     G[q][e] = f32x2{acc[mt][4 * (e >> 1) + (e & 1)][q], acc[mt][4 * (e >> 1) + 2 + (e & 1)][q]};
-                    *(f32x2*)(dst + (long)e * Plo) = f32x2{G[q][e].x * (((nib2 >> e) & 1u) ? 1.0f : LEAK16),
-                                                           G[q][e].y * (((nib2 >> (8 + e)) & 1u) ? 1.0f : LEAK16)};
+                    ustore2(dst + (long)e * Plo, f32x2{G[q][e].x * (((nib2 >> e) & 1u) ? 1.0f : LEAK16),
+                                                       G[q][e].y * (((nib2 >> (8 + e)) & 1u) ? 1.0f : LEAK16)});
                 }
             }
             float* dr = cp.dres + (long)b * cp.dres_batch + (long)(4 * cb) * Plo + pix;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) *(f32x2*)(dr + (long)e * Plo) = (G[0][e] + G[1][e]) + (G[2][e] + G[3][e]);
+            for (int e = 0; e < 4; ++e) ustore2(dr + (long)e * Plo, (G[0][e] + G[1][e]) + (G[2][e] + G[3][e]));
         }
     } else {
         // any channel count: rows in their natural order, dpre2 only -- the x.repeat adjoint's four terms of an output sit in
@@ -709,9 +723,9 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv16_unshuffle_kernel(const Con
                 float* dst = cp.C + (long)b * cp.c_batch + (long)(4 * c) * Plo + pix;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    *(f32x2*)(dst + (long)e * Plo) =
-                        f32x2{acc[mt][4 * (e >> 1) + (e & 1)][q] * (((nib2 >> e) & 1u) ? 1.0f : LEAK16),
-                              acc[mt][4 * (e >> 1) + 2 + (e & 1)][q] * (((nib2 >> (8 + e)) & 1u) ? 1.0f : LEAK16)};
+                    ustore2(dst + (long)e * Plo,
+                            f32x2{acc[mt][4 * (e >> 1) + (e & 1)][q] * (((nib2 >> e) & 1u) ? 1.0f : LEAK16),
+                                  acc[mt][4 * (e >> 1) + 2 + (e & 1)][q] * (((nib2 >> (8 + e)) & 1u) ? 1.0f : LEAK16)});
             }
     }
 }
@@ -1083,8 +1097,10 @@ int launch_conv16(const Conv16Params& cp, hipStream_t st) {
     if (cp.blur && !cp.shuffle && cp.plan.NT == 4 && cp.plan.slices == 1 && (cp.plan.MT == 2 || cp.plan.MT == 4) &&
         cp.W % 64 == 0 && cp.H % BL_ROWS == 0 && (long)cp.W * cp.H == cp.P && !g_forced_tile.load() &&
         items >= 512) {          // below two workgroups per CU its barriers are exposed (one 256 x 256 image: 30.7 us against 27.3)
-        if (cp.plan.MT == 2) hipLaunchKernelGGL((conv16_blur_lds_kernel<2>), dim3(blocks), dim3(64 * WPB), 0, st, cp);
-        else hipLaunchKernelGGL((conv16_blur_lds_kernel<4>), dim3(blocks), dim3(64 * WPB), 0, st, cp);
+        const long bitems = (long)cp.batch * (cp.H / BL_ROWS) * (cp.W / 64);
+        const unsigned bblocks = (unsigned)(8 * ((bitems + 7) / 8));
+        if (cp.plan.MT == 2) hipLaunchKernelGGL((conv16_blur_lds_kernel<2, BL_ROWS>), dim3(bblocks), dim3(64 * BL_ROWS), 0, st, cp);
+        else hipLaunchKernelGGL((conv16_blur_lds_kernel<4, BL_ROWS>), dim3(bblocks), dim3(64 * BL_ROWS), 0, st, cp);
         return 0;
     }
     const int key = cp.plan.MT * 10 + cp.plan.NT;

@@ -31,6 +31,7 @@ for draw in range(n):
         for who in ("null", "fp32", "bf16x3"):
             eps = tp.GRAD_EPS.get(who, tp.GRAD_EPS["fp32"])
             ratios.setdefault(k, {}).setdefault(who, []).append(max(e[who] - eps, 0.0) / max(e_ref, 1e-30))
+            ratios[k].setdefault("abs_" + who, []).append(e[who])
         ratios[k].setdefault("ref", []).append(e_ref)
 from gazenerf_amd import _lib
 print("build: %s" % _lib.build_info())
@@ -52,7 +53,8 @@ for who in ("null", "fp32", "bf16x3"):
     print("%-7s all (tensor, draw) ratios: median %.2f  p90 %.2f  p99 %.2f  max %.2f   share > 3: %.3f" % (
         who, q(0.5), q(0.9), q(0.99), allr[-1], sum(r > 3 for r in allr) / len(allr)))
 by_who = {who: {k: d[who] for k, d in ratios.items()} for who in ("null", "fp32", "bf16x3")}
-bad = tp.noise_gate_failures(by_who)
+by_abs = {who: {k: d["abs_" + who] for k, d in ratios.items()} for who in ("null", "fp32", "bf16x3")}
+bad = tp.noise_gate_failures(by_who, by_abs)
 print("gate (tests/test_parity_gpu.py NOISE_GATE = %s): %s" % (tp.NOISE_GATE, "PASS" if not bad else "FAIL"))
 for b in bad:
     print("  " + b)

@@ -837,16 +837,22 @@ N_NOISE_DRAWS = 16
 # its noise of zero and ONE flipped mask moves a whole layer pair's tensors by a factor of ~12 in that draw (observed once in
 # 8 draws).  Round 4 let that through with "max <= 20, 5 % of the ratios above 3", which would also pass a kernel that
 # occasionally drops a layer's contribution on one tensor.  Now, per tensor over 16 draws: AT MOST ONE draw above
-# `outlier` = 5 (or above 1.25 x the yardstick's own worst ratio on that tensor, where the yardstick itself exceeds 5), that one
-# draw bounded by `outlier_cap`, and every other draw below it.  profiles/r5_grad_noise_draws.txt is the distribution;
+# `outlier` = 5 (or above 1.25 x the yardstick's own worst ratio on that tensor, where the yardstick itself exceeds 5), and that one
+# draw bounded in ABSOLUTE terms: rel-L2 against fp64 <= `outlier_abs` = 1e-2, the reference's own fp32 noise on its noisiest
+# tensors (dR).  A ratio cap cannot do that job: the 16 draws contain one (draw 13, eyes stream) in which the reference's fp32 run
+# flips no mask at all -- its noise on eyes.FeaExt_module_0..4 is 1e-5 -- while the bf16x3 kernels flip ONE (3e-3 on those
+# tensors, ratio 90-215; tests/diagnostics/gpu_x3_outlier.py shows the single channel / single row it sits in,
+# profiles/r5_x3_outlier_draw13.txt).  A kernel that drops a layer's contribution on one tensor is off by O(1), not 3e-3.
+# profiles/r5_grad_noise_draws.txt is the distribution;
 # profiles/r5_grad_gate_dropped_term.txt shows the gate failing when ONE cross term (W_lo x a_hi) is dropped from ONE layer of
 # bwd3_chain_kernel (an experimental build, -DGNR_ABLATE=128: a diagnostic, not CI).
 NOISE_GATE = {"fp32": dict(median=1.25, max_floor=3.0, max_vs_null=1.25, share_above_3=0.02),
-              "bf16x3": dict(median=1.5, outlier=5.0, outlier_vs_null=1.25, outliers_allowed=1, outlier_cap=20.0)}
+              "bf16x3": dict(median=1.5, outlier=5.0, outlier_vs_null=1.25, outliers_allowed=1, outlier_abs=1e-2)}
 
 
-def noise_gate_failures(ratios, precisions=None):
-    """ratios[who][tensor] = [err_who / err_ref32 per draw], who in PRECISIONS + ["null"] -> list of violated gates."""
+def noise_gate_failures(ratios, errs, precisions=None):
+    """ratios[who][tensor] = [err_who / err_ref32 per draw], errs[who][tensor] = [err_who per draw] (rel-L2 against the fp64
+    oracle), who in PRECISIONS + ["null"] -> list of violated gates."""
     import statistics
     null_worst = max(max(rs) for rs in ratios["null"].values())
     bad = []
@@ -859,10 +865,11 @@ def noise_gate_failures(ratios, precisions=None):
                 bad.append(line + " -- median gate %.2f" % gate["median"])
             if "outlier" in gate:
                 thr = max(gate["outlier"], gate["outlier_vs_null"] * max(ratios["null"][k]))
-                above = sum(r > thr for r in rs)
-                if above > gate["outliers_allowed"] or mx > gate["outlier_cap"]:
-                    bad.append(line + " -- %d draw(s) above %.2f (allowed %d), cap %.1f" % (above, thr, gate["outliers_allowed"],
-                                                                                             gate["outlier_cap"]))
+                above = [i for i, r in enumerate(rs) if r > thr]
+                worst_abs = max([errs[pr][k][i] for i in above], default=0.0)
+                if len(above) > gate["outliers_allowed"] or worst_abs > gate["outlier_abs"]:
+                    bad.append(line + " -- %d draw(s) above %.2f (allowed %d), their worst rel-L2 %.2e (allowed %.0e)" % (
+                        len(above), thr, gate["outliers_allowed"], worst_abs, gate["outlier_abs"]))
             else:
                 max_gate = max(gate["max_floor"], gate["max_vs_null"] * null_worst)
                 if mx > max_gate:
@@ -876,14 +883,17 @@ def noise_gate_failures(ratios, precisions=None):
 
 
 def noise_ratios(n_draws, dev):
+    """-> (ratios, errs): per arithmetic and tensor the list over the draws of err / err_ref32 and of err itself."""
     ratios = {pr: {} for pr in PRECISIONS + ["null"]}
+    errs = {pr: {} for pr in PRECISIONS + ["null"]}
     for draw in range(n_draws):
         for k, (e_ref, e_hip) in _noise_errors(False, draw, PRECISIONS, dev, with_null=True).items():
             for pr in ratios:
                 # eps: the floor where the reference's own noise is ~1e-6 (the layers above the last ReLU mask)
                 eps = GRAD_EPS.get(pr, GRAD_EPS["fp32"])
                 ratios[pr].setdefault(k, []).append(max(e_hip[pr] - eps, 0.0) / max(e_ref, 1e-30))
-    return ratios
+                errs[pr].setdefault(k, []).append(e_hip[pr])
+    return ratios, errs
 
 
 def test_backward_error_follows_the_reference_fp32_noise_distribution():
@@ -898,8 +908,8 @@ def test_backward_error_follows_the_reference_fp32_noise_distribution():
       * the tail against a yardstick that involves no HIP code: the reference's own fp32 autograd on a channel-permuted
         copy of the network (same function, other summation order = its own second draw).  fp32 kernels: per-tensor max
         <= 1.25 x the yardstick's worst ratio (floor 3) and at most 2 % of all (tensor, draw) ratios above 3; bf16x3: per
-        tensor at most one draw above 5 (see NOISE_GATE)."""
-    bad = noise_gate_failures(noise_ratios(N_NOISE_DRAWS, _dev()))
+        tensor at most one draw above 5, and that one within 1e-2 rel-L2 of fp64 (see NOISE_GATE)."""
+    bad = noise_gate_failures(*noise_ratios(N_NOISE_DRAWS, _dev()))
     assert not bad, bad
 
 

@@ -18,6 +18,9 @@
 #   ws8              bench.py --gpus 8 on one GPU over gloo (cfg4 + strong)       -> bench_ws8_*.json
 #   noise            tests/diagnostics/grad_noise_draws.py                        -> grad_noise_draws.txt
 #   dropterm         the bf16x3 gate on a build with one cross term dropped       -> grad_gate_dropped_term.txt
+#   x3outlier        anatomy of the gate's outlier draw (bf16x3 vs fp32 kernels)  -> x3_outlier_draw13.txt
+#   abn1:<tag>:<flags>  rebuild gnr_conv16.hip + gnr_upsample.hip with extra -D flags (experimental build), N1 B = 7 trace,
+#                    restore the product build                                    -> ab_<tag>_launches.txt
 #   x3energy         J per step of the bf16x3 leg (tools/smi_sample.py)           -> x3_energy.txt
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -80,6 +83,14 @@ for STEP in "$@"; do
       python -m gazenerf_amd.build > $O/dropterm_rebuild.log 2>&1          # back to the product build
       python -c "from gazenerf_amd import _lib; print('restored:', _lib.build_info())"
       grep -c "FAIL\|  bf16x3" $O/grad_gate_dropped_term.txt; grep "^gate" $O/grad_gate_dropped_term.txt | cut -c1-60;;
+    abn1:*)
+      T=${STEP#abn1:}; TAG=${T%%:*}; FL=${T#*:}
+      GNR_EXTRA_FILES="gnr_conv16.hip,gnr_upsample.hip" GNR_EXTRA_HIPCC_FLAGS="$FL" python -m gazenerf_amd.build --no-torch-ext > $O/ab_$TAG.build.log 2>&1
+      GNR_ALLOW_EXPERIMENTAL_LIB=1 bash tools/n1_trace.sh $NAME/ab_$TAG --batch 7 --iters 5 > /dev/null 2>&1
+      { echo "# $FL"; grep "N1 B" $O/ab_$TAG/wall.log; grep -v "torch:" $O/ab_$TAG/launches.txt; } > $O/ab_${TAG}_launches.txt; rm -rf $O/ab_$TAG/prof
+      python -m gazenerf_amd.build --no-torch-ext > $O/ab_restore.log 2>&1
+      grep -E "N1 B|kernel time|blur_lds|unshuffle_kernel" $O/ab_${TAG}_launches.txt;;
+    x3outlier) timeout 600 python tests/diagnostics/gpu_x3_outlier.py 13 > $O/x3_outlier_draw13.txt 2> $O/x3_outlier.err; cut -c1-230 $O/x3_outlier_draw13.txt | tail -22;;
     x3energy) timeout 900 python tools/x3_energy.py > $O/x3_energy.txt 2> $O/x3_energy.err; tail -12 $O/x3_energy.txt;;
     *) echo "unknown step $STEP";;
   esac
