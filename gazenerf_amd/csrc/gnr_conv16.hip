@@ -438,10 +438,8 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv16_kernel(const Conv16Params 
 // stays on the epilogue), W % 64 == 0, H % 4 == 0; everything else keeps the register-fed kernel.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int BL_RS = 72;           // floats per LDS row (halo 3 | 64 pixels 4..67 | halo 68)
-#ifndef GNR_BLUR_ROWS
-#define GNR_BLUR_ROWS 4             // round-5 A/B: image rows per workgroup tile = waves per workgroup (4 or 8)
-#endif
-constexpr int BL_ROWS = GNR_BLUR_ROWS;
+constexpr int BL_ROWS = 4;          // image rows per workgroup tile = waves per workgroup.  8 (halo 1.25 x instead of 1.5 x, 46 KB of LDS, two
+                                    // workgroups per CU) was measured in round 5: 246 / 183 us against 240 / 137 (profiles/r5_n1_experiments.txt)
 constexpr int BL_DEPTH = 1;         // k-blocks of global loads in flight per thread (staging register sets).  2 was measured: 148 / 202
                                     // VGPRs, three / two waves per SIMD, 255 / 156 us against 238 / 139 -- occupancy beats prefetch depth here
 template <int MT, int ROWS>
@@ -595,13 +593,8 @@ __global__ __launch_bounds__(64 * ROWS, (ROWS == 4 ? (MT <= 2 ? 4 : 3) : (MT <= 
 //   dres(4 cb + e) = sum_q G(cb + q C/4, sub-pixel e)
 // sit in ONE lane (the same fixed order as unshuffle_bwd4_kernel: results are bit-identical to the two-kernel path), and
 // dpre2 = G * lrelu'(pre2) leaves as 8-byte stores (16 lanes = 128 contiguous bytes of one channel plane).
-#ifndef GNR_UNSHUF_NT
-#define GNR_UNSHUF_NT 0             // round-5 A/B: 1 = nontemporal stores of dpre2 / dres
-#endif
-__device__ __forceinline__ void ustore2(float* p, f32x2 v) {
-    if (GNR_UNSHUF_NT) __builtin_nontemporal_store(v, (f32x2*)p);
-    else *(f32x2*)p = v;
-}
+// (nontemporal stores of dpre2 / dres were measured in round 5: 213 us against 193 at the 64-channel level -- profiles/r5_n1_experiments.txt)
+__device__ __forceinline__ void ustore2(float* p, f32x2 v) { *(f32x2*)p = v; }
 template <int MT, bool PERM>
 __global__ __launch_bounds__(64 * WPB, 2) void conv16_unshuffle_kernel(const Conv16Params cp) {
     constexpr int NT = 8;

@@ -40,6 +40,7 @@ void launch_wgrad_img(const float* A, int lda, int n_valid, const float* B, int 
                       hipStream_t stream, WgradDefer* defer);
 
 constexpr float LEAK = 0.2f;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int UP_MAX = GNR_UPSAMPLE_MAX_BLOCKS;
 
 // ---------------------------------------------------------------------------------------------
@@ -161,32 +162,55 @@ __global__ __launch_bounds__(256) void bilinear_blur_kernel(const float* __restr
     *(f32x4*)(out + plane * ((long)H2 * W2) + (long)y * W2 + x) = yl * rows[0] + yc * rows[1] + yr * rows[2];
 }
 
-__global__ __launch_bounds__(256) void bilinear2x_adj_kernel(const float* __restrict__ dout, float* __restrict__ din,
-                                                             long planes, int H, int W) {
+// Adjoint of rgb_upsample = Blur o bilinear x2 in ONE pass (round 5; until then blur_kernel(adjoint) wrote the blurred
+// 2H x 2W gradient and bilinear2x_adj_kernel gathered 16 of its values per output):
+//   din(y, x) = sum_{a,c} wy[a] wx[c] Bt(2y - 1 + a, 2x - 1 + c),   Bt = blur^T(dout)
+// A thread owns one low-resolution pixel: the 6 x 6 patch rows 2y-2 .. 2y+3, columns 2x-2 .. 2x+3 of dout (three 8-byte loads
+// per row in the interior), the stencil's row pass on it (6 rows x 4 columns), then its column pass on the 4 x 4 values the
+// bilinear adjoint combines -- blur_kernel's expressions (rows first), then the 4 x 4 gather of round 1-4's bilinear2x_adj_kernel; taps that fall outside
+// the image carry weight 0 in both, so clamped patch elements stand in for them.
+__global__ __launch_bounds__(256) void blur_bilinear_adj_kernel(const float* __restrict__ dout, float* __restrict__ din,
+                                                                long planes, int H, int W) {
     const int H2 = 2 * H, W2 = 2 * W;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= planes * H * W) return;
     const int x = (int)(idx % W), y = (int)((idx / W) % H);
     const float* p = dout + (idx / ((long)H * W)) * ((long)H2 * W2);
-    auto taps = [](int m, int n, int (&o)[4], float (&w)[4]) {
-        o[0] = 2 * m - 1; w[0] = m >= 1 ? 0.25f : 0.0f;                 // odd output of m-1 reads in[m]
-        o[1] = 2 * m;     w[1] = m >= 1 ? 0.75f : 1.0f;
-        o[2] = 2 * m + 1; w[2] = m + 1 < n ? 0.75f : 1.0f;
-        o[3] = 2 * m + 2; w[3] = m + 1 < n ? 0.25f : 0.0f;              // even output of m+1 reads in[m]
-        if (o[0] < 0) o[0] = 0;
-        if (o[3] > 2 * n - 1) o[3] = 2 * n - 1;
-    };
-    int ox[4], oy[4];
+    auto clampi = [](int v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); };
+    // bilinear adjoint taps: outputs 2m-1 .. 2m+2 read in[m] (see the forward rule above bilinear_blur_kernel)
     float wx[4], wy[4];
-    taps(x, W, ox, wx);
-    taps(y, H, oy, wy);
+    wx[0] = x >= 1 ? 0.25f : 0.0f; wx[1] = x >= 1 ? 0.75f : 1.0f; wx[2] = x + 1 < W ? 0.75f : 1.0f; wx[3] = x + 1 < W ? 0.25f : 0.0f;
+    wy[0] = y >= 1 ? 0.25f : 0.0f; wy[1] = y >= 1 ? 0.75f : 1.0f; wy[2] = y + 1 < H ? 0.75f : 1.0f; wy[3] = y + 1 < H ? 0.25f : 0.0f;
+    // blur adjoint taps of the four columns X = 2x-1+c and the four rows Y = 2y-1+a (clamped where the bilinear weight is 0)
+    float bxl[4], bxc[4], bxr[4], byl[4], byc[4], byr[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        blur_taps(clampi(2 * x - 1 + c, W2), W2, true, bxl[c], bxc[c], bxr[c]);
+        blur_taps(clampi(2 * y - 1 + c, H2), H2, true, byl[c], byc[c], byr[c]);
+    }
+    const bool interior = x >= 1 && x + 1 < W;
+    float xb[6][4];                                              // row pass: patch row j, column X = 2x-1+c
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const float* r = p + (long)clampi(2 * y - 2 + j, H2) * W2;
+        float v[6];
+        if (interior) {
+            const f32x2 a = *(const f32x2*)(r + 2 * x - 2), b = *(const f32x2*)(r + 2 * x), c = *(const f32x2*)(r + 2 * x + 2);
+            v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) v[k] = r[clampi(2 * x - 2 + k, W2)];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xb[j][c] = bxl[c] * v[c] + bxc[c] * v[c + 1] + bxr[c] * v[c + 2];
+    }
     float acc = 0.0f;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        float r = 0.0f;
+        float rsum = 0.0f;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) r += wx[c] * p[(long)oy[a] * W2 + ox[c]];
-        acc += wy[a] * r;
+        for (int c = 0; c < 4; ++c) rsum += wx[c] * (byl[a] * xb[a][c] + byc[a] * xb[a + 1][c] + byr[a] * xb[a + 2][c]);
+        acc += wy[a] * rsum;
     }
     din[idx] = acc;
 }
@@ -246,7 +270,7 @@ __global__ __launch_bounds__(256) void rgb_conv_kernel(const float* __restrict__
 // A thread owns RGBF_IT pixel quads (their d(rgb) stays in registers) and walks the channels: per channel one b128 load of
 // the activation (+ one of dnet when accumulating), one b128 store, and three partial dots that are reduced over the wave
 // once per channel; a workgroup's four wave sums meet in LDS and leave as ONE partial per (channel, output):
-// part[(c * nwg + wg) * 3 + o]; rgb_wsum_kernel adds the workgroups' partials in a fixed order (deterministic).
+// part[(c * nwg + wg) * 3 + o]; rgb_wsum_batch_kernel adds the workgroups' partials in a fixed order (deterministic).
 // Grid (pixel groups, channel groups): at the low resolutions (4096 pixels x 258 channels) the pixels alone are a handful
 // of workgroups, so the channel range is split too (blockIdx.y; the bias pseudo-channel rides with the last group).
 constexpr int RGBF_IT = 4;
@@ -553,19 +577,32 @@ __global__ __launch_bounds__(256) void rgb_bwd_blur_kernel(const float* __restri
     }
 }
 
-// one wave per (channel, output): lane l adds the partials l, l + 64, ... in order, then the 64 lane sums are added in a
-// fixed tree
-__global__ __launch_bounds__(64) void rgb_wsum_kernel(const float* __restrict__ part, int C, int nwg, float* __restrict__ dw,
-                                                      float* __restrict__ db) {
-    const int i = blockIdx.x, lane = threadIdx.x;                 // (c, o)
+// rgb_wsum_batch_kernel: one wave per (level, channel, output): lane l adds the partials l, l + 64, ... in order, then the
+// 64 lane sums are added in a fixed tree.
+// Round 5: the (up to) n_blocks + 1 reductions of a backward as ONE launch at its end (each was a 5-9 us launch of mostly
+// latency right behind its producer, on the stream's critical path): every level keeps its partials in its own slice of the
+// scratch; per (level, channel, output) the same wave, the same order of additions -- the same bits as the per-level launches of rounds 2-4.
+struct RgbWsumBatch {
+    int n;
+    unsigned first[UP_MAX + 2];          // job j owns blocks first[j] .. first[j + 1] - 1
+    const float* part[UP_MAX + 1];
+    int C[UP_MAX + 1], nwg[UP_MAX + 1];
+    float* dw[UP_MAX + 1]; float* db[UP_MAX + 1];
+};
+__global__ __launch_bounds__(64) void rgb_wsum_batch_kernel(const RgbWsumBatch rb) {
+    int j = 0;
+    while (j + 1 < rb.n && blockIdx.x >= rb.first[j + 1]) ++j;
+    const int i = (int)(blockIdx.x - rb.first[j]), lane = threadIdx.x;
+    const int C = rb.C[j], nwg = rb.nwg[j];
+    const float* part = rb.part[j];
     const int c = i / 3, o = i - 3 * c;
     float a = 0.0f;
     for (int sp = lane; sp < nwg; sp += 64) a += part[((long)c * nwg + sp) * 3 + o];
 #pragma unroll
     for (int sft = 32; sft > 0; sft >>= 1) a += __shfl_xor(a, sft);
     if (lane == 0) {
-        if (c < C) { if (dw) dw[o * C + c] = a; }
-        else if (db) db[o] = a;
+        if (c < C) { if (rb.dw[j]) rb.dw[j][o * C + c] = a; }
+        else if (rb.db[j]) rb.db[j][o] = a;
     }
 }
 
@@ -828,20 +865,26 @@ struct UpScratch {                      // backward temporaries
     float* g2;                          // same size: d(net) alternates between g2 and g1, so the
                                         // saved forward state stays intact and a second backward (retain_graph) is valid
     float* drgb_a; float* drgb_b;       // [B][3][Pn]
-    float* colsum;                      // [B][max M]
+    float* colsum;                      // the RGB-branch backward's partial sums, level i at colsum + colsum_off[i]
+    size_t colsum_off[UP_MAX + 1];
     float* wg;                          // partial tiles of every weight-gradient GEMM of the call (gnr_wgrad.h)
 };
+
+static size_t up_colsum_floats(const UpDims& d, int batch, int level) {
+    const size_t px = (size_t)batch * d.side[level] * d.side[level];
+    size_t wgs = (size_t)rgbf_workgroups((long)px);
+    if (px / (RB_TH * RB_TW) > wgs) wgs = px / (RB_TH * RB_TW);       // rgb_bwd_blur_kernel: one workgroup per 16 x 64 tile
+    return (((size_t)(d.ch[level] + 1) * wgs * 3) + 63) & ~(size_t)63;
+}
 
 static size_t up_carve_bwd(const GnrUpsampleProblem* p, const UpDims& d, char* base, UpScratch* s) {
     size_t off = 0;
     auto take = [&](size_t bytes) { char* q = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return q; };
     size_t big = 0;
     const size_t B = (size_t)p->batch;
-    int mmax = 0;
     for (int i = 0; i < d.n_blocks; ++i) {
         const size_t C = d.ch[i], P = (size_t)d.side[i] * d.side[i];
         if (B * 4 * C * P * 4 > big) big = B * 4 * C * P * 4;       // dpre2 == du size
-        if (4 * d.ch[i] > mmax) mmax = 4 * d.ch[i];
     }
     const size_t Pn = (size_t)d.side[d.n_blocks] * d.side[d.n_blocks];
     UpScratch z{};
@@ -850,13 +893,10 @@ static size_t up_carve_bwd(const GnrUpsampleProblem* p, const UpDims& d, char* b
     z.g2 = (float*)take(big);        // d(net) of block i+1 becomes block i's X (dhid, du, dpre1: up to 4 C P floats)
     z.drgb_a = (float*)take(B * 3 * Pn * 4);
     z.drgb_b = (float*)take(B * 3 * Pn * 4);
-    size_t cs_floats = B * (size_t)(mmax + 128);
-    for (int i = 0; i <= d.n_blocks; ++i) {           // rgb_bwd_fused_kernel's partials: (channels + 1) x workgroups x 3
-        const size_t px = B * (size_t)d.side[i] * d.side[i];
-        size_t wgs = (size_t)rgbf_workgroups((long)px);
-        if (px / (RB_TH * RB_TW) > wgs) wgs = px / (RB_TH * RB_TW);       // rgb_bwd_blur_kernel: one workgroup per 16 x 64 tile
-        const size_t need = (size_t)(d.ch[i] + 1) * wgs * 3;
-        if (cs_floats < need) cs_floats = need;
+    size_t cs_floats = 0;
+    for (int i = 0; i <= d.n_blocks; ++i) {           // the RGB-branch backward's partials, one slice per level: (channels + 1) x workgroups x 3
+        z.colsum_off[i] = cs_floats;
+        cs_floats += up_colsum_floats(d, p->batch, i);
     }
     z.colsum = (float*)take(cs_floats * 4);
     z.wg = (float*)take(wgrad_arena_floats() * 4);
@@ -1032,6 +1072,13 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
     jobs.dst = s.pack;
     launch_conv16_pack(jobs, st);                 // every transposed weight matrix of the call, one launch
 
+    // the RGB branch's weight-gradient partials of every level are reduced by ONE launch at the end of the call
+    RgbWsumBatch wsum{};
+    auto wsum_push = [&](const float* part, int C, int nwg, float* dwp, float* dbp) {
+        const int j = wsum.n++;
+        wsum.part[j] = part; wsum.C[j] = C; wsum.nwg[j] = nwg; wsum.dw[j] = dwp; wsum.db[j] = dbp;
+        wsum.first[j + 1] = wsum.first[j] + 3u * (unsigned)(C + 1);
+    };
     // the split-K reductions of the nine weight-gradient GEMMs are queued and run as ONE launch at the end of the call
     WgradDefer wd;
     wgrad_defer_init(&wd, t.wg, wgrad_arena_floats());
@@ -1048,10 +1095,9 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
         // the RGB branch at this resolution: rgb_i = up(rgb_{i-1}) + conv(net') ...; undo the up() that FOLLOWED block i
         if (i < nb - 1) {
             // drgb currently is at side 4S (block i+1's resolution): adjoint of blur o bilinear
-            hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * 3 * 4 * P)), dim3(256), 0, st, drgb, drgb_tmp, (long)B * 3, 4 * S,
-                               4 * S, 1);
-            hipLaunchKernelGGL(bilinear2x_adj_kernel, dim3(blocks_for((long)B * 3 * P4)), dim3(256), 0, st, drgb_tmp, drgb, (long)B * 3,
+            hipLaunchKernelGGL(blur_bilinear_adj_kernel, dim3(blocks_for((long)B * 3 * P4)), dim3(256), 0, st, drgb, drgb_tmp, (long)B * 3,
                                2 * S, 2 * S);
+            float* sw = drgb; drgb = drgb_tmp; drgb_tmp = sw;
         }
         // conv_rgb(i+1): weight / bias gradients and dhid = (dnet' + Wr^T drgb) * lrelu'(net'), one pass over net'
         float* X = dnet_next ? dnet_next : t.g0;       // dhid, later du, later dpre1
@@ -1064,15 +1110,13 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
                 const size_t lds = ((size_t)((12 * (Cn + 1) + 3) & ~3) + 2 * RB_TILE) * sizeof(float);
                 hipLaunchKernelGGL(rgb_bwd_blur_kernel, dim3(nwg, rgbf_channel_groups(nwg, Cn)), dim3(256), lds, st, drgb, s.net[i], Cn,
                                    2 * S, 2 * S, B, w->rgb_w[i + 1], dnet_next ? X : (const float*)nullptr, Y,
-                                   want_w ? t.colsum : (float*)nullptr);
-                if (want_w)
-                    hipLaunchKernelGGL(rgb_wsum_kernel, dim3(3 * (Cn + 1)), dim3(64), 0, st, t.colsum, Cn, (int)nwg, G.rgb_w[i + 1], G.rgb_b[i + 1]);
+                                   want_w ? t.colsum + t.colsum_off[i + 1] : (float*)nullptr);
+                if (want_w) wsum_push(t.colsum + t.colsum_off[i + 1], Cn, (int)nwg, G.rgb_w[i + 1], G.rgb_b[i + 1]);
             } else {
                 const unsigned nwg = (unsigned)rgbf_workgroups((long)B * P4);
                 hipLaunchKernelGGL(rgb_bwd_fused_kernel, dim3(nwg, rgbf_channel_groups(nwg, Cn)), dim3(256), (size_t)12 * (Cn + 1) * sizeof(float), st, drgb, s.net[i], Cn,
-                                   P4, B, w->rgb_w[i + 1], X, dnet_next ? 1 : 0, 1, want_w ? t.colsum : (float*)nullptr);
-                if (want_w)
-                    hipLaunchKernelGGL(rgb_wsum_kernel, dim3(3 * (Cn + 1)), dim3(64), 0, st, t.colsum, Cn, (int)nwg, G.rgb_w[i + 1], G.rgb_b[i + 1]);
+                                   P4, B, w->rgb_w[i + 1], X, dnet_next ? 1 : 0, 1, want_w ? t.colsum + t.colsum_off[i + 1] : (float*)nullptr);
+                if (want_w) wsum_push(t.colsum + t.colsum_off[i + 1], Cn, (int)nwg, G.rgb_w[i + 1], G.rgb_b[i + 1]);
                 // g = blur^T dhid
                 hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * Cn * P)), dim3(256), 0, st, X, Y, (long)B * Cn, 2 * S, 2 * S, 1);
             }
@@ -1122,17 +1166,17 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
     {
         const int S = d.side[0];
         const long P = (long)S * S;
-        hipLaunchKernelGGL(blur_kernel, dim3(blocks_for((long)B * 3 * P)), dim3(256), 0, st, drgb, drgb_tmp, (long)B * 3, 2 * S, 2 * S, 1);
-        hipLaunchKernelGGL(bilinear2x_adj_kernel, dim3(blocks_for((long)B * 3 * P)), dim3(256), 0, st, drgb_tmp, drgb, (long)B * 3, S, S);
+        hipLaunchKernelGGL(blur_bilinear_adj_kernel, dim3(blocks_for((long)B * 3 * P)), dim3(256), 0, st, drgb, drgb_tmp, (long)B * 3, S, S);
+        drgb = drgb_tmp;
         const bool want_w = G.rgb_w[0] || G.rgb_b[0];
         if (want_w || d_x) {
             const unsigned nwg = (unsigned)rgbf_workgroups((long)B * P);
             hipLaunchKernelGGL(rgb_bwd_fused_kernel, dim3(nwg, rgbf_channel_groups(nwg, d.ch[0])), dim3(256), (size_t)12 * (d.ch[0] + 1) * sizeof(float), st, drgb, p->x,
-                               d.ch[0], P, B, w->rgb_w[0], d_x ? dnet_next : (float*)nullptr, 1, 0, want_w ? t.colsum : (float*)nullptr);
-            if (want_w)
-                hipLaunchKernelGGL(rgb_wsum_kernel, dim3(3 * (d.ch[0] + 1)), dim3(64), 0, st, t.colsum, d.ch[0], (int)nwg, G.rgb_w[0], G.rgb_b[0]);
+                               d.ch[0], P, B, w->rgb_w[0], d_x ? dnet_next : (float*)nullptr, 1, 0, want_w ? t.colsum + t.colsum_off[0] : (float*)nullptr);
+            if (want_w) wsum_push(t.colsum + t.colsum_off[0], d.ch[0], (int)nwg, G.rgb_w[0], G.rgb_b[0]);
         }
     }
+    if (wsum.n) hipLaunchKernelGGL(rgb_wsum_batch_kernel, dim3(wsum.first[wsum.n]), dim3(64), 0, st, wsum);
     wgrad_defer_flush(&wd, st);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("gnr_upsample_bwd: launch failed: %s", hipGetErrorString(e));
