@@ -52,7 +52,7 @@ namespace {
 
 #ifndef GNR_C16_ABL
 #define GNR_C16_ABL 0       // timing experiments (wrong results; tools/ab_n1.sh): 1 no epilogue, 2 B rows of k-block 0 only, 4 A of k-block 0
-                            // only, 32 epilogue without its loads, 64 epilogue without its stores, 128 stores folded into a 1 MiB window (L2-resident)
+                            // only, 8 (blur_lds) no stencil / MFMAs, 32 epilogue without its loads, 64 epilogue without its stores, 128 stores folded into a 1 MiB window (L2-resident)
 #endif
 constexpr int WPB = 4;       // waves per workgroup: they share a row slice (the A stream hits in L1) and take adjacent pixels
 constexpr float LEAK16 = 0.2f;
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(64 * ROWS, (ROWS == 4 ? (MT <= 2 ? 4 : 3) : (MT <= 
     float sth[DEPTH];
     auto load_stage = [&](auto set, int kb) {          // rows >= K: beyond the descriptor's bound -- zeros, no request
         constexpr int S = decltype(set)::value;
-        const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)kb * 16u * rowB));
+        const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((GNR_C16_ABL & 2) ? 0 : kb) * 16u * rowB));
 #pragma unroll
         for (int j = 0; j < NJ; ++j) stg[S][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, vst[j], (int)sb, 0));
         sth[S] = load1(rsB, vh, sb);
@@ -537,6 +537,7 @@ __global__ __launch_bounds__(64 * ROWS, (ROWS == 4 ? (MT <= 2 ? 4 : 3) : (MT <= 
     // tile rows wave .. wave + 2 = image rows y - 1, y, y + 1
     const float* my = &tile[(g * TR + wave) * BL_RS + 4 + 4 * li];
     auto compute = [&](const f32x4 (&A)[MT]) {
+        if ((GNR_C16_ABL & 8) && cp.K != -12345) return;          // timing experiment: no stencil, no MFMAs
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const float* base = my + s * (4 * TR * BL_RS);
@@ -594,7 +595,10 @@ __global__ __launch_bounds__(64 * ROWS, (ROWS == 4 ? (MT <= 2 ? 4 : 3) : (MT <= 
 // sit in ONE lane (the same fixed order as unshuffle_bwd4_kernel: results are bit-identical to the two-kernel path), and
 // dpre2 = G * lrelu'(pre2) leaves as 8-byte stores (16 lanes = 128 contiguous bytes of one channel plane).
 // (nontemporal stores of dpre2 / dres were measured in round 5: 213 us against 193 at the 64-channel level -- profiles/r5_n1_experiments.txt)
-__device__ __forceinline__ void ustore2(float* p, f32x2 v) { *(f32x2*)p = v; }
+__device__ __forceinline__ void ustore2(float* p, f32x2 v) {
+    if ((GNR_C16_ABL & 64) && v.x != 1.2345f) return;             // timing experiment: no stores
+    *(f32x2*)p = v;
+}
 template <int MT, bool PERM>
 __global__ __launch_bounds__(64 * WPB, 2) void conv16_unshuffle_kernel(const Conv16Params cp) {
     constexpr int NT = 8;
