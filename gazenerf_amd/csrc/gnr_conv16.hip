@@ -509,8 +509,11 @@ __global__ __launch_bounds__(64 * ROWS, (ROWS == 4 ? (MT <= 2 ? 4 : 3) : (MT <= 
         constexpr int S = decltype(set)::value;
         const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((GNR_C16_ABL & 2) ? 0 : kb) * 16u * rowB));
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) stg[S][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, vst[j], (int)sb, 0));
-        sth[S] = load1(rsB, vh, sb);
+        for (int j = 0; j < NJ; ++j)
+            stg[S][j] = ((GNR_C16_ABL & 256) && j >= NJ / 2) ? f32x4{0.0f, 0.0f, 0.0f, 0.0f}       // 256: timing experiment, half of the row pieces
+                                                             : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, vst[j], (int)sb, 0));
+        if (!(GNR_C16_ABL & 16)) sth[S] = load1(rsB, vh, sb);       // 16: timing experiment, no halo-column loads
+        else sth[S] = 0.0f;
     };
     auto store_stage = [&](auto set) {
         constexpr int S = decltype(set)::value;
@@ -600,7 +603,7 @@ __device__ __forceinline__ void ustore2(float* p, f32x2 v) {
     *(f32x2*)p = v;
 }
 template <int MT, bool PERM>
-__global__ __launch_bounds__(64 * WPB, 2) void conv16_unshuffle_kernel(const Conv16Params cp) {
+__global__ __launch_bounds__(64 * WPB, MT == 1 ? 4 : 2) void conv16_unshuffle_kernel(const Conv16Params cp) {
     constexpr int NT = 8;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -933,7 +936,7 @@ struct Variant { int MT, NT; bool blur; };
 // (round 4: half-width 2x2 / 4x2 instances were measured for the single-image forward and removed again -- a B = 1 GEMM is not
 // short of waves, profiles/r4_n1_small_tiles.txt)
 const Variant kVariants[] = {{2, 4, true}, {4, 4, true}, {8, 4, false}, {9, 2, true}, {11, 2, false}, {13, 2, false}};
-constexpr int kUnshuffleMT[] = {2, 3, 4};
+constexpr int kUnshuffleMT[] = {2, 3, 4, 1};      // (1: round-5 experiment, pinned only -- never the heuristic's choice: see conv16_plan_unshuffle)
 
 template <int MT, int NT>
 void launch_variant(const Conv16Params& cp, unsigned blocks, hipStream_t st) {
@@ -972,6 +975,7 @@ Conv16Plan conv16_plan_unshuffle(int M, int K, int side) {
         // fewest padded row tiles, then the smallest tile (64 channels at 256 x 256, 7 images: 2 x (2,8) 190 us, 1 x (4,8) 210 us)
         int best_pad = 1 << 30;
         for (int v : kUnshuffleMT) {
+            if (v == 1) continue;
             const int sl = (tiles + v - 1) / v, pad = sl * v - tiles;
             if (pad < best_pad) { best_pad = pad; mt = v; }
         }
@@ -1077,6 +1081,8 @@ int launch_conv16(const Conv16Params& cp, hipStream_t st) {
         const int key = 2 * cp.plan.MT + (cp.dres ? 1 : 0);       // dres given: rows packed with perm4 (M % 4 == 0)
         if (cp.dres && cp.M % 4) return fail("conv16: the un-shuffle epilogue with dres needs M %% 4 == 0 (M = %d)", cp.M);
         switch (key) {
+            case 3: hipLaunchKernelGGL((conv16_unshuffle_kernel<1, true>), dim3(wblocks), dim3(64 * WPB), 0, st, cp); break;
+            case 2: hipLaunchKernelGGL((conv16_unshuffle_kernel<1, false>), dim3(wblocks), dim3(64 * WPB), 0, st, cp); break;
             case 5: hipLaunchKernelGGL((conv16_unshuffle_kernel<2, true>), dim3(wblocks), dim3(64 * WPB), 0, st, cp); break;
             case 7: hipLaunchKernelGGL((conv16_unshuffle_kernel<3, true>), dim3(wblocks), dim3(64 * WPB), 0, st, cp); break;
             case 9: hipLaunchKernelGGL((conv16_unshuffle_kernel<4, true>), dim3(wblocks), dim3(64 * WPB), 0, st, cp); break;

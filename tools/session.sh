@@ -21,6 +21,7 @@
 #   x3outlier        anatomy of the gate's outlier draw (bf16x3 vs fp32 kernels)  -> x3_outlier_draw13.txt
 #   abn1:<tag>:<flags>  rebuild gnr_conv16.hip + gnr_upsample.hip with extra -D flags (experimental build), N1 B = 7 trace,
 #                    restore the product build                                    -> ab_<tag>_launches.txt
+#   n1tile:<mt,nt>   N1 B = 7 trace with a GEMM instance pinned (gnr_set_conv16_tile)   -> tile_<mt>x<nt>_launches.txt
 #   x3energy         J per step of the bf16x3 leg (tools/smi_sample.py)           -> x3_energy.txt
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -90,6 +91,11 @@ for STEP in "$@"; do
       { echo "# $FL"; grep "N1 B" $O/ab_$TAG/wall.log; grep -v "torch:" $O/ab_$TAG/launches.txt; } > $O/ab_${TAG}_launches.txt; rm -rf $O/ab_$TAG/prof
       python -m gazenerf_amd.build --no-torch-ext > $O/ab_restore.log 2>&1
       grep -E "N1 B|kernel time|blur_lds|unshuffle_kernel" $O/ab_${TAG}_launches.txt;;
+    n1tile:*)
+      TL=${STEP#n1tile:}
+      N1_CONV16_TILE=$TL bash tools/n1_trace.sh $NAME/tile_${TL/,/x} --batch 7 --iters 5 > /dev/null 2>&1
+      { echo "# N1_CONV16_TILE=$TL (gnr_set_conv16_tile)"; grep "N1 B" $O/tile_${TL/,/x}/wall.log; grep -v "torch:" $O/tile_${TL/,/x}/launches.txt; } > $O/tile_${TL/,/x}_launches.txt; rm -rf $O/tile_${TL/,/x}/prof
+      grep -E "N1 B|kernel time|unshuffle" $O/tile_${TL/,/x}_launches.txt;;
     x3outlier) timeout 600 python tests/diagnostics/gpu_x3_outlier.py 13 > $O/x3_outlier_draw13.txt 2> $O/x3_outlier.err; cut -c1-230 $O/x3_outlier_draw13.txt | tail -22;;
     x3energy) timeout 900 python tools/x3_energy.py > $O/x3_energy.txt 2> $O/x3_energy.err; tail -12 $O/x3_energy.txt;;
     *) echo "unknown step $STEP";;
