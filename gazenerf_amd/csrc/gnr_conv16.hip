@@ -585,6 +585,7 @@ __global__ __launch_bounds__(64 * ROWS, (ROWS == 4 ? (MT <= 2 ? 4 : 3) : (MT <= 
     }
     if (nkb & 1) compute(Aq[0]);
 
+    if ((GNR_C16_ABL & 1) && cp.K != -12345) return;              // timing experiment: no epilogue
     conv16_plain_epilogue<MT, NT>(cp, acc, b, n, 0, g, rgbw);
 }
 
