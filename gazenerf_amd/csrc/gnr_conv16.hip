@@ -466,6 +466,13 @@ __global__ __launch_bounds__(64 * ROWS, (ROWS == 4 ? (MT <= 2 ? 4 : 3) : (MT <= 
 
     __shared__ float rgbw[3 * 16 * MT];
     __shared__ float tile[16 * TR * BL_RS];
+    if ((GNR_C16_ABL & 512) && blockIdx.x < 1024u) {              // experiment: de-phase the four workgroups of a CU (first round only)
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        const int slot = (int)(hw & 3u);
+#pragma unroll 1
+        for (int i = 0; i < 2 * slot; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     if (cp.rgb_w)
         for (int i = tid; i < 3 * cp.M; i += NTH) rgbw[i] = cp.rgb_w[i];       // visible after the first barrier below
 
