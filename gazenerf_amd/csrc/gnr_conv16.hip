@@ -105,9 +105,36 @@ __global__ __launch_bounds__(256) void conv16_pack_kernel(const Conv16PackJobs j
 
 // The plain epilogue (bias, LeakyReLU, mask, accumulate, store) with the optional RGB rider: register e of acc[mt][t] is channel
 // m0 + 16 mt + 4 g + e at pixel n + t of image b.  Shared by conv16_kernel and conv16_blur_lds_kernel.
+// PRE (conv16_blur_lds_kernel, round 5): the epilogue's own operands -- the bias of the lane's MT x 4 channels and the running
+// RGB values its rider accumulates into -- were requested before the last k-block's MFMAs (conv16_epilogue_prefetch) and arrive
+// as registers: a workgroup whose waves meet at barriers cannot hide two dependent load latencies at its end behind other waves
+// (measured: the epilogue without its stores was 54 of that kernel's 241 us).  Same values, same arithmetic.
 template <int MT, int NT>
+struct Conv16EpiPre { float bias[MT][4]; float rgb[(3 * NT + 3) / 4]; };
+template <int MT, int NT>
+__device__ __forceinline__ void conv16_epilogue_prefetch(const Conv16Params& cp, int b, int n, int m0, int g, Conv16EpiPre<MT, NT>& pre) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = m0 + 16 * mt + 4 * g + e;
+            pre.bias[mt][e] = (cp.bias && m < cp.M) ? cp.bias[m] : 0.0f;
+        }
+    constexpr int NV = 3 * NT, NG = (NV + 3) / 4;
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        const int idx = 4 * k + g;
+        pre.rgb[k] = 0.0f;
+        if (cp.rgb_w && cp.rgb_accumulate && idx < NV) {
+            const int o = idx / NT, t = idx - o * NT;
+            pre.rgb[k] = cp.rgb[((long)b * 3 + o) * cp.P + n + t];
+        }
+    }
+}
+
+template <int MT, int NT, bool PRE = false>
 __device__ __forceinline__ void conv16_plain_epilogue(const Conv16Params& cp, f32x4 (&acc)[MT][NT], int b, int n, int m0, int g,
-                                                      const float* rgbw) {
+                                                      const float* rgbw, const Conv16EpiPre<MT, NT>* pre = nullptr) {
     typedef typename Pix<NT>::T pv;
     // the RGB branch on the block output (slices == 1): per lane the dot over its channels, then over the four lane groups
     float ra[3][NT];
@@ -124,7 +151,8 @@ __device__ __forceinline__ void conv16_plain_epilogue(const Conv16Params& cp, f3
             pv v;
 #pragma unroll
             for (int t = 0; t < NT; ++t) v[t] = acc[mt][t][e];
-            if (cp.bias && !(GNR_C16_ABL & 32)) v += cp.bias[m];
+            if (PRE) v += pre->bias[mt][e];                        // (0 where there is no bias)
+            else if (cp.bias && !(GNR_C16_ABL & 32)) v += cp.bias[m];
             if (cp.leaky) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) v[t] = v[t] > 0.0f ? v[t] : LEAK16 * v[t];
@@ -175,7 +203,8 @@ __device__ __forceinline__ void conv16_plain_epilogue(const Conv16Params& cp, f3
                 const int o = idx / NT, t = idx - o * NT;
                 const long off = ((long)b * 3 + o) * cp.P + n + t;
                 float r = tot + cp.rgb_bias[o];
-                if (cp.rgb_accumulate) r += cp.rgb[off];
+                if (PRE) { if (cp.rgb_accumulate) r += pre->rgb[k]; }
+                else if (cp.rgb_accumulate) r += cp.rgb[off];
                 cp.rgb[off] = r;
                 if (cp.rgb_img) {
                     r = 1.0f / (1.0f + expf(-r));
@@ -440,11 +469,9 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv16_kernel(const Conv16Params 
 constexpr int BL_RS = 72;           // floats per LDS row (halo 3 | 64 pixels 4..67 | halo 68)
 constexpr int BL_ROWS = 4;          // image rows per workgroup tile = waves per workgroup.  8 (halo 1.25 x instead of 1.5 x, 46 KB of LDS, two
                                     // workgroups per CU) was measured in round 5: 246 / 183 us against 240 / 137 (profiles/r5_n1_experiments.txt)
-constexpr int BL_DEPTH = 1;         // k-blocks of global loads in flight per thread (staging register sets).  2 was measured: 148 / 202
-                                    // VGPRs, three / two waves per SIMD, 255 / 156 us against 238 / 139 -- occupancy beats prefetch depth here
-template <int MT, int ROWS>
+template <int MT, int ROWS, bool ODD>          // ODD: the number of k-blocks is odd (which Aq set the last block uses is then static)
 __global__ __launch_bounds__(64 * ROWS, (ROWS == 4 ? (MT <= 2 ? 4 : 3) : (MT <= 2 ? 4 : 2))) void conv16_blur_lds_kernel(const Conv16Params cp) {
-    constexpr int NT = 4, DEPTH = BL_DEPTH, TR = ROWS + 2, NTH = 64 * ROWS;
+    constexpr int NT = 4, TR = ROWS + 2, NTH = 64 * ROWS;
     constexpr int SEGS = 16 * TR, NJ = (SEGS * 16 + NTH - 1) / NTH, NHALO = 2 * 16 * TR;      // 256-byte row segments, b128 pieces per thread, halo elements
     static_assert(SEGS * 16 == NJ * NTH, "every thread stages the same number of pieces");
     static_assert(NHALO <= NTH, "one halo element per thread");
@@ -466,13 +493,6 @@ __global__ __launch_bounds__(64 * ROWS, (ROWS == 4 ? (MT <= 2 ? 4 : 3) : (MT <= 
 
     __shared__ float rgbw[3 * 16 * MT];
     __shared__ float tile[16 * TR * BL_RS];
-    if ((GNR_C16_ABL & 512) && blockIdx.x < 1024u) {              // experiment: de-phase the four workgroups of a CU (first round only)
-        unsigned hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        const int slot = (int)(hw & 3u);
-#pragma unroll 1
-        for (int i = 0; i < 2 * slot; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     if (cp.rgb_w)
         for (int i = tid; i < 3 * cp.M; i += NTH) rgbw[i] = cp.rgb_w[i];       // visible after the first barrier below
 
@@ -510,26 +530,20 @@ __global__ __launch_bounds__(64 * ROWS, (ROWS == 4 ? (MT <= 2 ? 4 : 3) : (MT <= 
         vh = tid < NHALO ? ((unsigned)ch * (unsigned)cp.P + (unsigned)(iy * W + ix)) * 4u : 0xFFFFFF00u;
         lh = (unsigned)((ch * TR + r) * BL_RS + (side ? 68 : 3));
     }
-    f32x4 stg[DEPTH][NJ];
-    float sth[DEPTH];
-    auto load_stage = [&](auto set, int kb) {          // rows >= K: beyond the descriptor's bound -- zeros, no request
-        constexpr int S = decltype(set)::value;
+    f32x4 stg[NJ];                                     // ONE staging set: a second k-block in flight was measured (148 / 202 VGPRs, three /
+    float sth;                                         // two waves per SIMD: 255 / 156 us against 238 / 139) -- occupancy beats prefetch depth here
+    auto load_stage = [&](int kb) {                    // rows >= K: beyond the descriptor's bound -- zeros, no request
         const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((GNR_C16_ABL & 2) ? 0 : kb) * 16u * rowB));
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            stg[S][j] = ((GNR_C16_ABL & 256) && j >= NJ / 2) ? f32x4{0.0f, 0.0f, 0.0f, 0.0f}       // 256: timing experiment, half of the row pieces
-                                                             : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, vst[j], (int)sb, 0));
-        if (!(GNR_C16_ABL & 16)) sth[S] = load1(rsB, vh, sb);       // 16: timing experiment, no halo-column loads
-        else sth[S] = 0.0f;
+        for (int j = 0; j < NJ; ++j) stg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, vst[j], (int)sb, 0));
+        if (!(GNR_C16_ABL & 16)) sth = load1(rsB, vh, sb);          // 16: timing experiment, no halo-column loads
+        else sth = 0.0f;
     };
-    auto store_stage = [&](auto set) {
-        constexpr int S = decltype(set)::value;
+    auto store_stage = [&]() {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) *(f32x4*)&tile[lst[j]] = stg[S][j];
-        if (tid < NHALO) tile[lh] = sth[S];
+        for (int j = 0; j < NJ; ++j) *(f32x4*)&tile[lst[j]] = stg[j];
+        if (tid < NHALO) tile[lh] = sth;
     };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, DEPTH - 1>;
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -566,34 +580,49 @@ __global__ __launch_bounds__(64 * ROWS, (ROWS == 4 ? (MT <= 2 ? 4 : 3) : (MT <= 
                 for (int t = 0; t < NT; ++t) acc[mt][t] = mfma16c(A[mt][s], Bo[t], acc[mt][t]);
         }
     };
-    // LDS <- block `next` (in staging set `set`), that set <- block next + DEPTH
-    auto swap_stage = [&](auto set, int next) {
+    // one k-block: the next block's A rows, this block's MFMAs, then LDS <- the staged block kb + 1 and (REQ) staging <- block kb + 2
+    auto step = [&](auto cur, int kb, auto req) {
+        constexpr int CUR = decltype(cur)::value;
+        load_a(kb + 1, Aq[1 - CUR]);
+        compute(Aq[CUR]);
         __syncthreads();
-        store_stage(set);
-        if (next + DEPTH < nkb) load_stage(set, next + DEPTH);
+        store_stage();
+        if constexpr (decltype(req)::value) load_stage(kb + 2);
         __syncthreads();
     };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    using Req = std::true_type;
+    using NoReq = std::false_type;
 
-    load_stage(I0{}, 0);
+    load_stage(0);
     load_a(0, Aq[0]);
-    if constexpr (DEPTH == 2) load_stage(I1{}, 1);
-    store_stage(I0{});
-    if (DEPTH < nkb) load_stage(I0{}, DEPTH);
+    store_stage();
+    if (1 < nkb) load_stage(1);
     __syncthreads();
-    // DEPTH 1: set 0 always holds the next block.  DEPTH 2: before an even block kb, set 1 holds kb + 1 and set 0 holds kb + 2.
+    // The last block is peeled, so that its MFMAs run with the staging registers free: that is where the epilogue's own operands
+    // are requested (conv16_epilogue_prefetch).  Requests past the last block read zeros through the descriptor's bound.
+    Conv16EpiPre<MT, NT> pre;
     int kb = 0;
-    for (; kb + 1 < nkb; kb += 2) {
-        load_a(kb + 1, Aq[1]);
+    if constexpr (ODD) {
+        for (; kb + 1 < nkb; kb += 2) {
+            step(C0{}, kb, Req{});
+            step(C1{}, kb + 1, Req{});
+        }
+        conv16_epilogue_prefetch<MT, NT>(cp, b, n, 0, g, pre);
         compute(Aq[0]);
-        swap_stage(I1{}, kb + 1);
-        if (kb + 2 < nkb) load_a(kb + 2, Aq[0]);
+    } else {
+        for (; kb + 2 < nkb; kb += 2) {
+            step(C0{}, kb, Req{});
+            step(C1{}, kb + 1, Req{});
+        }
+        step(C0{}, kb, NoReq{});
+        conv16_epilogue_prefetch<MT, NT>(cp, b, n, 0, g, pre);
         compute(Aq[1]);
-        if (kb + 2 < nkb) swap_stage(I0{}, kb + 2);
     }
-    if (nkb & 1) compute(Aq[0]);
 
     if ((GNR_C16_ABL & 1) && cp.K != -12345) return;              // timing experiment: no epilogue
-    conv16_plain_epilogue<MT, NT>(cp, acc, b, n, 0, g, rgbw);
+    conv16_plain_epilogue<MT, NT, true>(cp, acc, b, n, 0, g, rgbw, &pre);
 }
 
 // du = Wf^T g with the adjoint of the PixelShuffleUpsample tail in the epilogue (round 4; until then the GEMM wrote du
@@ -1110,8 +1139,14 @@ int launch_conv16(const Conv16Params& cp, hipStream_t st) {
         items >= 512) {          // below two workgroups per CU its barriers are exposed (one 256 x 256 image: 30.7 us against 27.3)
         const long bitems = (long)cp.batch * (cp.H / BL_ROWS) * (cp.W / 64);
         const unsigned bblocks = (unsigned)(8 * ((bitems + 7) / 8));
-        if (cp.plan.MT == 2) hipLaunchKernelGGL((conv16_blur_lds_kernel<2, BL_ROWS>), dim3(bblocks), dim3(64 * BL_ROWS), 0, st, cp);
-        else hipLaunchKernelGGL((conv16_blur_lds_kernel<4, BL_ROWS>), dim3(bblocks), dim3(64 * BL_ROWS), 0, st, cp);
+        const bool odd = cp.plan.nkb & 1;
+        if (cp.plan.MT == 2) {
+            if (odd) hipLaunchKernelGGL((conv16_blur_lds_kernel<2, BL_ROWS, true>), dim3(bblocks), dim3(64 * BL_ROWS), 0, st, cp);
+            else hipLaunchKernelGGL((conv16_blur_lds_kernel<2, BL_ROWS, false>), dim3(bblocks), dim3(64 * BL_ROWS), 0, st, cp);
+        } else {
+            if (odd) hipLaunchKernelGGL((conv16_blur_lds_kernel<4, BL_ROWS, true>), dim3(bblocks), dim3(64 * BL_ROWS), 0, st, cp);
+            else hipLaunchKernelGGL((conv16_blur_lds_kernel<4, BL_ROWS, false>), dim3(bblocks), dim3(64 * BL_ROWS), 0, st, cp);
+        }
         return 0;
     }
     const int key = cp.plan.MT * 10 + cp.plan.NT;
