@@ -110,16 +110,21 @@ __global__ __launch_bounds__(256) void conv16_pack_kernel(const Conv16PackJobs j
 // as registers: a workgroup whose waves meet at barriers cannot hide two dependent load latencies at its end behind other waves
 // (measured: the epilogue without its stores was 54 of that kernel's 241 us).  Same values, same arithmetic.
 template <int MT, int NT>
-struct Conv16EpiPre { float bias[MT][4]; float rgb[(3 * NT + 3) / 4]; };
+struct Conv16EpiPre {
+    static constexpr bool BIAS = MT <= 2;          // four row tiles: the 16 bias registers spill (168-VGPR budget); only the RGB values travel
+    float bias[BIAS ? MT : 1][4]; float rgb[(3 * NT + 3) / 4];
+};
 template <int MT, int NT>
 __device__ __forceinline__ void conv16_epilogue_prefetch(const Conv16Params& cp, int b, int n, int m0, int g, Conv16EpiPre<MT, NT>& pre) {
+    if constexpr (Conv16EpiPre<MT, NT>::BIAS) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int m = m0 + 16 * mt + 4 * g + e;
-            pre.bias[mt][e] = (cp.bias && m < cp.M) ? cp.bias[m] : 0.0f;
-        }
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + 16 * mt + 4 * g + e;
+                pre.bias[mt][e] = (cp.bias && m < cp.M) ? cp.bias[m] : 0.0f;
+            }
+    }
     constexpr int NV = 3 * NT, NG = (NV + 3) / 4;
 #pragma unroll
     for (int k = 0; k < NG; ++k) {
@@ -151,7 +156,7 @@ __device__ __forceinline__ void conv16_plain_epilogue(const Conv16Params& cp, f3
             pv v;
 #pragma unroll
             for (int t = 0; t < NT; ++t) v[t] = acc[mt][t][e];
-            if (PRE) v += pre->bias[mt][e];                        // (0 where there is no bias)
+            if constexpr (PRE && Conv16EpiPre<MT, NT>::BIAS) v += pre->bias[mt][e];      // (0 where there is no bias)
             else if (cp.bias && !(GNR_C16_ABL & 32)) v += cp.bias[m];
             if (cp.leaky) {
 #pragma unroll
@@ -704,6 +709,20 @@ __global__ __launch_bounds__(64 * WPB, MT == 1 ? 4 : 2) void conv16_unshuffle_ke
     };
     load_b(0, Bq[0]);
     load_a(0, Aq[0]);
+    // Round 5: the epilogue's sign nibbles (two bytes per row of the lane's quads) are requested up front.  Loaded inside the
+    // epilogue they were a dependent latency at the end of every wave, in front of its stores, with two or three waves per SIMD to
+    // hide it (the contraction is 2-17 k-blocks short).
+    const long Plo = (long)S * S;
+    const long pix = (long)y * S + x0;
+    unsigned nibs[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = PERM ? ((m0 >> 2) + 4 * mt + g) + q * (cp.M >> 2) : m0 + 16 * mt + 4 * g + q;
+            const bool live = PERM ? ((m0 >> 2) + 4 * mt + g) < (cp.M >> 2) : c < cp.M;
+            nibs[mt][q] = live ? *(const unsigned short*)(cp.sign_in + (long)b * cp.sign_batch + (long)c * Plo + pix) : 0u;
+        }
     int kb = 0;
     for (; kb + 1 < nkb; kb += 2) {
         load_b(kb + 1, Bq[1]);
@@ -721,8 +740,6 @@ __global__ __launch_bounds__(64 * WPB, MT == 1 ? 4 : 2) void conv16_unshuffle_ke
     if (nkb & 1) compute(Aq[0], Bq[0]);
 
     // ---- epilogue: register q of acc[mt][4 i + 2 xs + j] is du(channel of row q, 2y + i, 2 (x0 + xs) + j) ----
-    const long Plo = (long)S * S;
-    const long pix = (long)y * S + x0;
     if constexpr (PERM) {
         // rows packed with perm4: row q of a lane's quad is channel cb + q Cq -- the four x.repeat-adjoint terms in one lane
         const int Cq = cp.M >> 2;
@@ -734,7 +751,7 @@ __global__ __launch_bounds__(64 * WPB, MT == 1 ? 4 : 2) void conv16_unshuffle_ke
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int c = cb + q * Cq;
-                const unsigned nib2 = *(const unsigned short*)(cp.sign_in + (long)b * cp.sign_batch + (long)c * Plo + pix);
+                const unsigned nib2 = nibs[mt][q];
                 float* dst = cp.C + (long)b * cp.c_batch + (long)(4 * c) * Plo + pix;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -756,7 +773,7 @@ __global__ __launch_bounds__(64 * WPB, MT == 1 ? 4 : 2) void conv16_unshuffle_ke
             for (int q = 0; q < 4; ++q) {
                 const int c = m0 + 16 * mt + 4 * g + q;
                 if (c >= cp.M) continue;
-                const unsigned nib2 = *(const unsigned short*)(cp.sign_in + (long)b * cp.sign_batch + (long)c * Plo + pix);
+                const unsigned nib2 = nibs[mt][q];
                 float* dst = cp.C + (long)b * cp.c_batch + (long)(4 * c) * Plo + pix;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
