@@ -645,7 +645,7 @@ __device__ __forceinline__ void ustore2(float* p, f32x2 v) {
     *(f32x2*)p = v;
 }
 template <int MT, bool PERM>
-__global__ __launch_bounds__(64 * WPB, MT == 1 ? 4 : 2) void conv16_unshuffle_kernel(const Conv16Params cp) {
+__global__ __launch_bounds__(64 * WPB, 2) void conv16_unshuffle_kernel(const Conv16Params cp) {
     constexpr int NT = 8;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -709,20 +709,6 @@ __global__ __launch_bounds__(64 * WPB, MT == 1 ? 4 : 2) void conv16_unshuffle_ke
     };
     load_b(0, Bq[0]);
     load_a(0, Aq[0]);
-    // Round 5: the epilogue's sign nibbles (two bytes per row of the lane's quads) are requested up front.  Loaded inside the
-    // epilogue they were a dependent latency at the end of every wave, in front of its stores, with two or three waves per SIMD to
-    // hide it (the contraction is 2-17 k-blocks short).
-    const long Plo = (long)S * S;
-    const long pix = (long)y * S + x0;
-    unsigned nibs[MT][4];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = PERM ? ((m0 >> 2) + 4 * mt + g) + q * (cp.M >> 2) : m0 + 16 * mt + 4 * g + q;
-            const bool live = PERM ? ((m0 >> 2) + 4 * mt + g) < (cp.M >> 2) : c < cp.M;
-            nibs[mt][q] = live ? *(const unsigned short*)(cp.sign_in + (long)b * cp.sign_batch + (long)c * Plo + pix) : 0u;
-        }
     int kb = 0;
     for (; kb + 1 < nkb; kb += 2) {
         load_b(kb + 1, Bq[1]);
@@ -740,6 +726,8 @@ __global__ __launch_bounds__(64 * WPB, MT == 1 ? 4 : 2) void conv16_unshuffle_ke
     if (nkb & 1) compute(Aq[0], Bq[0]);
 
     // ---- epilogue: register q of acc[mt][4 i + 2 xs + j] is du(channel of row q, 2y + i, 2 (x0 + xs) + j) ----
+    const long Plo = (long)S * S;
+    const long pix = (long)y * S + x0;
     if constexpr (PERM) {
         // rows packed with perm4: row q of a lane's quad is channel cb + q Cq -- the four x.repeat-adjoint terms in one lane
         const int Cq = cp.M >> 2;
@@ -751,7 +739,7 @@ __global__ __launch_bounds__(64 * WPB, MT == 1 ? 4 : 2) void conv16_unshuffle_ke
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int c = cb + q * Cq;
-                const unsigned nib2 = nibs[mt][q];
+                const unsigned nib2 = *(const unsigned short*)(cp.sign_in + (long)b * cp.sign_batch + (long)c * Plo + pix);
                 float* dst = cp.C + (long)b * cp.c_batch + (long)(4 * c) * Plo + pix;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -773,7 +761,7 @@ __global__ __launch_bounds__(64 * WPB, MT == 1 ? 4 : 2) void conv16_unshuffle_ke
             for (int q = 0; q < 4; ++q) {
                 const int c = m0 + 16 * mt + 4 * g + q;
                 if (c >= cp.M) continue;
-                const unsigned nib2 = nibs[mt][q];
+                const unsigned nib2 = *(const unsigned short*)(cp.sign_in + (long)b * cp.sign_batch + (long)c * Plo + pix);
                 float* dst = cp.C + (long)b * cp.c_batch + (long)(4 * c) * Plo + pix;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -990,7 +978,7 @@ struct Variant { int MT, NT; bool blur; };
 // (round 4: half-width 2x2 / 4x2 instances were measured for the single-image forward and removed again -- a B = 1 GEMM is not
 // short of waves, profiles/r4_n1_small_tiles.txt)
 const Variant kVariants[] = {{2, 4, true}, {4, 4, true}, {8, 4, false}, {9, 2, true}, {11, 2, false}, {13, 2, false}};
-constexpr int kUnshuffleMT[] = {2, 3, 4, 1};      // (1: round-5 experiment, pinned only -- never the heuristic's choice: see conv16_plan_unshuffle)
+constexpr int kUnshuffleMT[] = {2, 3, 4};
 
 template <int MT, int NT>
 void launch_variant(const Conv16Params& cp, unsigned blocks, hipStream_t st) {
@@ -1029,7 +1017,6 @@ Conv16Plan conv16_plan_unshuffle(int M, int K, int side) {
         // fewest padded row tiles, then the smallest tile (64 channels at 256 x 256, 7 images: 2 x (2,8) 190 us, 1 x (4,8) 210 us)
         int best_pad = 1 << 30;
         for (int v : kUnshuffleMT) {
-            if (v == 1) continue;
             const int sl = (tiles + v - 1) / v, pad = sl * v - tiles;
             if (pad < best_pad) { best_pad = pad; mt = v; }
         }
@@ -1135,8 +1122,6 @@ int launch_conv16(const Conv16Params& cp, hipStream_t st) {
         const int key = 2 * cp.plan.MT + (cp.dres ? 1 : 0);       // dres given: rows packed with perm4 (M % 4 == 0)
         if (cp.dres && cp.M % 4) return fail("conv16: the un-shuffle epilogue with dres needs M %% 4 == 0 (M = %d)", cp.M);
         switch (key) {
-            case 3: hipLaunchKernelGGL((conv16_unshuffle_kernel<1, true>), dim3(wblocks), dim3(64 * WPB), 0, st, cp); break;
-            case 2: hipLaunchKernelGGL((conv16_unshuffle_kernel<1, false>), dim3(wblocks), dim3(64 * WPB), 0, st, cp); break;
             case 5: hipLaunchKernelGGL((conv16_unshuffle_kernel<2, true>), dim3(wblocks), dim3(64 * WPB), 0, st, cp); break;
             case 7: hipLaunchKernelGGL((conv16_unshuffle_kernel<3, true>), dim3(wblocks), dim3(64 * WPB), 0, st, cp); break;
             case 9: hipLaunchKernelGGL((conv16_unshuffle_kernel<4, true>), dim3(wblocks), dim3(64 * WPB), 0, st, cp); break;
