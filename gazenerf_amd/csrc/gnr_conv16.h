@@ -53,6 +53,11 @@ struct Conv16Params {
     int leaky;                                     // LeakyReLU(0.2) on (acc + bias)
     const float* mask_ref; long mask_batch;        // result *= (mask_ref(b,m,n) > 0 ? 1 : 0.2)
     int accumulate;                                // C += result
+    // round 5: the x.repeat adjoint collected in this GEMM's epilogue instead of by unshuffle_dres_kernel (layer_1's data gradient,
+    // channel counts that are no multiple of 4):  C = result + dres,  dres(b,m,n) = sum_q G(b, m + q M, n),
+    //   G(b,k,n) = dres_from(b,k,n) * (bit k&3 of dres_sign(b,k>>2,n) ? 1 : 1/0.2)      (dres_from = dpre2 [batch][4 M][P])
+    const float* dres_from; long dres_from_batch;
+    const unsigned char* dres_sign; long dres_sign_batch;
     int shuffle, W;                                // PixelShuffleUpsample tail: n = y*W + x
     const float* res; long res_batch;              // residual res(b, m % (M/4), n)
     unsigned char* sign_out; long sign_batch;      // shuffle: bit e of byte (b, m/4, n) = (acc + bias > 0) of channel 4(m/4)+e

@@ -169,6 +169,21 @@ __device__ __forceinline__ void conv16_plain_epilogue(const Conv16Params& cp, f3
             }
             float* dst = cp.C + (((GNR_C16_ABL & 128) ? 0x3FFFCL : -1L) & ((long)b * cp.c_batch + (long)m * cp.P + n));
             if (cp.accumulate && !(GNR_C16_ABL & 32)) v += *(const pv*)dst;
+            if constexpr (NT == 4) {
+                if (cp.dres_from) {
+                    // unshuffle_dres_kernel's expression, term for term (un-masking by x 5.0f where the mask multiplied by 0.2f)
+                    pv G[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int k = m + q * cp.M;
+                        const pv d = *(const pv*)(cp.dres_from + (long)b * cp.dres_from_batch + (long)k * cp.P + n);
+                        const unsigned nib4 = *(const unsigned*)(cp.dres_sign + (long)b * cp.dres_sign_batch + (long)(k >> 2) * cp.P + n);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) G[q][t] = d[t] * (((nib4 >> (8 * t + (k & 3))) & 1u) ? 1.0f : 1.0f / LEAK16);
+                    }
+                    v += (G[0] + G[1]) + (G[2] + G[3]);
+                }
+            }
             if ((GNR_C16_ABL & 64) && v[0] != 1.2345f) continue;
             *(pv*)dst = v;
             if (cp.rgb_w) {

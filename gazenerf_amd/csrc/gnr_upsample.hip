@@ -274,6 +274,7 @@ __global__ __launch_bounds__(256) void rgb_conv_kernel(const float* __restrict__
 // Grid (pixel groups, channel groups): at the low resolutions (4096 pixels x 258 channels) the pixels alone are a handful
 // of workgroups, so the channel range is split too (blockIdx.y; the bias pseudo-channel rides with the last group).
 constexpr int RGBF_IT = 4;
+constexpr int RB_AHEAD = 3;             // rgb_bwd_blur_kernel: channels requested ahead
 static long rgbf_workgroups(long pixels_total) { return (pixels_total / 4 + 256 * RGBF_IT - 1) / (256 * RGBF_IT); }
 static int rgbf_channel_groups(long nwg, int C) {          // ~1024 workgroups in all, at least 8 channels each
     long g = (1024 + nwg - 1) / nwg;
@@ -500,12 +501,15 @@ __global__ __launch_bounds__(256) void rgb_bwd_blur_kernel(const float* __restri
     const int cbeg = (int)blockIdx.y * cper;
     const int cend = cbeg + cper < C ? cbeg + cper : C;
     const bool with_bias = blockIdx.y + 1 == gridDim.y;
-    // The memory operands of channel c + 1 are requested before channel c is worked on (round 4): a workgroup's channels are a
-    // serial chain (load -> LDS -> barrier -> stencil -> store), and with the load at the top of the iteration every channel
-    // paid a full memory latency -- 155 us for 470 MB at the 512 x 512 level.
-    f32x4 nv_n = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, dn_n = nv_n;
-    float hn_n = 0.0f, hd_n = 0.0f;
-    auto fetch = [&](int c) {
+    // The memory operands of the next channels are requested before channel c is worked on: a workgroup's channels are a serial
+    // chain (load -> LDS -> barrier -> stencil -> store).  Round 4: one channel ahead (155 -> 119 us at the 512 x 512 level); round 5:
+    // RB_AHEAD = 3 channels ahead in a ring of register sets -- one channel in flight is 4-8 KB per workgroup, ~50 KB per CU, which at
+    // the ~2 us a load takes under this traffic is the 4 TB/s the kernel ran at.
+    f32x4 nvq[RB_AHEAD], dnq[RB_AHEAD];
+    float hnq[RB_AHEAD], hdq[RB_AHEAD];
+#pragma unroll
+    for (int d = 0; d < RB_AHEAD; ++d) { nvq[d] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; dnq[d] = nvq[d]; hnq[d] = 0.0f; hdq[d] = 0.0f; }
+    auto fetch = [&](int c, f32x4& nv_n, f32x4& dn_n, float& hn_n, float& hd_n) {
         nv_n = *(const f32x4*)(net + base + (long)c * P);
         if (dnet_in) dn_n = *(const f32x4*)(dnet_in + base + (long)c * P);
         if (hin) {
@@ -513,51 +517,60 @@ __global__ __launch_bounds__(256) void rgb_bwd_blur_kernel(const float* __restri
             if (dnet_in) hd_n = dnet_in[hbase + (long)c * P];
         }
     };
-    if (cbeg < cend) fetch(cbeg);
-    for (int c = cbeg, j = 0; c < cend; ++c, ++j) {
-        float* tb = tile + (j & 1) * RB_TILE;
-        const float w0 = w[c], w1 = w[C + c], w2 = w[2 * C + c];
-        const f32x4 nv = nv_n, dn = dn_n;
-        const float hn = hn_n, hd = hd_n;
-        fetch(c + 1 < cend ? c + 1 : c);
-        f32x4 v = w0 * g[0] + w1 * g[1] + w2 * g[2];
-        if (dnet_in) v += dn;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= nv[e] > 0.0f ? 1.0f : LEAK;
-        *(f32x4*)(tb + cpos) = v;
-        if (halo) {
-            float hv = 0.0f;
-            if (hin) {
-                hv = w0 * hg[0] + w1 * hg[1] + w2 * hg[2];
-                if (dnet_in) hv += hd;
-                hv *= hn > 0.0f ? 1.0f : LEAK;
+    for (int d = 0; d < RB_AHEAD; ++d)
+        if (cbeg + d < cend) fetch(cbeg + d, nvq[d], dnq[d], hnq[d], hdq[d]);
+    int j = 0;
+    for (int c0 = cbeg; c0 < cend; c0 += RB_AHEAD) {
+#pragma unroll
+        for (int d = 0; d < RB_AHEAD; ++d) {
+            const int c = c0 + d;
+            if (c >= cend) break;                                // (uniform)
+            float* tb = tile + (j & 1) * RB_TILE;
+            ++j;
+            const float w0 = w[c], w1 = w[C + c], w2 = w[2 * C + c];
+            const f32x4 nv = nvq[d], dn = dnq[d];
+            const float hn = hnq[d], hd = hdq[d];
+            if (c + RB_AHEAD < cend) fetch(c + RB_AHEAD, nvq[d], dnq[d], hnq[d], hdq[d]);
+            f32x4 v = w0 * g[0] + w1 * g[1] + w2 * g[2];
+            if (dnet_in) v += dn;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= nv[e] > 0.0f ? 1.0f : LEAK;
+            *(f32x4*)(tb + cpos) = v;
+            if (halo) {
+                float hv = 0.0f;
+                if (hin) {
+                    hv = w0 * hg[0] + w1 * hg[1] + w2 * hg[2];
+                    if (dnet_in) hv += hd;
+                    hv *= hn > 0.0f ? 1.0f : LEAK;
+                }
+                tb[hpos] = hv;
             }
-            tb[hpos] = hv;
+            if (part) {
+                float a[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int o = 0; o < 3; ++o)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[o] = fmaf(g[o][e], nv[e], a[o]);
+                // the three wave sums without the LDS pipe (18 ds_bpermute per channel before): inside the 16-lane rows by DPP
+                // butterflies, across the four rows by the gfx950 row / half swaps -- row o of the wave ends up with the total of a[o]
+#pragma unroll
+                for (int o = 0; o < 3; ++o) a[o] = row_sum16(a[o]);
+                const float t = rows_total4(a[0], a[1], a[2], 0.0f);
+                if ((lane & 15) == 0 && lane < 48) wsum[(wave * 3 + (lane >> 4)) * (C + 1) + c] = t;
+            }
+            __syncthreads();
+            f32x4 rows[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float* rp = tb + (r + k) * RB_LD + 4 + 4 * q;
+                const f32x4 cc = *(const f32x4*)rp;
+                const float l = rp[-1], rr = rp[4];
+                rows[k] = f32x4{wl[0] * l + wc[0] * cc.x + wr[0] * cc.y, wl[1] * cc.x + wc[1] * cc.y + wr[1] * cc.z,
+                                wl[2] * cc.y + wc[2] * cc.z + wr[2] * cc.w, wl[3] * cc.z + wc[3] * cc.w + wr[3] * rr};
+            }
+            *(f32x4*)(gout + base + (long)c * P) = yl * rows[0] + yc * rows[1] + yr * rows[2];
         }
-        if (part) {
-            float a[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int o = 0; o < 3; ++o)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) a[o] = fmaf(g[o][e], nv[e], a[o]);
-            // the three wave sums without the LDS pipe (18 ds_bpermute per channel before): inside the 16-lane rows by DPP
-            // butterflies, across the four rows by the gfx950 row / half swaps -- row o of the wave ends up with the total of a[o]
-#pragma unroll
-            for (int o = 0; o < 3; ++o) a[o] = row_sum16(a[o]);
-            const float t = rows_total4(a[0], a[1], a[2], 0.0f);
-            if ((lane & 15) == 0 && lane < 48) wsum[(wave * 3 + (lane >> 4)) * (C + 1) + c] = t;
-        }
-        __syncthreads();
-        f32x4 rows[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float* rp = tb + (r + k) * RB_LD + 4 + 4 * q;
-            const f32x4 cc = *(const f32x4*)rp;
-            const float l = rp[-1], rr = rp[4];
-            rows[k] = f32x4{wl[0] * l + wc[0] * cc.x + wr[0] * cc.y, wl[1] * cc.x + wc[1] * cc.y + wr[1] * cc.z,
-                            wl[2] * cc.y + wc[2] * cc.z + wr[2] * cc.w, wl[3] * cc.z + wc[3] * cc.w + wr[3] * rr};
-        }
-        *(f32x4*)(gout + base + (long)c * P) = yl * rows[0] + yc * rows[1] + yr * rows[2];
     }
     if (!part) return;
     if (with_bias) {
@@ -1128,6 +1141,7 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
         // -- never a buffer of the saved forward workspace (round 3 wrote it over u[i], which made a second backward over
         // the same saved state wrong).
         float* dnet = (i == 0 && d_x) ? d_x : (((nb - 1 - i) & 1) ? t.g1 : t.g2);
+        bool dres_folded = false;
         Conv16Params g{};
         g.plan = bp[i].c3; g.At = s.pack + bp[i].o3; g.B = Y; g.b_batch = (long)Cn * P4; g.M = C; g.K = Cn; g.P = (int)P4; g.batch = B;
         if (bp[i].unshuffle_fused) {
@@ -1135,7 +1149,11 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
             g.C = X; g.c_batch = 4L * C * P; g.W = S; g.sign_in = s.sign2[i]; g.sign_batch = (long)C * P;
             if (C % 4 == 0) { g.dres = dnet; g.dres_batch = (long)C * P; }
             if (launch_conv16(g, st)) return 1;
-            if (C % 4)            // the x.repeat adjoint's terms sit in different row slices of the GEMM: collected from dpre2
+            // C % 4 != 0: the x.repeat adjoint's terms sit in different row slices of this GEMM.  Round 4 collected them from dpre2
+            // with unshuffle_dres_kernel; round 5: layer_1's data-gradient GEMM below (which accumulated into that kernel's output)
+            // collects them in its own epilogue when it runs a 64-pixel tile -- d(net) is written once and never read back
+            dres_folded = C % 4 != 0 && bp[i].c1.NT == 4;
+            if (C % 4 && !dres_folded)
                 hipLaunchKernelGGL(unshuffle_dres_kernel, dim3(blocks_for((long)B * C * (P / 4))), dim3(256), 0, st, X, s.sign2[i], C, P, B, dnet);
             float* sw = X; X = Y; Y = sw;                                        // Y = dpre2, X free for dpre1
         } else {
@@ -1159,6 +1177,10 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
         g = Conv16Params{};
         g.plan = bp[i].c1; g.At = s.pack + bp[i].o1; g.B = X; g.b_batch = 2L * C * P; g.C = dnet; g.c_batch = (long)C * P;
         g.M = C; g.K = 2 * C; g.P = (int)P; g.batch = B; g.accumulate = 1;
+        if (dres_folded) {
+            g.accumulate = 0;
+            g.dres_from = Y; g.dres_from_batch = 4L * C * P; g.dres_sign = s.sign2[i]; g.dres_sign_batch = (long)C * P;
+        }
         if (launch_conv16(g, st)) return 1;
         dnet_next = dnet;             // block i-1's dhid accumulates into it (its Cn x 4P' is this C x P)
     }
