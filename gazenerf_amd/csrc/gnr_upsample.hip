@@ -274,7 +274,10 @@ __global__ __launch_bounds__(256) void rgb_conv_kernel(const float* __restrict__
 // Grid (pixel groups, channel groups): at the low resolutions (4096 pixels x 258 channels) the pixels alone are a handful
 // of workgroups, so the channel range is split too (blockIdx.y; the bias pseudo-channel rides with the last group).
 constexpr int RGBF_IT = 4;
-constexpr int RB_AHEAD = 3;             // rgb_bwd_blur_kernel: channels requested ahead
+#ifndef GNR_RB_AHEAD
+#define GNR_RB_AHEAD 3
+#endif
+constexpr int RB_AHEAD = GNR_RB_AHEAD;  // rgb_bwd_blur_kernel: channels requested ahead
 static long rgbf_workgroups(long pixels_total) { return (pixels_total / 4 + 256 * RGBF_IT - 1) / (256 * RGBF_IT); }
 static int rgbf_channel_groups(long nwg, int C) {          // ~1024 workgroups in all, at least 8 channels each
     long g = (1024 + nwg - 1) / nwg;

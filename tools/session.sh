@@ -90,7 +90,7 @@ for STEP in "$@"; do
       GNR_ALLOW_EXPERIMENTAL_LIB=1 bash tools/n1_trace.sh $NAME/ab_$TAG --batch 7 --iters 5 > /dev/null 2>&1
       { echo "# $FL"; grep "N1 B" $O/ab_$TAG/wall.log; grep -v "torch:" $O/ab_$TAG/launches.txt; } > $O/ab_${TAG}_launches.txt; rm -rf $O/ab_$TAG/prof
       python -m gazenerf_amd.build --no-torch-ext > $O/ab_restore.log 2>&1
-      grep -E "N1 B|kernel time|blur_lds|unshuffle_kernel" $O/ab_${TAG}_launches.txt;;
+      grep -E "N1 B|kernel time|blur_lds|unshuffle_kernel|rgb_bwd_blur|946176" $O/ab_${TAG}_launches.txt;;
     n1tile:*)
       TL=${STEP#n1tile:}
       N1_CONV16_TILE=$TL bash tools/n1_trace.sh $NAME/tile_${TL/,/x} --batch 7 --iters 5 > /dev/null 2>&1
