@@ -274,10 +274,7 @@ __global__ __launch_bounds__(256) void rgb_conv_kernel(const float* __restrict__
 // Grid (pixel groups, channel groups): at the low resolutions (4096 pixels x 258 channels) the pixels alone are a handful
 // of workgroups, so the channel range is split too (blockIdx.y; the bias pseudo-channel rides with the last group).
 constexpr int RGBF_IT = 4;
-#ifndef GNR_RB_AHEAD
-#define GNR_RB_AHEAD 3
-#endif
-constexpr int RB_AHEAD = GNR_RB_AHEAD;  // rgb_bwd_blur_kernel: channels requested ahead
+constexpr int RB_AHEAD = 1;             // rgb_bwd_blur_kernel: channels requested ahead (2 / 3 measured slower, profiles/r5_n1_experiments.txt)
 static long rgbf_workgroups(long pixels_total) { return (pixels_total / 4 + 256 * RGBF_IT - 1) / (256 * RGBF_IT); }
 static int rgbf_channel_groups(long nwg, int C) {          // ~1024 workgroups in all, at least 8 channels each
     long g = (1024 + nwg - 1) / nwg;
@@ -505,9 +502,10 @@ __global__ __launch_bounds__(256) void rgb_bwd_blur_kernel(const float* __restri
     const int cend = cbeg + cper < C ? cbeg + cper : C;
     const bool with_bias = blockIdx.y + 1 == gridDim.y;
     // The memory operands of the next channels are requested before channel c is worked on: a workgroup's channels are a serial
-    // chain (load -> LDS -> barrier -> stencil -> store).  Round 4: one channel ahead (155 -> 119 us at the 512 x 512 level); round 5:
-    // RB_AHEAD = 3 channels ahead in a ring of register sets -- one channel in flight is 4-8 KB per workgroup, ~50 KB per CU, which at
-    // the ~2 us a load takes under this traffic is the 4 TB/s the kernel ran at.
+    // chain (load -> LDS -> barrier -> stencil -> store).  Round 4: one channel ahead (155 -> 119 us at the 512 x 512 level).  Round 5
+    // made the distance a parameter (a ring of RB_AHEAD register sets) and measured 2 and 3: SLOWER at every level (107.6 / 94.8 /
+    // 44.8 us at 1, 109.0 / 99.6 / 53.8 at 2, 122.0 / 107.4 / 56.2 at 3) -- with seven workgroups per CU the kernel is not short of
+    // bytes in flight; its ~150 VALU / LDS instructions per channel and wave are half of its time.
     f32x4 nvq[RB_AHEAD], dnq[RB_AHEAD];
     float hnq[RB_AHEAD], hdq[RB_AHEAD];
 #pragma unroll
