@@ -22,7 +22,8 @@
 #   abn1:<tag>:<flags>  rebuild gnr_conv16.hip + gnr_upsample.hip with extra -D flags (experimental build), N1 B = 7 trace,
 #                    restore the product build                                    -> ab_<tag>_launches.txt
 #   n1tile:<mt,nt>   N1 B = 7 trace with a GEMM instance pinned (gnr_set_conv16_tile)   -> tile_<mt>x<nt>_launches.txt
-#   x3energy         J per step of the bf16x3 leg (tools/smi_sample.py)           -> x3_energy.txt
+#   x3energy         J per step of the bf16x3 leg (tools/x3_energy.py)            -> x3_energy.txt
+#   x3ab:<tag>:<flags>  the same on gnr_fwd3.hip / gnr_bwd3.hip rebuilt with extra -D flags -> x3_energy_<tag>.txt
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 NAME=$1; shift
@@ -98,6 +99,11 @@ for STEP in "$@"; do
       grep -E "N1 B|kernel time|unshuffle" $O/tile_${TL/,/x}_launches.txt;;
     x3outlier) timeout 600 python tests/diagnostics/gpu_x3_outlier.py 13 > $O/x3_outlier_draw13.txt 2> $O/x3_outlier.err; cut -c1-230 $O/x3_outlier_draw13.txt | tail -22;;
     x3energy) timeout 900 python tools/x3_energy.py > $O/x3_energy.txt 2> $O/x3_energy.err; tail -12 $O/x3_energy.txt;;
+    x3ab:*)
+      T=${STEP#x3ab:}; TAG=${T%%:*}; FL=${T#*:}
+      GNR_EXTRA_FILES="gnr_fwd3.hip,gnr_bwd3.hip" GNR_EXTRA_HIPCC_FLAGS="$FL" python -m gazenerf_amd.build --no-torch-ext > $O/x3ab_$TAG.build.log 2>&1
+      GNR_ALLOW_EXPERIMENTAL_LIB=1 timeout 900 python tools/x3_energy.py > $O/x3_energy_$TAG.txt 2> $O/x3_energy_$TAG.err; tail -12 $O/x3_energy_$TAG.txt
+      python -m gazenerf_amd.build --no-torch-ext > $O/x3ab_restore.log 2>&1;;
     *) echo "unknown step $STEP";;
   esac
 done
