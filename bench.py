@@ -379,28 +379,31 @@ def timed_loop(ctx, step, reset):
     reset(True)
     t0 = time.perf_counter()
     enq = 0.0
+    c0 = time.process_time()
     for _ in range(args.steps):
         e0 = time.perf_counter()
         step()                               # enqueues only: no host synchronisation inside a step
         enq += time.perf_counter() - e0
+    cpu = time.process_time() - c0           # user + system CPU time of this process (all its threads) over the steps' host code
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist:
-        tt = torch.tensor([dt, enq], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt, enq, cpu], device=dev, dtype=torch.float64)
         if ctx["backend"] != "nccl":
             tt = tt.cpu()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt, enq = float(tt[0].item()), float(tt[1].item())
-    # host_enqueue_ms_per_step: wall time of the step's host code up to its last launch (max over ranks).  Well below
-    # ms_per_step = the GPU is the bottleneck and the host runs ahead; equal to it = the rank is launch-bound (or the HIP
-    # queue is full and the host waits on the GPU -- both show up as the same number, which is why it is reported per leg
-    # beside the kernel-time sums)
+        dt, enq, cpu = float(tt[0].item()), float(tt[1].item()), float(tt[2].item())
+    # host_enqueue_ms_per_step (max over ranks): `ms` = wall time of the step's host code up to its last launch.  Well below
+    # ms_per_step = the host runs ahead of the GPU.  Equal to it = EITHER the rank is launch-bound OR the HIP queue is full and
+    # the launches block on the GPU (what a healthy GPU-bound step looks like once the queue has filled) -- `cpu_ms` tells them
+    # apart: the CPU time this process really spent on those launches.  cpu_ms well below ms_per_step = the host has slack.
     ctx["host"].setdefault("host_enqueue_ms_per_step", []).append(
-        {"leg": ctx.get("leg", "main"), "ms": enq / args.steps * 1e3, "ms_per_step": dt / args.steps * 1e3,
-         "share": enq / dt if dt > 0 else None})
+        {"leg": ctx.get("leg", "main"), "ms": enq / args.steps * 1e3, "cpu_ms": cpu / args.steps * 1e3,
+         "ms_per_step": dt / args.steps * 1e3, "share": enq / dt if dt > 0 else None,
+         "cpu_share": cpu / dt if dt > 0 else None})
     return dt
 
 
@@ -765,6 +768,7 @@ def run_cfg4(ctx):
 
     dt = timed_loop(ctx, step, reset)
     stage_ms = {k: t.collect() for k, t in timers.items()}
+    ar = dist_info(ctx, reducer, clock)       # (before the probe steps below reset the clock: round 4 read it afterwards -- 0 calls timed)
     # two more, untimed, steps with the shader-clock probe armed (as in the cfg2b legs): at this launch size every stage starts right
     # after lower-power kernels and pays the power management's transition dip -- the probe shows it
     reset(False)
@@ -844,7 +848,6 @@ def run_cfg4(ctx):
         "upsampler": upsampler,
         "outside_hot_path_ms": ms - sum(st["avg_ms"] * mult for st, mult in zip(stages, (1, 2, 2))),
     }
-    ar = dist_info(ctx, reducer, clock)
     if ar:
         res["allreduce"] = ar
     return res

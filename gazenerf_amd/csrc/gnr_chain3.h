@@ -35,18 +35,11 @@ __device__ __forceinline__ unsigned hi_pair(float a, float b) {                 
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 __device__ __forceinline__ unsigned lo_pair(float a, float b, unsigned hi) {    // 4 VALU
-#if (GNR_ABLATE & 256)      // round-5 experiment (same results): two scalar subtracts instead of one v_pk_add_f32 (a packed f32 op beside MFMAs
-                            // costs more than its issue slot, MI355X_MICROARCH.md) -- 5 VALU
-    float d0, d1;
-    asm volatile("v_sub_f32 %0, %2, %3\n\tv_sub_f32 %1, %4, %5" : "=&v"(d0), "=v"(d1)
-                 : "v"(a), "v"(__builtin_bit_cast(float, hi << 16)), "v"(b), "v"(__builtin_bit_cast(float, hi & 0xffff0000u)));
-    const f32x2 dv = {d0, d1};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(dv, bf16x2));
-#else
     const f32x2 v = {a, b};
     const f32x2 hf = {__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
+    // (round 5: two scalar v_sub_f32 instead of the packed subtract -- a packed f32 op beside MFMAs costs more than its issue slot --
+    // were measured: 5 VALU per pair instead of 4, bwd3_chain_kernel 12.67 -> 14.11 ms, 904.5 -> 925.2 J per step: profiles/r5_x3_energy.txt)
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v - hf, bf16x2));
-#endif
 }
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
     hi = hi_pair(a, b);

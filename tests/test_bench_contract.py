@@ -148,6 +148,7 @@ def test_world_size_8_rehearsal_through_the_self_launcher(what):
         assert d["config"]["trainable_floats"] == 5015714
         ar = d["allreduce"]
         assert ar["floats"] == 5015714 and ar["bytes"] == 4 * 5015714 and ar["buckets"] == 3 and ar["world_size_formed"] == 8
+        assert ar["calls_timed"] == 2 and ar["ms"] > 0
         assert abs(d["value"] - 8 * 2 * 4096 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     else:
         d = _run([sys.executable, "bench.py", "--gpus", "8", "--scaling", "strong", "--micro", "4096", "--steps", "1", "--warmup", "1",
@@ -160,6 +161,7 @@ def test_world_size_8_rehearsal_through_the_self_launcher(what):
     host = d["host"]
     enq = host["host_enqueue_ms_per_step"][0]
     assert 0 < enq["ms"] <= enq["ms_per_step"] * 1.001 and abs(enq["ms_per_step"] - d["ms_per_step"]) < 1e-6
+    assert 0 < enq["cpu_ms"] and 0 < enq["cpu_share"]
     aff = host["cpu_affinity"]                   # rank 0's block of the CPUs the job may use
     assert aff is not None and (aff.get("pinned") is False or aff["n_cpus"] >= 1)
 
@@ -167,7 +169,7 @@ def test_world_size_8_rehearsal_through_the_self_launcher(what):
 def test_host_enqueue_time_is_reported_at_one_rank():
     d = _run([sys.executable, "bench.py", "--side", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-one-call"])
     legs = {e["leg"]: e for e in d["host"]["host_enqueue_ms_per_step"]}
-    assert set(legs) == {"fp32", "bf16x3"} and all(0 < e["ms"] <= e["ms_per_step"] * 1.001 for e in legs.values())
+    assert set(legs) == {"fp32", "bf16x3"} and all(0 < e["ms"] <= e["ms_per_step"] * 1.001 and e["cpu_ms"] > 0 for e in legs.values())
     assert d["host"]["cpu_affinity"] is None           # one rank keeps the whole mask (the CPU baseline needs it)
     hb = d["roofline_hbm"]                             # priced on the algorithm's 258 channels, the layout's 288 beside it
     assert abs(hb["frac_incl_padding"] / hb["frac"] - hb["bytes_per_launch_incl_padding"] / hb["bytes_per_launch"]) < 1e-9

@@ -36,7 +36,7 @@ import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
     print(sys.argv[1].split('/')[-1], 'value %.1f' % d['value'], 'ms/step %.2f' % d['ms_per_step'], 'up', d.get('upsampler', {}).get('fwdbwd_ms'),
-          'frac %.3f' % d['roofline']['frac'], 'step_frac', d['roofline'].get('step_frac'), 'enq', [round(e['ms'], 2) for e in d.get('host', {}).get('host_enqueue_ms_per_step', [])], d.get('build'))
+          'frac %.3f' % d['roofline']['frac'], 'step_frac', d['roofline'].get('step_frac'), 'enq/cpu', [(round(e['ms'], 2), round(e.get('cpu_ms', 0), 2)) for e in d.get('host', {}).get('host_enqueue_ms_per_step', [])], d.get('build'))
 except Exception as e:
     print(sys.argv[1], 'ERR', e)
 P
