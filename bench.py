@@ -280,10 +280,37 @@ def chain_suffix(x3):
     return "3" if x3 else "16"
 
 
+_RESULT_FD = None
+
+
+def guard_stdout():
+    """stdout carries ONE JSON line.  Libraries write there too -- RCCL prints its NCCL_DEBUG=VERSION banner to the process's
+    stdout (whatever NCCL_DEBUG_FILE says: profiles/r5_bench_forced_rccl_ws1.json before this guard), buffered, i.e. BEHIND the
+    line -- so file descriptor 1 is pointed at stderr for the life of the process and the line goes to a duplicate of the
+    original descriptor."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_result(res):
+    line = (json.dumps(res) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+        return
+    view = memoryview(line)
+    while view:
+        view = view[os.write(_RESULT_FD, view):]
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args)
+    guard_stdout()
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -323,9 +350,8 @@ def main():
             if rank == 0 and world > 1:
                 print_topology(world)
             if backend == "nccl" and rank == 0:
-                # RCCL's version banner (and nothing else) into stderr of rank 0: stdout carries the one JSON line
+                # RCCL's version banner (and nothing else) from rank 0; it lands in stderr (guard_stdout)
                 os.environ.setdefault("NCCL_DEBUG", "VERSION")
-                os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
             timeout = datetime.timedelta(seconds=args.pg_timeout)      # a rank that never arrives fails the job, not hangs it
             if backend == "nccl":
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=timeout)
@@ -351,7 +377,7 @@ def main():
             if world == 1 and not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(args.mode if args.config == "cfg2b" else "fwdbwd", 64 if args.config == "cfg4" else args.samples,
                                                    args.cpu_budget)
-            print(json.dumps(res), flush=True)
+            emit_result(res)
     except BaseException as e:            # noqa: BLE001 -- every failure of a rank must end the job with ITS message
         if isinstance(e, SystemExit) and e.code in (0, None):
             raise

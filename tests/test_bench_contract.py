@@ -17,7 +17,7 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
 TWO_ON_ONE = {"GNR_BENCH_DEVICE": "0", "GNR_BENCH_BACKEND": "gloo"}
 
 
-def _run(cmd, env=None):
+def _run(cmd, env=None, strict=False):
     e = dict(os.environ)
     e.pop("WORLD_SIZE", None)
     e.update(env or {})
@@ -25,13 +25,15 @@ def _run(cmd, env=None):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]   # launcher / gloo chatter is not JSON
     assert len(lines) == 1, r.stdout[-2000:]
+    if strict:      # NOTHING but the line on stdout (round 5: RCCL's NCCL_DEBUG=VERSION banner used to follow it -- bench.guard_stdout)
+        assert r.stdout.strip() == lines[0].strip(), r.stdout[-2000:]
     return json.loads(lines[0])
 
 
 @pytest.mark.parametrize("mode", ["fwdbwd", "fwd"])
 def test_single_gpu_line(mode):
     extra = ["--cpu-budget", "6"] if mode == "fwd" else ["--no-cpu-baseline"]
-    d = _run([sys.executable, "bench.py", "--side", "64", "--steps", "2", "--warmup", "1", "--mode", mode] + extra)
+    d = _run([sys.executable, "bench.py", "--side", "64", "--steps", "2", "--warmup", "1", "--mode", mode] + extra, strict=True)
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
     assert d["unit"] == "rays/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
@@ -185,7 +187,7 @@ def test_a_one_rank_rccl_communicator_forms_and_carries_the_gradient_buckets():
     creates a communicator, exercises the hand-off between the compute stream and RCCL's, and shows whether
     HSA_ENABLE_IPC_MODE_LEGACY=0 is harmless."""
     d = _run([sys.executable, "bench.py", "--side", "64", "--steps", "2", "--warmup", "1", "--no-alt", "--no-cpu-baseline",
-              "--no-one-call"], env={"GNR_BENCH_FORCE_DIST": "1"})
+              "--no-one-call"], env={"GNR_BENCH_FORCE_DIST": "1"}, strict=True)
     dd = d["distributed"]
     assert dd["backend"] == "nccl" and dd["world_size_formed"] == 1 and dd["forced_at_world_size_1"] is True
     assert dd["rccl_version"] and dd["rccl_version"][0].isdigit()
@@ -195,7 +197,7 @@ def test_a_one_rank_rccl_communicator_forms_and_carries_the_gradient_buckets():
     assert d["n_gpus"] == 1 and abs(d["value"] - 64 * 64 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     # the same through the whole network: 3 buckets, the NeuralRenderer one launched from autograd hooks
     d = _run([sys.executable, "bench.py", "--config", "cfg4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
-             env={"GNR_BENCH_FORCE_DIST": "1"})
+             env={"GNR_BENCH_FORCE_DIST": "1"}, strict=True)
     assert d["distributed"]["backend"] == "nccl" and d["allreduce"]["floats"] == 5015714 and d["allreduce"]["buckets"] == 3
 
 
