@@ -1098,10 +1098,10 @@ UpChainPlan upchain_plan(int K1, int M1, int M2, long pixels_per_image) {
     UpChainPlan p{};
     if (g_forced_tile.load() || g_unshuffle_mt.load()) return p;
     const int t1 = (M1 + 15) / 16;
-    const int np = t1 == 8 ? ((GNR_C16_ABL & 256) ? 2 : 4) : 0;   // the one instance: 128 middle channels, 64 pixels per wave (256: experiment, 32 pixels)
+    const int np = t1 == 8 ? 4 : 0;                               // the one instance: 128 middle channels, 64 pixels per wave
     if (!np || pixels_per_image % (16 * WPB * np)) return p;
     // shuffle epilogue: four in-channels per out-channel, biases of both layers in LDS, one wrap of the residual row
-    if (M2 > 2 * 16 * t1 || M2 % 4 || M2 / 4 < 16 * (8 / np - 1) + 4) return p;        // (a slab's rows add at most 16 (MS - 1) + 3)
+    if (M2 > 2 * 16 * t1 || M2 % 4 || M2 / 4 < 16 * (8 / np) + 4) return p;
     p.T1 = t1; p.NP = np;
     p.nkb1 = (K1 + 15) / 16;
     const int ms = 8 / np;
@@ -1126,7 +1126,6 @@ int launch_upchain(const UpChainParams& cp, hipStream_t st) {
     const long groups = (long)cp.batch * cp.P / (16 * WPB * cp.plan.NP);
     const unsigned blocks = (unsigned)(8 * ((groups + 7) / 8));
     if (cp.plan.T1 == 8 && cp.plan.NP == 4) hipLaunchKernelGGL((upchain_kernel<8, 4>), dim3(blocks), dim3(64 * WPB), 0, st, cp);
-    else if (cp.plan.T1 == 8 && cp.plan.NP == 2 && (GNR_C16_ABL & 256)) hipLaunchKernelGGL((upchain_kernel<8, 2>), dim3(blocks), dim3(64 * WPB), 0, st, cp);
     else return fail("upchain: no instance for %d middle row tiles x %d pixel tiles", cp.plan.T1, cp.plan.NP);
     return 0;
 }

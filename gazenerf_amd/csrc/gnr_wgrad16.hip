@@ -7,8 +7,8 @@
 // 1032), so 516 x 258 filled 60 % of its tiles and 258 x 129 / 129 x 258 45 % (profiles/r3_n1_launches.txt: 0.37-0.53 of the
 // fp32-MFMA peak on these five products).  This kernel is conv16_kernel's recipe applied to the contraction over pixels:
 // no LDS, no barrier, independent waves, several per SIMD, operands straight from memory into v_mfma_f32_16x16x4_f32 --
-//   * a wave owns MT x NT tiles of 16 x 16 outputs over its split's pixels ((3,6) and (6,3): 516 = 11 x 48, 129 + 1 -> 3 x 48;
-//     258 + 1 = 17 tiles = 6 + 6 + 5: round 5, the waves of the last row / column group run a 5-tile body instead of padding);
+//   * a wave owns MT x NT tiles of 16 x 16 outputs over its split's pixels; padding is to multiples of 16 MT / 16 NT
+//     ((3,6) and (6,3): 516 = 11 x 48, 1032 = 11 x 96 - 24, 258 + 1 -> 3 x 96, 129 + 1 -> 3 x 48: <= 6 % in every product);
 //   * both operands are "rows of pixels": lane (li, g) loads pixels 16 h + 4 g .. + 3 of row li of each of its tiles (one
 //     b128 per tile per 16-pixel half step = 4 MFMA steps; the contraction order over the pixels is free), two operand
 //     sets, one half step ahead; three waves per SIMD (148 VGPRs).  Measured and dropped: 32-pixel steps with both halves of
@@ -43,62 +43,7 @@ constexpr int W16_OCC = 3;               // waves per SIMD (148 VGPRs)
 
 __device__ __forceinline__ f32x4 mfma16g(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-// One wave's product: MTV x NTV tiles of 16 x 16 (the full MT x NT of the instance, or the fewer tiles of the last row / column
-// group: round 5 -- until then every group ran MT x NT tiles and e.g. 516 x 259 = 33 x 17 tiles was computed as 33 x 18).
-template <int MTV, int NTV>
-__device__ __forceinline__ void wgrad16_body(const Wgrad16Params& wp, const __amdgpu_buffer_rsrc_t rsA, const __amdgpu_buffer_rsrc_t rsB,
-                                             unsigned row, unsigned tstride, int kb0, int nkb, float one_last, float* dst, long k_pad) {
-    f32x4 acc[MTV][NTV];
-#pragma unroll
-    for (int mt = 0; mt < MTV; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NTV; ++nt) acc[mt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-
-    f32x4 A1[2][MTV], B1[2][NTV];
-    auto load = [&](int kb, int half, f32x4 (&A)[MTV], f32x4 (&Bv)[NTV]) {
-        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((2 * (kb0 + kb) + half) * 64);
-        // the row-tile stride rides in the scalar offset: one address register per lane
-#pragma unroll
-        for (int mt = 0; mt < MTV; ++mt)
-            A[mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, row, (int)(so + (unsigned)mt * tstride), 0));
-#pragma unroll
-        for (int nt = 0; nt < NTV; ++nt)
-            Bv[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, row, (int)(so + (unsigned)nt * tstride), 0));
-    };
-    auto compute = [&](const f32x4 (&A)[MTV], const f32x4 (&Bv)[NTV]) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const float blast = Bv[NTV - 1][s] + one_last;
-#pragma unroll
-            for (int mt = 0; mt < MTV; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NTV; ++nt) acc[mt][nt] = mfma16g(A[mt][s], nt == NTV - 1 ? blast : Bv[nt][s], acc[mt][nt]);
-        }
-    };
-    if (nkb > 0) {                                                // 16-pixel half steps, two operand sets, one half ahead
-        load(0, 0, A1[0], B1[0]);
-        for (int kb = 0; kb < nkb; ++kb) {
-            load(kb, 1, A1[1], B1[1]);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(A1[0], B1[0]);
-            __builtin_amdgcn_sched_barrier(0);
-            load(kb + 1 < nkb ? kb + 1 : kb, 0, A1[0], B1[0]);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(A1[1], B1[1]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    // register e of acc[mt][nt]: row m0 + 16 mt + 4 g + e, column k0 + 16 nt + li
-#pragma unroll
-    for (int mt = 0; mt < MTV; ++mt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int nt = 0; nt < NTV; ++nt) dst[(long)(16 * mt + e) * k_pad + 16 * nt] = acc[mt][nt][e];
-}
-
-// MTL / NTL: the tiles of the LAST row / column group (mt16 - (mg - 1) MT, kt16 - (kg - 1) NT); every other group has MT / NT
-template <int MT, int NT, int MTL, int NTL>
+template <int MT, int NT>
 __global__ __launch_bounds__(64 * W16_WPB, W16_OCC) void wgrad16_kernel(const Wgrad16Params wp) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -128,19 +73,59 @@ __global__ __launch_bounds__(64 * W16_WPB, W16_OCC) void wgrad16_kernel(const Wg
     const unsigned row = ((unsigned)li * (unsigned)wp.P + 4u * (unsigned)g) * 4u;       // this lane's row / pixel quad inside a tile
     const unsigned tstride = (unsigned)__builtin_amdgcn_readfirstlane((int)(16u * (unsigned)wp.P * 4u));     // bytes between row tiles
 
-    // the bias column is the LAST column of the padded product (the host pads to at least one column past K): the last tile,
-    // lane 15, of the waves of the last column group -- 1.0 is added to the zeros the descriptor's bound returns there
-    const bool lastm = mgi == wp.mg - 1, lastk = kgi == wp.kg - 1;
-    const float one_last = (wp.ones_col >= 0 && lastk && li == 15) ? 1.0f : 0.0f;
-    const long k_pad = 16L * ((long)(wp.kg - 1) * NT + NTL), n_pad = 16L * ((long)(wp.mg - 1) * MT + MTL);
-    float* dst = wp.partial + ((long)split * n_pad + m0 + 4 * g) * k_pad + k0 + li;
-    if (MTL != MT && lastm) {
-        if (NTL != NT && lastk) wgrad16_body<MTL, NTL>(wp, rsA, rsB, row, tstride, kb0, nkb, one_last, dst, k_pad);
-        else wgrad16_body<MTL, NT>(wp, rsA, rsB, row, tstride, kb0, nkb, one_last, dst, k_pad);
-    } else {
-        if (NTL != NT && lastk) wgrad16_body<MT, NTL>(wp, rsA, rsB, row, tstride, kb0, nkb, one_last, dst, k_pad);
-        else wgrad16_body<MT, NT>(wp, rsA, rsB, row, tstride, kb0, nkb, one_last, dst, k_pad);
+    // the bias column is the LAST column of the padded product (the host pads to at least one column past K): tile NT - 1,
+    // lane 15 of the waves of the last column group -- 1.0 is added to the zeros the descriptor's bound returns there
+    const float one_last = (wp.ones_col >= 0 && kgi == wp.kg - 1 && li == 15) ? 1.0f : 0.0f;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    f32x4 A1[2][MT], B1[2][NT];
+    auto load = [&](int kb, int half, f32x4 (&A)[MT], f32x4 (&Bv)[NT]) {
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((2 * (kb0 + kb) + half) * 64);
+        // the row-tile stride rides in the scalar offset: one address register per lane
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            A[mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, row, (int)(so + (unsigned)mt * tstride), 0));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            Bv[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, row, (int)(so + (unsigned)nt * tstride), 0));
+    };
+    auto compute = [&](const f32x4 (&A)[MT], const f32x4 (&Bv)[NT]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float blast = Bv[NT - 1][s] + one_last;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16g(A[mt][s], nt == NT - 1 ? blast : Bv[nt][s], acc[mt][nt]);
+        }
+    };
+    if (nkb > 0) {                                                // 16-pixel half steps, two operand sets, one half ahead
+        load(0, 0, A1[0], B1[0]);
+        for (int kb = 0; kb < nkb; ++kb) {
+            load(kb, 1, A1[1], B1[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(A1[0], B1[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            load(kb + 1 < nkb ? kb + 1 : kb, 0, A1[0], B1[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(A1[1], B1[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
+    // register e of acc[mt][nt]: row m0 + 16 mt + 4 g + e, column k0 + 16 nt + li
+    const long n_pad = (long)wp.mg * (16 * MT), k_pad = (long)wp.kg * (16 * NT);
+    float* dst = wp.partial + ((long)split * n_pad + m0 + 4 * g) * k_pad + k0 + li;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) dst[(long)(16 * mt + e) * k_pad + 16 * nt] = acc[mt][nt][e];
 }
 
 
@@ -170,12 +155,7 @@ bool launch_wgrad16_img(const float* A, int M, const float* B, int K, int batch,
     wp.A = A; wp.B = B; wp.M = M; wp.K = K; wp.P = (int)P; wp.batch = batch;
     wp.mg = (mt16 + MT - 1) / MT; wp.kg = (kt16 + NT - 1) / NT;
     wp.ones_col = bias_out ? 1 : -1;
-    // the last row / column group runs only the tiles that exist, when there is an instance for that remainder (the reference's
-    // channel counts: 17 = 6 + 6 + 5 tiles; anything else keeps whole groups, i.e. pads to a multiple of MT / NT tiles)
-    int MTL = mt16 - (wp.mg - 1) * MT, NTL = kt16 - (wp.kg - 1) * NT;
-    if (!((o36 && MTL == 3 && NTL == 5) || (!o36 && MTL == 5 && NTL == 3))) { MTL = MT; NTL = NT; }
-    const long n_pad = 16L * ((wp.mg - 1) * MT + MTL), k_pad = 16L * ((wp.kg - 1) * NT + NTL);
-    const long tiles = (long)wp.mg * wp.kg, area = n_pad * k_pad;
+    const long tiles = (long)wp.mg * wp.kg, area = (long)wp.mg * 16 * MT * wp.kg * 16 * NT;
     const long kb_img = P / 32;
     // one round of waves: 1024 SIMDs x 2 waves
     long spi = 1024 * W16_OCC / (tiles * batch);
@@ -193,12 +173,10 @@ bool launch_wgrad16_img(const float* A, int M, const float* B, int K, int batch,
     wp.partial = scratch;
     const long witems = (long)batch * wp.spi * tiles, wg_items = (witems + W16_WPB - 1) / W16_WPB;
     const unsigned blocks = (unsigned)(8 * ((wg_items + 7) / 8));
-    if (o36 && NTL == 5) hipLaunchKernelGGL((wgrad16_kernel<3, 6, 3, 5>), dim3(blocks), dim3(64 * W16_WPB), 0, st, wp);
-    else if (o36) hipLaunchKernelGGL((wgrad16_kernel<3, 6, 3, 6>), dim3(blocks), dim3(64 * W16_WPB), 0, st, wp);
-    else if (MTL == 5) hipLaunchKernelGGL((wgrad16_kernel<6, 3, 5, 3>), dim3(blocks), dim3(64 * W16_WPB), 0, st, wp);
-    else hipLaunchKernelGGL((wgrad16_kernel<6, 3, 6, 3>), dim3(blocks), dim3(64 * W16_WPB), 0, st, wp);
+    if (o36) hipLaunchKernelGGL((wgrad16_kernel<3, 6>), dim3(blocks), dim3(64 * W16_WPB), 0, st, wp);
+    else hipLaunchKernelGGL((wgrad16_kernel<6, 3>), dim3(blocks), dim3(64 * W16_WPB), 0, st, wp);
     Wgrad16ReduceParams rp{};
-    rp.partial = scratch; rp.splits = batch * wp.spi; rp.n_pad = n_pad; rp.k_pad = k_pad;
+    rp.partial = scratch; rp.splits = batch * wp.spi; rp.n_pad = (long)wp.mg * 16 * MT; rp.k_pad = (long)wp.kg * 16 * NT;
     rp.M = M; rp.K = K; rp.dW = dW; rp.ldw = ldw; rp.bias = bias_out;
     const long total = (long)M * kw;
     if (defer) wgrad_defer_push16(defer, rp, (unsigned)((total + 255) / 256));
