@@ -50,7 +50,7 @@ HBM_PEAK_GBS = 8000.0
 HBM_STREAM_GBS = 6290.0                       # measured float4 copy on MI355X (same table): what a streaming kernel can reach
 PEAK_CLOCK_MHZ = 2400.0                       # the clock both MFMA peaks are quoted at
 # the weight-gradient stage: its main kernel instance first (the 384^2 layers), then what else runs inside the bracket
-WGRAD_KERNEL = {False: "gnr::wgrad2w_kernel<false, false> + its other instances + gnr::wgrad_pipe_kernel<3, 1, false, 2> + gnr::wgrad_reduce_batch_kernel (one launch for the 13 split-K reductions)",
+WGRAD_KERNEL = {False: "gnr::wgrad2w_kernel<false, false, 6, 3> + its other instances (<.., 3, 3>: 96 x 192, <.., 6, 1>: 192 x 64) + gnr::wgrad_reduce_batch_kernel (one launch for the 13 split-K reductions)",
                 True: "gnr::wgrad3_tr_kernel<3, false> + its other instances + gnr::wgrad_reduce_batch_kernel"}
 
 

@@ -12,10 +12,11 @@
 // pass and the ds_read_b128 of the MFMA pass bank-conflict free (MI355X LDS: 64 banks for b128,
 // non-contiguous 16-lane groups).
 //
-// Two kernels share that operand scheme:
-//   wgrad_pipe_kernel  chunk-channel-major operands (the whole MLP): ONE software-pipelined workgroup per CU,
-//                      192-row tiles, LDS-DMA ring, operand prefetch -- see its header below;
-//   wgrad_kernel       everything else (the upsampler's channels-first images): WN x WK waves of XN x XK MFMA tiles,
+// Two fp32 kernels share that operand scheme (wgrad3_tr_kernel is the bf16x3 one):
+//   wgrad2w_kernel     the whole MLP (and the upsampler's 1032 x 516 product): ONE software-pipelined workgroup per CU, eight
+//                      waves on 16x16x4 MFMAs, LDS-DMA ring, operand prefetch; 192 x 192, 96 x 192 and 192 x 64 tiles -- see
+//                      its header below;
+//   wgrad_kernel       the upsampler's narrow channels-first products: WN x WK waves of XN x XK MFMA tiles,
 //                      i.e. a (32 XN WN) x (32 XK WK) workgroup tile chosen per shape by padded work
 //                          128 x 128  (2x2 waves of 2x2)      192 x 64 / 64 x 192  (2x2 waves of 3x1 / 1x3)
 //                           96 x  96  (3x1 waves of 1x3)
@@ -29,7 +30,7 @@
 // Riding along: column sums of dY (bias gradients, per image) and vec^T X for a per-sample vector (density-head
 // gradient).  wgrad_kernel takes them from the operand registers between the MFMAs, in every workgroup (GNR_WG_RIDERS
 // below: with two workgroups per CU that is free, and a single round of workgroups ends with its slowest member);
-// wgrad_pipe_kernel shares them between the waves that hold the same rows.
+// wgrad2w_kernel shares them between the waves that hold the same rows.
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -46,7 +47,7 @@ namespace gnr {
 //                  fastest -- a single round of workgroups ends with its slowest member, and in this two-workgroups-
 //                  per-CU kernel a few VALU adds between the MFMAs cost nothing: 384^2 layer 2.65 / 2.77 / 2.92 /
 //                  2.99 ms for modes 3 / 1 / 2 / 0)
-//   GNR_PIPE_ABL   timing experiments on wgrad_pipe_kernel, see there
+//   GNR_PIPE_ABL   timing experiments on wgrad2w_kernel, see there
 #ifndef GNR_WG_RIDERS
 #define GNR_WG_RIDERS 3
 #endif
@@ -313,258 +314,19 @@ __global__ __launch_bounds__(64 * WN * WK, 2) void wgrad_kernel(const WgradParam
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// wgrad_pipe_kernel: the same GEMM as ONE software-pipelined workgroup per CU (chunk-channel-major operands).
-//
-// Why: in wgrad_kernel every chunk ends with [wait for the global loads, ds_write_b128 x8, barrier, ds_read_b128 x16,
-// wait] before the next MFMA -- ~1350 matrix-pipe cycles per 4096-cycle chunk when a workgroup runs alone on a CU
-// (measured, tools/ubench/wgrad_bench.hip), and the second resident workgroup hides only ~950 of them.  Here one wave
-// per SIMD owns the whole 512-entry register file and nothing waits:
-//   * 2x2 waves of XN x XK MFMA tiles: 3x3 for the 384^2 layers = a 192 x 192 workgroup tile: 144 accumulator
-//     registers, 24 ds_read_b128 per 144 MFMAs (wgrad_kernel: 16 per 64) and 85 staged bytes per MFMA (128);
-//   * the operands of chunk c+1 are read into a SECOND register set underneath the MFMAs of chunk c;
-//   * chunk c+2 arrives by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB per wave instruction, XOR swizzle applied to
-//     the source address) into a ring of three LDS buffers (144 KiB): a DMA has a whole chunk period (~4 us) to
-//     land, and there are no staging registers, no ds_write, no vmcnt wait in front of anything;
-//   * one s_waitcnt vmcnt(0) + s_barrier per chunk, placed where the matrix pipe still has the last MFMAs queued.
-// Riders (bias column sums, density-head dot) come from the operand registers as masked FMAs, the same in every
-// wave and workgroup (a single round of workgroups ends with its slowest member): the 2 tiles_k waves-columns that
-// hold the same dY rows share the 16 k-steps of a lane-half between them (mask per 4-step group), likewise the
-// 2 tiles_n wave-rows for the density vector; wgrad_reduce_kernel adds the shares.
-// ---------------------------------------------------------------------------------------------
 #ifndef GNR_PIPE_ABL
-#define GNR_PIPE_ABL 0      // timing experiments (wrong results): 1 no riders, 2 no DMA requests in the loop, 4 no per-chunk wait + barrier
+#define GNR_PIPE_ABL 0      // timing experiments on wgrad2w_kernel (wrong results): 1 no riders, 2 no DMA requests in the loop, 4 no per-chunk wait + barrier
 #endif
 constexpr int PABL = GNR_PIPE_ABL;
 
-template <int XN, int XK, bool VEC, int CSG>
-__global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradParams wp) {
-    constexpr int TN = 64 * XN, TK = 64 * XK;
-    constexpr int BUF_BYTES = (TN + TK) * CHUNK * 4;
-    constexpr int PA = TN / 8 / 4, PB = TK / 8 / 4;               // 1 KiB DMA pieces per wave per chunk
-    __shared__ __attribute__((aligned(1024))) char lds[3 * BUF_BYTES];
-    const int tiles = wp.tiles_n * wp.tiles_k;
-    const int id = blockIdx.x;
-    const int xcd = id & 7, slot = id >> 3;
-    const int split = xcd + 8 * (slot / tiles);
-    const int tile = slot % tiles;
-    if (split >= wp.batch * wp.spi) return;
-    const int tn = tile / wp.tiles_k, tk = tile - tn * wp.tiles_k;
-    const ClkProbe clk0 = clk_begin();
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave >> 1, wk = wave & 1;
-    const int li = lane & 31, lh = lane >> 5;
-    const int b = split / wp.spi, sp = split - b * wp.spi;
-    const long c0 = (long)b * wp.chunks_per_image + (long)sp * wp.chunks_per_split;
-    long c1 = c0 + wp.chunks_per_split;
-    const long cmax = (long)(b + 1) * wp.chunks_per_image;
-    if (c1 > cmax) c1 = cmax;
-    const int nchunks = (int)(c1 - c0);
-
-    // LDS-DMA: descriptor per operand with base = first chunk of this split, tile row 0; num_records = end of the
-    // split, so requests for chunks past it return zeros (no tail branches).
-    const unsigned chunk_a = (unsigned)(wp.lda * CHUNK * 4), chunk_b = (unsigned)(wp.ldb * CHUNK * 4);
-    auto desc = [&](const float* base, long ld, long tile_row0, unsigned chunk_bytes, int s16) {
-        const long row0 = tile_row0 * (s16 ? 16 : CHUNK);          // floats from the chunk's start to the tile's first row
-        const unsigned long long a = (unsigned long long)(base + c0 * (CHUNK * ld) + row0);
-        long bytes = (long)nchunks * chunk_bytes - row0 * 4;
-        if (bytes < 0) bytes = 0;
-        i32x4 r;
-        r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-        r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
-        r.z = __builtin_amdgcn_readfirstlane((int)(unsigned)bytes);
-        r.w = 0x00020000;
-        return r;
-    };
-    const i32x4 rsa = desc(wp.A, wp.lda, (long)tn * TN, chunk_a, wp.a_s16);
-    const i32x4 rsb = desc(wp.B, wp.ldb, (long)tk * TK, chunk_b, wp.b_s16);
-    // lane l fills slot l%8 of row 8i + l/8 with source piece (l%8) ^ ((4i + l/16) % 8): odd i = the piece index ^ 4
-    const int pe = (lane & 7) ^ (lane >> 4);
-    const unsigned voff_even_c = (unsigned)(lane >> 3) * 128u + (unsigned)pe * 16u, voff_odd_c = voff_even_c ^ 64u;      // rows of 32 samples
-    const unsigned voff_even_a = wp.a_s16 ? s16_lane_off(lane >> 3, pe, wp.lda) : voff_even_c;
-    const unsigned voff_odd_a = wp.a_s16 ? s16_lane_off(lane >> 3, pe ^ 4, wp.lda) : voff_odd_c;
-    const unsigned voff_even_b = wp.b_s16 ? s16_lane_off(lane >> 3, pe, wp.ldb) : voff_even_c;
-    const unsigned voff_odd_b = wp.b_s16 ? s16_lane_off(lane >> 3, pe ^ 4, wp.ldb) : voff_odd_c;
-    const unsigned lds0 = (unsigned)(size_t)&lds[0];
-    // scalar source offset of this wave's piece j inside a chunk
-    unsigned poff[PA + PB];
-#pragma unroll
-    for (int j = 0; j < PA + PB; ++j) {
-        const bool isa = j < PA;
-        const unsigned i = (unsigned)(isa ? wave * PA + j : wave * PB + (j - PA));
-        poff[j] = (isa ? wp.a_s16 : wp.b_s16) ? s16_piece_off(i) : i * 1024u;
-    }
-    // piece j (0 .. PA+PB-1) of this wave's share of chunk c0 + k, into ring buffer `buf`
-    auto dma_piece = [&](int k, int buf, int j) {
-        const bool isa = j < PA;
-        const unsigned i = (unsigned)(isa ? wave * PA + j : wave * PB + (j - PA));
-        const unsigned l = lds0 + (unsigned)buf * BUF_BYTES + (isa ? 0u : (unsigned)(TN * CHUNK * 4)) + i * 1024u;
-        const unsigned so = (unsigned)k * (isa ? chunk_a : chunk_b) + poff[j];
-        unsigned keep;
-        if (isa)
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"((i & 1) ? voff_odd_a : voff_even_a), "s"(rsa), "s"(l), "s"(so) : "memory");
-        else
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"((i & 1) ? voff_odd_b : voff_even_b), "s"(rsb), "s"(l), "s"(so) : "memory");
-    };
-    auto dma_chunk = [&](int k, int buf) {
-#pragma unroll
-        for (int j = 0; j < PA + PB; ++j) dma_piece(k, buf, j);
-    };
-
-    // operand read offsets (bytes within a ring buffer): rows wn*32*XN + 32x + li (A) / wk*32*XK + 32y + li (B).
-    // The swizzle term depends on (row/2)%8 = (li/2)%8 only, so tile x is a constant +4096 bytes (an instruction
-    // offset): four address registers per operand.
-    //
-    // Rider shares without masks: the contraction order is free, so every wave reads the four 4-step groups of its
-    // lane-half in an order ROTATED by rot (the same for A and B): group slot g holds samples 16 lh + 4 ((g + rot) % 4).
-    // The riders then always take slot(s) g < CSG (static code, 12 CSG FMAs per chunk instead of 48 masked ones:
-    // every VALU instruction between two fp32 MFMAs costs ~13 matrix-pipe cycles, measured), and the rotation makes
-    // the slots of the waves that hold the same rows cover different samples:
-    //   dY rows (tn, wn) are held by the 2 tiles_k wave columns qc = 2 tk + wk: CSG = 4 / (2 tiles_k) slots each;
-    //   X rows (tk, wk) by the 2 tiles_n wave rows qv = 2 tn + wn (VEC: tiles_n = tiles_k = 2, one slot each);
-    //   rot = (qc CSG + qv) % 4 is distinct along either family.
-    const int qc = tk * 2 + wk, qv = tn * 2 + wn;
-    const int rot = (qc * CSG + (VEC ? qv : 0)) & 3;
-    int apos[4], bpos[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        apos[g] = 4 * swz(wn * 32 * XN + li, 4 * lh + ((g + rot) & 3));
-        bpos[g] = 4 * (TN * CHUNK + swz(wk * 32 * XK + li, 4 * lh + ((g + rot) & 3)));
-    }
-    float csl[XN], vsl[XK];
-#pragma unroll
-    for (int x = 0; x < XN; ++x) csl[x] = 0.0f;
-#pragma unroll
-    for (int y = 0; y < XK; ++y) vsl[y] = 0.0f;
-    f32x16 acc[XN][XK];
-#pragma unroll
-    for (int x = 0; x < XN; ++x)
-#pragma unroll
-        for (int y = 0; y < XK; ++y)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.0f;
-
-    f32x4 opa[2][XN][4], opb[2][XK][4], vv[2][1];
-    auto read_ops = [&](int buf, f32x4 (&a)[XN][4], f32x4 (&bb)[XK][4], int g) {
-        const char* pa = lds + buf * BUF_BYTES + apos[g];
-        const char* pb = lds + buf * BUF_BYTES + bpos[g];
-#pragma unroll
-        for (int x = 0; x < XN; ++x) a[x][g] = *(const f32x4*)(pa + x * (32 * CHUNK * 4));
-#pragma unroll
-        for (int y = 0; y < XK; ++y) bb[y][g] = *(const f32x4*)(pb + y * (32 * CHUNK * 4));
-    };
-    auto load_vec = [&](int k, f32x4 (&v)[1]) {
-        if (VEC) {
-            const long c = c0 + (k < nchunks ? k : nchunks - 1);
-            v[0] = *(const f32x4*)(wp.vec + c * CHUNK + 16 * lh + 4 * rot);        // the samples of slot 0
-        }
-    };
-
-    // prologue: chunks 0 and 1 in flight; chunk 0's operands into register set 0
-    dma_chunk(0, 0);
-    dma_chunk(1, 1);
-    load_vec(0, vv[0]);
-    wait_vm_dma<PA + PB>();                                 // everything but the last chunk's pieces
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int g = 0; g < 4; ++g) read_ops(0, opa[0], opb[0], g);
-
-    // One chunk: [chunk k+1 landed -> barrier -> request chunk k+2] then 16 MFMA steps of chunk k from register set S
-    // with the operand reads of chunk k+1 into set S^1 placed in front of each 4-step group.
-    auto chunk = [&](int k, int b1, int b2, auto set_tag) {
-        constexpr int S = decltype(set_tag)::value;
-        if (!(PABL & 4)) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // chunk k+1 (requested one chunk ago) has landed
-            __builtin_amdgcn_s_barrier();                         // ... in every wave; ring buffer b2 is free
-        }
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            __builtin_amdgcn_sched_barrier(0);
-            read_ops(b1, opa[S ^ 1], opb[S ^ 1], g);
-            // the density vector of chunk k+1: requested AFTER this chunk's last DMA piece and first used right
-            // behind the next chunk's vmcnt(0), before that chunk's first piece -- the compiler's own counted wait
-            // for it (it cannot see the asm requests sharing the in-order vmcnt queue) then never waits on a DMA
-            if (g == 3) load_vec(k + 1, vv[S ^ 1]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                for (int x = 0; x < XN; ++x)
-#pragma unroll
-                    for (int y = 0; y < XK; ++y) acc[x][y] = mfma32(opa[S][x][g][e], opb[S][y][g][e], acc[x][y]);
-                if (!(PABL & 1) && g < CSG) {
-#pragma unroll
-                    for (int x = 0; x < XN; ++x) csl[x] += opa[S][x][g][e];
-                    if (VEC && g == 0) {
-#pragma unroll
-                        for (int y = 0; y < XK; ++y) vsl[y] = fmaf(vv[S][0][e], opb[S][y][g][e], vsl[y]);
-                    }
-                    // the rider adds go between the MFMAs, not in one block
-#pragma unroll
-                    for (int i = 0; i < XN; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, XK, 0);          // XK MFMAs
-                        __builtin_amdgcn_sched_group_barrier(0x002, VEC ? 2 : 1, 0);   // rider VALU
-                    }
-                }
-                // the request for chunk k+2 goes out one piece per MFMA step (an LDS-DMA instruction blocks the
-                // issuing wave for ~60 cycles: twelve in a row would drain the matrix pipe at every chunk start)
-                if (4 * g + e < PA + PB && !(PABL & 2)) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    dma_piece(k + 2, b2, 4 * g + e);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-    };
-    int b0 = 0;                                             // ring buffer of chunk k
-    for (int k = 0; k < nchunks; k += 2) {
-        const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;
-        chunk(k, b1, b2, std::integral_constant<int, 0>{});
-        if (k + 1 < nchunks) chunk(k + 1, b2, b0, std::integral_constant<int, 1>{});
-        b0 = b2;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the zero-filled tail requests
-
-    clk_end(clk0, wp.clk);
-    float* pt = wp.partial + (((long)split * wp.tiles_n + tn) * wp.tiles_k + tk) * (long)(TN * TK);
-#pragma unroll
-    for (int x = 0; x < XN; ++x)
-#pragma unroll
-        for (int y = 0; y < XK; ++y)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = wn * 32 * XN + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int jx = wk * 32 * XK + y * 32 + li;
-                pt[i * TK + jx] = acc[x][y][r];
-            }
-    // rider shares: colsum_part[split][q][tiles_n*TN], vec_part[split][q'][tiles_k*TK]
-    {
-        const int Qc = wp.tiles_k * 2, Qv = wp.tiles_n * 2;
-#pragma unroll
-        for (int x = 0; x < XN; ++x) {
-            const float t = csl[x] + __shfl_xor(csl[x], 32);
-            if (lh == 0) wp.colsum_part[((long)split * Qc + qc) * (wp.tiles_n * TN) + tn * TN + wn * 32 * XN + 32 * x + li] = t;
-        }
-        if (VEC) {
-#pragma unroll
-            for (int y = 0; y < XK; ++y) {
-                const float t = vsl[y] + __shfl_xor(vsl[y], 32);
-                if (lh == 0) wp.vec_part[((long)split * Qv + qv) * (wp.tiles_k * TK) + tk * TK + wk * 32 * XK + 32 * y + li] = t;
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// wgrad2w_kernel (round 3): wgrad_pipe_kernel's 192 x 192 workgroup tile, LDS-DMA ring of three buffers, split / partial
-// / rider-share layout -- with EIGHT waves (two per SIMD) of 96 x 48 on v_mfma_f32_16x16x4_f32 instead of four waves of
-// 96 x 96 on 32x32x2.  Why: with one wave per SIMD every ds_read / LDS-DMA / rider instruction between two MFMAs stalls
-// the matrix pipe (~13 cycles each; ablations of wgrad_pipe_kernel: reads + loop 2.8 %, DMA issue 1.4 %, riders 1.6 %);
+// wgrad2w_kernel (round 3): ONE software-pipelined workgroup per CU on a 192 x 192 tile -- operands of chunk c + 2 arrive by
+// LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB per wave instruction, XOR swizzle applied to the source address) into a ring of
+// three LDS buffers, the operands of the next slot are read into a second register set underneath the current slot's MFMAs, one
+// s_waitcnt vmcnt(0) + s_barrier per chunk -- with EIGHT waves (two per SIMD) of 96 x 48 on v_mfma_f32_16x16x4_f32.  (Round 2's
+// wgrad_pipe_kernel ran the same pipeline with four waves of 96 x 96 on 32x32x2; round 5 moved its last shape, the 64 encoding
+// columns, here and removed it: HISTORY.md 3.3.)  Why two waves: with one wave per SIMD every ds_read / LDS-DMA / rider
+// instruction between two MFMAs stalls the matrix pipe (~13 cycles each; ablations: reads + loop 2.8 %, DMA issue 1.4 %, riders 1.6 %);
 // with a second wave on the SIMD those issue beside the other wave's MFMAs (tools/ubench/mfma_2w.hip) and a VALU
 // instruction costs ~4.  A wave's registers: 72 accumulators (6 x 3 tiles of 16 x 16) + 2 x 36 operand registers.
 //
@@ -583,13 +345,26 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgradParams wp
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ f32x4 mfma16w(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-template <bool VEC, bool CS2>
+// XA = 16-row tiles per wave in the row direction: 6 = the 192 x 192 workgroup tile; 3 (round 5) = a 96 x 192 tile of 48 x 48
+// waves for RGB_layer_2's 66 rows beyond its first 192 (until then a 96 x 96 tile of wgrad_kernel: 0.87 ms at 0.58 of the matrix
+// pipe per 2 M samples).  Its 36 DMA pieces per chunk do not divide by the eight waves: the first wave of every SIMD takes
+// five, the second four -- the same split as the de-phasing (PH) of the loop, so every count stays a compile-time constant.
+// XB = 16-column tiles per wave: 3 = 192 columns; 1 (round 5) = a 192 x 64 tile of 96 x 16 waves for the two 384 x 64 encoding-column
+// products per weight set (until then wgrad_pipe_kernel<3, 1, false, 2>, one wave per SIMD: 0.87 ms at 0.78 of the matrix pipe).
+// NB = LDS ring buffers.  3: chunk k + 2 is requested during chunk k (one chunk period = 3.8 us of lead on the 192 x 192 tile).  The
+// 192 x 64 tile's chunk period is 1.3 us and its traffic 10.7 bytes per CU and clock: with one 32 KiB chunk in flight per CU the
+// kernel waited on HBM latency (0.795 ms = 4.65 TB/s); NB = 4 keeps two in flight (chunk k + 3 requested during chunk k).
+template <bool VEC, bool CS2, int XA = 6, int XB = 3, int NB = 3>
 __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
-    constexpr int TN = 192, TK = 192, WKG = 4;                    // wave grid 2 (rows) x 4 (columns): 96 x 48 per wave
-    constexpr int XA = 6, XB = 3;                                 // 16-row tiles per wave
-    constexpr int BUF_BYTES = (TN + TK) * CHUNK * 4;              // 48 KiB
-    constexpr int NPIECE = BUF_BYTES / 1024 / 8;                  // 6 DMA pieces of 1 KiB per wave per chunk
-    __shared__ __attribute__((aligned(1024))) char lds[3 * BUF_BYTES];
+    static_assert(!VEC || NB == 3, "the density-vector loads share the in-order vmcnt queue: counted for a ring of three");
+    constexpr int TN = 32 * XA, TK = 64 * XB, WKG = 4;            // wave grid 2 (rows) x 4 (columns): (16 XA) x (16 XB) per wave
+    constexpr int WR = 16 * XA, WC = 16 * XB;                     // rows / columns per wave
+    constexpr int BUF_BYTES = (TN + TK) * CHUNK * 4;              // 48 KiB (XA = 3: 36 KiB)
+    constexpr int NP_ALL = BUF_BYTES / 1024;                      // DMA pieces of 1 KiB per chunk
+    constexpr int NP0 = (NP_ALL + 7) / 8, NP1 = (NP_ALL + 3) / 8; // ... of a wave with wave < 4 / wave >= 4 (piece 8 j + wave < NP_ALL)
+    constexpr int NPIECE = NP0;
+    static_assert(NP_ALL % 4 == 0 && (TN / 8) % 4 == 0, "the four waves of a phase group take pieces of the same operand");
+    __shared__ __attribute__((aligned(1024))) char lds[NB * BUF_BYTES];
     const int tiles = wp.tiles_n * wp.tiles_k;
     const int id = blockIdx.x;
     const int xcd = id & 7, slot = id >> 3;
@@ -653,7 +428,7 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
     };
     const i32x4 rsa = desc(wp.A, wp.lda, (long)tn * TN, kstride_a, wp.n_valid, wp.a_row, wp.a_img, wp.a_s16);
     const i32x4 rsb = desc(wp.B, wp.ldb, (long)tk * TK, kstride_b, wp.k_valid, wp.b_row, wp.b_img, wp.b_s16);
-    // lane l fills slot l%8 of row 8i + l/8 with source piece (l%8) ^ ((4i + l/16) % 8)   (as wgrad_pipe_kernel): odd i =
+    // lane l fills slot l%8 of row 8i + l/8 with source piece (l%8) ^ ((4i + l/16) % 8): odd i =
     // the piece index ^ 4
     const int pe = (lane & 7) ^ (lane >> 4);
     const unsigned vpiece = (unsigned)pe * 16u;
@@ -664,17 +439,18 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
     const unsigned lds0 = (unsigned)(size_t)&lds[0];
     constexpr int PA = TN / 8;                                    // A pieces per chunk (24), then TK / 8 B pieces
     // scalar source offset of this wave's piece j inside a chunk (piece i = 8 rows of the tile)
+    const int wave_hi = wave >= 4 ? 4 : 0;                        // pieces 8 j + wave_hi .. + 3 belong to this wave's phase group
     unsigned poff[NPIECE];
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) {
-        const bool isa = 8 * j < PA;
+        const bool isa = 8 * j + wave_hi < PA;
         const unsigned i = isa ? (unsigned)(8 * j + wave) : (unsigned)(8 * j + wave) - PA;
         poff[j] = (isa ? wp.a_s16 : wp.b_s16) ? s16_piece_off(i) : i * (isa ? pstride_a : pstride_b);
     }
-    // piece j (0 .. NPIECE-1) of this wave's share of chunk c0 + k, into ring buffer `buf`: global piece index 8 j + wave
-    auto dma_piece = [&](int k, int buf, int j) {
+    // piece j of this wave's share of chunk c0 + k, into ring buffer `buf`: global piece index 8 j + wave.  isa (an A piece?) is
+    // the caller's: a compile-time constant inside the loop (j and the phase group are), a uniform branch in the prologue
+    auto dma_piece = [&](int k, int buf, int j, bool isa) {
         const unsigned gp = (unsigned)(8 * j + wave);
-        const bool isa = 8 * j < PA;                              // static after unrolling (PA = 24: j < 3): no branch
         const unsigned i = isa ? gp : gp - PA;
         const unsigned l = lds0 + (unsigned)buf * BUF_BYTES + (isa ? 0u : (unsigned)(TN * CHUNK * 4)) + i * 1024u;
         const unsigned so = (unsigned)k * (isa ? kstride_a : kstride_b) + poff[j];
@@ -686,9 +462,13 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"((i & 1) ? voff_odd_b : voff_even_b), "s"(rsb), "s"(l), "s"(so) : "memory");
     };
-    auto dma_chunk = [&](int k, int buf) {
+    auto dma_chunk = [&](int k, int buf) {                        // prologue only
 #pragma unroll
-        for (int j = 0; j < NPIECE; ++j) dma_piece(k, buf, j);
+        for (int j = 0; j < NPIECE; ++j)
+            if (8 * j + wave_hi < NP_ALL) {
+                if (8 * j + wave_hi < PA) dma_piece(k, buf, j, true);
+                else dma_piece(k, buf, j, false);
+            }
     };
 
     // rider shares: holders of the same dY rows = the (tk, wk) waves
@@ -703,8 +483,8 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
     int apos[2], bpos[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        apos[t] = 4 * swz(wn * 96 + li, lg + 4 * ((t + rot) & 1));
-        bpos[t] = 4 * (TN * CHUNK + swz(wk * 48 + li, lg + 4 * ((t + rot) & 1)));
+        apos[t] = 4 * swz(wn * WR + li, lg + 4 * ((t + rot) & 1));
+        bpos[t] = 4 * (TN * CHUNK + swz(wk * WC + li, lg + 4 * ((t + rot) & 1)));
     }
     float csl[XA], vsl[XB];
 #pragma unroll
@@ -737,7 +517,9 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
     // prologue: chunks 0 and 1 in flight; slot 0 of chunk 0 into operand set 0
     dma_chunk(0, 0);
     dma_chunk(1, 1);
-    wait_vm_dma<NPIECE>();                                  // everything but the last chunk's pieces
+    if (NB == 4) dma_chunk(2, 2);
+    if (NP0 == NP1 || wave < 4) wait_vm_dma<(NB - 2) * NP0>();     // everything but the last NB - 2 chunks' pieces
+    else wait_vm_dma<(NB - 2) * NP1>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     read_ops(0, 0, opa[0], opb[0]);
@@ -749,7 +531,7 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
     // their LDS reads and DMA requests at the same moments and neither would have an MFMA to issue meanwhile
     // (tools/ubench/mfma_2w.hip: two in-phase waves 92 %, two independent ones 97 %).  The second wave of each SIMD
     // (PH = 1) issues the next slot's reads after MFMA step 1 instead of before step 0 and its DMA pieces a step later.
-    auto chunk = [&](int k, int b0, int b1, int b2, auto etag, auto phtag) {
+    auto chunk = [&](int k, int b0, int b1, int bl, auto etag, auto phtag) {      // bl: the buffer chunk k - 1 just left = chunk k + NB - 1's
         constexpr int E = decltype(etag)::value;
         constexpr int PH = decltype(phtag)::value;
 #pragma unroll
@@ -767,8 +549,10 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
                 }
             };
             if (t == 1 && !(PABL & 4)) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // chunk k+1 (requested one chunk ago) has landed
-                __builtin_amdgcn_s_barrier();                          // ... in every wave; ring buffer b2 is free
+                // chunk k+1 has landed (NB = 3: it is the only one in flight; NB = 4: chunk k+2's pieces may still be out -- vmcnt
+                // retires in order)
+                wait_vm_dma<(NB - 3) * (PH ? NP1 : NP0)>();
+                __builtin_amdgcn_s_barrier();                          // ... in every wave; ring buffer bl is free
                 asm volatile("" ::: "memory");
             }
             if (PH == 0) next_reads();
@@ -796,8 +580,9 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
                 // freed its ring buffer): steps 0-2 in the first wave of a SIMD, 1-3 in the second
                 if (t == 1 && e >= PH && e < 3 + PH && !(PABL & 2)) {
                     __builtin_amdgcn_sched_barrier(0);
-                    dma_piece(k + 2, b2, 2 * (e - PH));
-                    dma_piece(k + 2, b2, 2 * (e - PH) + 1);
+#pragma unroll
+                    for (int jj = 2 * (e - PH); jj < 2 * (e - PH) + 2; ++jj)
+                        if (jj < (PH ? NP1 : NP0)) dma_piece(k + NB - 1, bl, jj, 8 * jj + 4 * PH < PA);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -807,8 +592,8 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
     auto run = [&](auto etag, auto phtag) {
         int b0 = 0;
         for (int k = 0; k < nchunks; ++k) {
-            const int b1 = b0 == 2 ? 0 : b0 + 1, b2 = b1 == 2 ? 0 : b1 + 1;
-            chunk(k, b0, b1, b2, etag, phtag);
+            const int b1 = b0 == NB - 1 ? 0 : b0 + 1, bl = b0 == 0 ? NB - 1 : b0 - 1;
+            chunk(k, b0, b1, bl, etag, phtag);
             b0 = b1;
         }
     };
@@ -832,8 +617,8 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
         for (int y = 0; y < XB; ++y)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = wn * 96 + x * 16 + 4 * lg + r;      // D register r of a 16x16 tile: row 4 (l>>4) + r
-                const int jx = wk * 48 + y * 16 + li;
+                const int i = wn * WR + x * 16 + 4 * lg + r;      // D register r of a 16x16 tile: row 4 (l>>4) + r
+                const int jx = wk * WC + y * 16 + li;
                 pt[i * TK + jx] = acc[x][y][r];
             }
     // rider shares: colsum_part[split][hc][tiles_n*TN], vec_part[split][0][tiles_k*TK]
@@ -844,7 +629,7 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
             float t = csl[x];
             t += __shfl_xor(t, 16);
             t += __shfl_xor(t, 32);
-            if (lg == 0) wp.colsum_part[((long)split * Qc + hc) * (wp.tiles_n * TN) + tn * TN + wn * 96 + 16 * x + li] = t;
+            if (lg == 0) wp.colsum_part[((long)split * Qc + hc) * (wp.tiles_n * TN) + tn * TN + wn * WR + 16 * x + li] = t;
         }
         if (VEC && wn == 0 && tn == 0) {
 #pragma unroll
@@ -852,7 +637,7 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
                 float t = vsl[y];
                 t += __shfl_xor(t, 16);
                 t += __shfl_xor(t, 32);
-                if (lg == 0) wp.vec_part[(long)split * (wp.tiles_k * TK) + tk * TK + wk * 48 + 16 * y + li] = t;
+                if (lg == 0) wp.vec_part[(long)split * (wp.tiles_k * TK) + tk * TK + wk * WC + 16 * y + li] = t;
             }
         }
     }
@@ -873,7 +658,7 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
 // channels, two reads = the 8 samples x 1 channel a lane feeds to v_mfma_f32_32x32x16_bf16.  The sample slot is XORed
 // with 4(q&3) in the dump so that the four quads of a 16-lane group hit four different 64-byte bank windows.
 //
-// Structure = wgrad_pipe_kernel: one workgroup per CU, 2x2 waves of 3 x XK tiles (192-row tiles), the operands of chunk
+// Structure = round 2's wgrad_pipe_kernel: one workgroup per CU, 2x2 waves of 3 x XK tiles (192-row tiles), the operands of chunk
 // c+1 read into a second register set under the MFMAs of chunk c, LDS-DMA ring of three buffers -- but with 1728
 // matrix-pipe cycles per chunk instead of 9216 the requests run TWO chunks ahead (the buffer of chunk c is free as soon
 // as its operands are in registers): 96 KiB in flight per CU.  HBM bounds the kernel: 3.2 GB per 384^2 layer at
@@ -1407,9 +1192,11 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
     if (!bf16x3 && pixels_per_image == 0 && n_valid <= 384 && (k_valid == 64 || k_valid == 192 || k_valid == 384) &&
         (!with_vec || (n_valid > 192 && k_valid == 384)))        // the density rider needs the 2 x 2 tile grid
         pipe_xk = k_valid == 64 ? 1 : 3;
-    // small_tiles: a product far below the 192-row tile (the 66 rows RGB_layer_2 has beyond its first 192) goes to
-    // wgrad_kernel's per-shape tiles instead of a 192 x 192 tile that would be two-thirds padding
-    if (small_tiles && !bf16x3 && !with_vec) pipe_xk = 0;
+    // small_tiles: a product far below the 192-row tile (the 66 rows RGB_layer_2 has beyond its first 192) takes a 96 x 192 tile
+    // of the two-wave kernel (round 5; until then a 96 x 96 tile of wgrad_kernel) instead of a 192 x 192 tile that would be
+    // two-thirds padding; other shapes keep wgrad_kernel's per-shape tiles
+    const bool half_rows = small_tiles && !bf16x3 && !with_vec && pipe_xk == 3 && n_valid <= 96 && k_valid == 192;
+    if (small_tiles && !bf16x3 && !with_vec && !half_rows) pipe_xk = 0;
     // bf16x3: pre-split QHL dumps of the chain kernels -> the transposing-read kernel (192-row tiles)
     if (bf16x3 && pixels_per_image == 0 && n_valid <= 384 && lda % 32 == 0 && ldb % 32 == 0 &&
         (k_valid == 64 || k_valid == 192 || k_valid == 384) && (!with_vec || (n_valid > 192 && k_valid == 384)))
@@ -1428,9 +1215,9 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
         img2w = fill >= 0.45 && tk <= 3;
     }
     if (img2w) pipe_xk = 3;
-    const bool two_wave = !bf16x3 && pipe_xk == 3;
+    const bool two_wave = !bf16x3 && pipe_xk != 0;        // (K = 64 never comes with the density rider: see above)
     const int cfg = pipe_xk ? 0 : choose_tile(n_valid, k_valid, with_vec);
-    const int TN = pipe_xk ? 192 : kTileCfgs[cfg].tn, TK = pipe_xk ? 64 * pipe_xk : kTileCfgs[cfg].tk;
+    const int TN = half_rows ? 96 : (pipe_xk ? 192 : kTileCfgs[cfg].tn), TK = pipe_xk ? 64 * pipe_xk : kTileCfgs[cfg].tk;
     wp.tiles_n = (n_valid + TN - 1) / TN;
     wp.tiles_k = (k_valid + TK - 1) / TK;
     const int tiles = wp.tiles_n * wp.tiles_k;
@@ -1479,17 +1266,13 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
         if (pipe_xk == 1) hipLaunchKernelGGL((wgrad3_tr_kernel<1, false>), dim3(blocks), dim3(512), 0, stream, wp);
         else if (wp.vec) hipLaunchKernelGGL((wgrad3_tr_kernel<3, true>), dim3(blocks), dim3(512), 0, stream, wp);
         else hipLaunchKernelGGL((wgrad3_tr_kernel<3, false>), dim3(blocks), dim3(512), 0, stream, wp);
-    } else if (pipe_xk == 3 && two_wave) {
-        // round 3: the same 192 x 192 tiles on eight waves (two per SIMD) of 16x16x4 MFMAs
-        if (wp.vec) hipLaunchKernelGGL((wgrad2w_kernel<true, false>), dim3(blocks), dim3(512), 0, stream, wp);
+    } else if (pipe_xk && two_wave) {
+        // eight waves (two per SIMD) of 16x16x4 MFMAs: 192 x 192 tiles; round 5: 192 x 64 (encoding columns), 96 x 192 (half_rows)
+        if (pipe_xk == 1) hipLaunchKernelGGL((wgrad2w_kernel<false, true, 6, 1, 4>), dim3(blocks), dim3(512), 0, stream, wp);
+        else if (half_rows) hipLaunchKernelGGL((wgrad2w_kernel<false, true, 3>), dim3(blocks), dim3(512), 0, stream, wp);
+        else if (wp.vec) hipLaunchKernelGGL((wgrad2w_kernel<true, false>), dim3(blocks), dim3(512), 0, stream, wp);
         else if (wp.tiles_k >= 2) hipLaunchKernelGGL((wgrad2w_kernel<false, false>), dim3(blocks), dim3(512), 0, stream, wp);
         else hipLaunchKernelGGL((wgrad2w_kernel<false, true>), dim3(blocks), dim3(512), 0, stream, wp);
-    } else if (pipe_xk) {
-        // CSG = rider slots per wave = 4 / (2 tiles_k)
-        if (pipe_xk == 1) hipLaunchKernelGGL((wgrad_pipe_kernel<3, 1, false, 2>), dim3(blocks), dim3(256), 0, stream, wp);
-        else if (wp.vec) hipLaunchKernelGGL((wgrad_pipe_kernel<3, 3, true, 1>), dim3(blocks), dim3(256), 0, stream, wp);
-        else if (wp.tiles_k == 2) hipLaunchKernelGGL((wgrad_pipe_kernel<3, 3, false, 1>), dim3(blocks), dim3(256), 0, stream, wp);
-        else hipLaunchKernelGGL((wgrad_pipe_kernel<3, 3, false, 2>), dim3(blocks), dim3(256), 0, stream, wp);
     } else if (wp.vec) {
         hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2, true>), dim3(blocks), dim3(256), 0, stream, wp);
     } else {
@@ -1506,7 +1289,7 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
     WgradReduceParams rp{};
     rp.partial = scratch; rp.splits = splits; rp.tiles_n = wp.tiles_n; rp.tiles_k = wp.tiles_k;
     rp.tn_rows = TN; rp.tk_cols = TK;
-    rp.cs_q = pipe_xk ? 2 * wp.tiles_k : 1; rp.vs_q = pipe_xk ? 2 * wp.tiles_n : 1;
+    rp.cs_q = pipe_xk ? 2 * wp.tiles_k : 1; rp.vs_q = pipe_xk ? 2 * wp.tiles_n : 1;       // (wgrad3_tr_kernel's share layout)
     if (two_wave) { rp.cs_q = 4 * wp.tiles_k; rp.vs_q = 1; }
     rp.n_valid = n_crop; rp.k_valid = k_crop; rp.dW = dW; rp.ldw = ldw; rp.col_off = col_off; rp.enc_map = enc_map;
     rp.colsum_part = cs_part; rp.colsum_out = colsum_out; rp.colsum_ld = colsum_ld; rp.batch = batch; rp.spi = (int)spi;
