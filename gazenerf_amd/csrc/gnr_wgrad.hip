@@ -1215,9 +1215,19 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
         img2w = fill >= 0.45 && tk <= 3;
     }
     if (img2w) pipe_xk = 3;
+    // the two-wave kernel's tile: (16-row tiles per wave, 16-column tiles per wave) -> (32 xa) x (64 xb) per workgroup
+    int xa = half_rows ? 3 : 6, xb = pipe_xk;
+    // Round 5: three of the upsampler's narrow products on instances of the two-wave kernel sized to them (ring of four: their
+    // chunk periods are 0.9-1.7 us) instead of wgrad_kernel's 32x32x2 tiles, two workgroups per CU
+    if (!(PABL & 8) && !img2w && !bf16x3 && pixels_per_image > 0 && !with_vec && pixels_per_image % CHUNK == 0) {
+        if (n_valid % 128 == 0 && k_valid == 128) { xa = 4; xb = 2; }                                  // 256 x 128 (layer_2 at 64 channels)
+        else if (n_valid == 128 && k_valid == 64) { xa = 4; xb = 1; }                                  // layer_1 at 64 channels
+        else if (n_valid > 32 && n_valid <= 64 && k_valid > 64 && k_valid <= 192) { xa = 2; xb = 3; }  // 64 x 129 (feat_layers)
+        if (xb) { img2w = true; pipe_xk = 3; }
+    }
     const bool two_wave = !bf16x3 && pipe_xk != 0;        // (K = 64 never comes with the density rider: see above)
     const int cfg = pipe_xk ? 0 : choose_tile(n_valid, k_valid, with_vec);
-    const int TN = half_rows ? 96 : (pipe_xk ? 192 : kTileCfgs[cfg].tn), TK = pipe_xk ? 64 * pipe_xk : kTileCfgs[cfg].tk;
+    const int TN = two_wave ? 32 * xa : (pipe_xk ? 192 : kTileCfgs[cfg].tn), TK = two_wave ? 64 * xb : (pipe_xk ? 64 * pipe_xk : kTileCfgs[cfg].tk);
     wp.tiles_n = (n_valid + TN - 1) / TN;
     wp.tiles_k = (k_valid + TK - 1) / TK;
     const int tiles = wp.tiles_n * wp.tiles_k;
@@ -1268,7 +1278,10 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
         else hipLaunchKernelGGL((wgrad3_tr_kernel<3, false>), dim3(blocks), dim3(512), 0, stream, wp);
     } else if (pipe_xk && two_wave) {
         // eight waves (two per SIMD) of 16x16x4 MFMAs: 192 x 192 tiles; round 5: 192 x 64 (encoding columns), 96 x 192 (half_rows)
-        if (pipe_xk == 1) hipLaunchKernelGGL((wgrad2w_kernel<false, true, 6, 1, 4>), dim3(blocks), dim3(512), 0, stream, wp);
+        if (xa == 6 && xb == 1) hipLaunchKernelGGL((wgrad2w_kernel<false, true, 6, 1, 4>), dim3(blocks), dim3(512), 0, stream, wp);
+        else if (xa == 4 && xb == 2) hipLaunchKernelGGL((wgrad2w_kernel<false, true, 4, 2, 4>), dim3(blocks), dim3(512), 0, stream, wp);
+        else if (xa == 4 && xb == 1) hipLaunchKernelGGL((wgrad2w_kernel<false, true, 4, 1, 4>), dim3(blocks), dim3(512), 0, stream, wp);
+        else if (xa == 2 && xb == 3) hipLaunchKernelGGL((wgrad2w_kernel<false, true, 2, 3, 4>), dim3(blocks), dim3(512), 0, stream, wp);
         else if (half_rows) hipLaunchKernelGGL((wgrad2w_kernel<false, true, 3>), dim3(blocks), dim3(512), 0, stream, wp);
         else if (wp.vec) hipLaunchKernelGGL((wgrad2w_kernel<true, false>), dim3(blocks), dim3(512), 0, stream, wp);
         else if (wp.tiles_k >= 2) hipLaunchKernelGGL((wgrad2w_kernel<false, false>), dim3(blocks), dim3(512), 0, stream, wp);
