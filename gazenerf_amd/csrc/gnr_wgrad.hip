@@ -542,10 +542,10 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
                     // both density-vector loads of the coming slots go out HERE, a slot ahead of the LDS-DMA pieces of
                     // t = 1: the compiler's counted wait for them (it cannot see the asm requests in the same in-order
                     // vmcnt queue) then never waits on a piece that has just been issued
-                    if (VEC) { vv[1] = load_vec(k, 1); vnext = load_vec(k + 1, 0); }
+                    if (VEC && PH == 0) { vv[1] = load_vec(k, 1); vnext = load_vec(k + 1, 0); }
                 } else {
                     read_ops(b1, 0, opa[0], opb[0]);
-                    if (VEC) vv[0] = vnext;
+                    if (VEC && PH == 0) vv[0] = vnext;
                 }
             };
             if (t == 1 && !(PABL & 4)) {
@@ -567,7 +567,9 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
 #pragma unroll
                     for (int x = 0; x < XA; ++x) csl[x] = fmaf(opa[t][x][e], cscale, csl[x]);
                 }
-                if (VEC) {
+                // the density dot belongs to the first wave row (wn == 0 == the PH = 0 waves: round 5 -- until then the second wave
+                // of every SIMD ran the same FMAs against a zero factor)
+                if (VEC && PH == 0) {
 #pragma unroll
                     for (int y = 0; y < XB; ++y) vsl[y] = fmaf(vv[t][e], opb[t][y][e], vsl[y]);
                 }
