@@ -515,9 +515,8 @@ __global__ __launch_bounds__(512, 1) void wgrad2w_kernel(const WgradParams wp) {
     };
 
     // prologue: chunks 0 and 1 in flight; slot 0 of chunk 0 into operand set 0
-    dma_chunk(0, 0);
-    dma_chunk(1, 1);
-    if (NB == 4) dma_chunk(2, 2);
+#pragma unroll
+    for (int c = 0; c < NB - 1; ++c) dma_chunk(c, c);
     if (NP0 == NP1 || wave < 4) wait_vm_dma<(NB - 2) * NP0>();     // everything but the last NB - 2 chunks' pieces
     else wait_vm_dma<(NB - 2) * NP1>();
     __builtin_amdgcn_s_barrier();
