@@ -19,7 +19,7 @@
 namespace gnr {
 int fail(const char* fmt, ...);
 size_t carve_fwd(const GnrProblem* p, int n_streams, bool save, char* base, FwdParams* fp);
-size_t wgrad_arena_floats();
+size_t wgrad_arena_floats(int batch, int max_m, int max_k);
 void launch_wgrad(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, int batch,
                   long chunks_per_image, float* dW, int ldw, int col_off, int enc_map, float* colsum_out,
                   int colsum_ld, const float* vec, float* vec_out, float* scratch, hipStream_t stream, bool bf16x3,
@@ -449,7 +449,7 @@ static size_t carve_bwd(const GnrProblem* p, char* base, BwdScratch* sc) {
     s.geo_part = take((size_t)p->batch * s.geo_blocks * 12);
     s.dbias = take((size_t)(N_CHAIN + 1) * p->batch * H);
     s.cs_part = nullptr;
-    s.wg_part = take(wgrad_arena_floats());           // partial tiles of every weight-gradient GEMM of one weight set (gnr_wgrad.h)
+    s.wg_part = take(wgrad_arena_floats(p->batch, H, H));           // partial tiles of every weight-gradient GEMM of one weight set (gnr_wgrad.h)
     s.vd = vd_on_device(p) ? take(vd_bwd_floats(p, 2)) : nullptr;
     if (sc) *sc = s;
     return off;
@@ -547,7 +547,7 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         if (s == 0) stage_mark(GNR_STAGE_WGRAD, 0, st);
         // the split-K reductions of the GEMMs below are queued and run as ONE launch behind the last GEMM (gnr_wgrad.h)
         WgradDefer wd;
-        wgrad_defer_init(&wd, sc.wg_part, wgrad_arena_floats());
+        wgrad_defer_init(&wd, sc.wg_part, wgrad_arena_floats(p->batch, H, H));
         // GEMM shapes = the kernels' (H, H2); the last two arguments crop the written gradient to the network's width
         if (!bf16x3 && p->feat_nc > 192 && p->feat_nc <= 288) {
             // RGB_layer_2 (258 x 192): as ONE product its rows pad to two 192-row tiles, the second two-thirds empty
@@ -581,6 +581,7 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         launch_wgrad(dyh(0), H, H, bf16x3 ? fp.enc3 : fp.enc, ENC_PAD, ENC_PAD, p->batch, cpi, DW.fea_w[0], vp, 0, bf16x3 ? 2 : 1,
                      dbl(0), H, nullptr, nullptr, sc.wg_part, st, bf16x3, Hh, ENC_PAD, false, &wd);
         wgrad_defer_flush(&wd, st);
+        if (wd.failed) return fail("gnr_bwd: a weight-gradient GEMM needs more split-K scratch than the workspace holds (batch %d)", p->batch);
         if (s == 0) stage_mark(GNR_STAGE_WGRAD, 1, st);
         launch_vecsum(sc.dsig_ray, p->batch, p->n_rays, dbl(N_CHAIN), H, st);
 

@@ -34,7 +34,7 @@
 
 namespace gnr {
 int fail(const char* fmt, ...);
-size_t wgrad_arena_floats();
+size_t wgrad_arena_floats(int batch, int max_m, int max_k);
 void launch_wgrad_img(const float* A, int lda, int n_valid, const float* B, int ldb, int k_valid, int batch,
                       long pixels_per_image, float* dW, int ldw, float* colsum_out, int colsum_ld, float* scratch,
                       hipStream_t stream, WgradDefer* defer);
@@ -913,7 +913,7 @@ static size_t up_carve_bwd(const GnrUpsampleProblem* p, const UpDims& d, char* b
         cs_floats += up_colsum_floats(d, p->batch, i);
     }
     z.colsum = (float*)take(cs_floats * 4);
-    z.wg = (float*)take(wgrad_arena_floats() * 4);
+    z.wg = (float*)take(wgrad_arena_floats(p->batch, 4 * d.ch[0], 2 * d.ch[0]) * 4);      // layer_2 of block 0 is the largest product
     if (s) *s = z;
     return off;
 }
@@ -1095,7 +1095,7 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
     };
     // the split-K reductions of the nine weight-gradient GEMMs are queued and run as ONE launch at the end of the call
     WgradDefer wd;
-    wgrad_defer_init(&wd, t.wg, wgrad_arena_floats());
+    wgrad_defer_init(&wd, t.wg, wgrad_arena_floats(p->batch, 4 * d.ch[0], 2 * d.ch[0]));
 
     // Blur and the 1x1 convolution act on different axes (pixels / channels) and commute: with g = blur^T(dhid)
     //   dWf = g u^T,  dbf = sum g (= sum dhid: blur's rows sum to 1),  du = Wf^T g,
@@ -1201,6 +1201,7 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
     }
     if (wsum.n) hipLaunchKernelGGL(rgb_wsum_batch_kernel, dim3(wsum.first[wsum.n]), dim3(64), 0, st, wsum);
     wgrad_defer_flush(&wd, st);
+    if (wd.failed) return fail("gnr_upsample_bwd: a weight-gradient GEMM needs more split-K scratch than the workspace holds (batch %d)", B);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("gnr_upsample_bwd: launch failed: %s", hipGetErrorString(e));
     return 0;

@@ -47,11 +47,13 @@ struct WgradReduceBatch {                  // kernel argument of wgrad_reduce_ba
 struct WgradDefer {
     float* arena = nullptr;
     size_t arena_floats = 0, cursor = 0;
+    bool failed = false;                   // a GEMM needed more scratch than the whole arena and was NOT launched: the entry point
+                                           // that owns the queue returns an error (arenas sized by wgrad_arena_floats never get here)
     WgradReduceBatch batch{};
 };
 
 inline void wgrad_defer_init(WgradDefer* d, float* arena, size_t floats) {
-    d->arena = arena; d->arena_floats = floats; d->cursor = 0; d->batch.n = 0; d->batch.first[0] = 0;
+    d->arena = arena; d->arena_floats = floats; d->cursor = 0; d->failed = false; d->batch.n = 0; d->batch.first[0] = 0;
 }
 // Launches the queued reductions (one kernel) and makes the whole scratch available again.
 void wgrad_defer_flush(WgradDefer* d, hipStream_t st);
@@ -63,6 +65,10 @@ void wgrad_defer_push16(WgradDefer* d, const Wgrad16ReduceParams& rp, unsigned b
 
 // scratch of one GEMM launched without a WgradDefer (the layout the launchers assume in that case)
 size_t wgrad_scratch_floats();
+// Arena for the queued reductions of one weight set / one upsampler backward whose largest product is max_m x max_k over `batch`
+// images: four single-GEMM scratches, or what that product's partial tiles + rider shares need when there are more (image, tile)
+// pairs than one round of workgroups -- the partial tiles of a GEMM grow with the batch then.
+size_t wgrad_arena_floats(int batch, int max_m, int max_k);
 
 #ifdef __HIPCC__
 // wgrad16_reduce_kernel's body: dW[n][k] = sum_s partial[s][n][k] (s ascending: fixed order), bias[n] = the last padded

@@ -1141,7 +1141,14 @@ size_t wgrad_scratch_floats() {
 // Scratch for the queued reductions of one weight set / one upsampler backward (gnr_wgrad.h): a 384 x 384 layer's GEMM takes
 // 256 tiles of 192 x 192 + its rider shares = 9.8 M floats, so four single-GEMM scratches (152 M floats, 610 MB) hold all 13-14
 // GEMMs of a weight set at once; anything beyond is handled by an early flush.
-size_t wgrad_arena_floats() { return 4 * wgrad_scratch_floats(); }
+size_t wgrad_arena_floats(int batch, int max_m, int max_k) {
+    const size_t base = 4 * wgrad_scratch_floats();
+    // one partial tile set per image at least (spi >= 1): padded output area x images, + the rider shares (<= 4 x 192 + 192 floats
+    // per workgroup of >= 32 x 64 outputs: < 1/2 of the tiles) + the rounding of the grid to eight
+    const size_t area = (size_t)(max_m + 191) * (size_t)(max_k + 191);
+    const size_t big = (size_t)batch * area * 3 / 2 + (size_t)16 * 192 * 192;
+    return big > base ? big : base;
+}
 
 // fp32 tile configurations: {rows, cols, relative cost per MFMA slot (LDS reads per MFMA, 3-wave workgroups)}
 struct TileCfg { int tn, tk; float cost; };
@@ -1255,21 +1262,37 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
     wp.chunks_per_split = (chunks_per_image + spi - 1) / spi;
     const int splits = batch * (int)spi;
     const unsigned blocks = img2w ? (unsigned)(8 * (((long)splits * tiles + 7) / 8)) : (unsigned)(8 * ((splits + 7) / 8) * tiles);
-    // scratch of this GEMM: [partial tiles][column-sum shares][vector shares].  Alone it owns `scratch` with the fixed
-    // offsets of wgrad_scratch_floats(); queued (gnr_wgrad.h) it takes what it needs from the caller's arena.
-    size_t part_floats = (size_t)WG_MAX_BLOCKS * WG_MAX_TILE;
+    // rider shares per split: the two-wave kernel 4 tiles_k column-sum shares, wgrad3_tr_kernel 2 tiles_k / 2 tiles_n, wgrad_kernel 1
+    const int cs_q = two_wave ? 4 * wp.tiles_k : (pipe_xk ? 2 * wp.tiles_k : 1);
+    const int vs_q = two_wave ? 1 : (pipe_xk ? 2 * wp.tiles_n : 1);
+    // scratch of this GEMM: [partial tiles][column-sum shares][vector shares], each at its exact size (round 5: the shares had a
+    // fixed 1024 x 192 floats each, sized for ONE round of workgroups -- more images than workgroup slots, e.g. 40 stacked maps
+    // through the upsampler's 18-tile product or > 64 images through the MLP, wrote past it into the next GEMM's partial tiles:
+    // wrong bias gradients, tests/test_upsample.py::test_hip_vs_oracle_live[258-16-32-32-40]).  Queued (gnr_wgrad.h) the GEMM takes
+    // what it needs from the caller's arena; alone it owns `scratch` (wgrad_scratch_floats()) and must fit it.
+    WgradDefer* const owner = defer;
+    const size_t need = ((size_t)blocks * TN * TK + 63) & ~(size_t)63;
+    const size_t cs_need = ((size_t)splits * cs_q * wp.tiles_n * TN + 63) & ~(size_t)63;
+    const size_t vec_need = with_vec ? (((size_t)splits * vs_q * wp.tiles_k * TK + 63) & ~(size_t)63) : 0;
     if (defer) {
-        const size_t need = ((size_t)blocks * TN * TK + 63) & ~(size_t)63;
-        float* q = wgrad_defer_take(defer, need + 2 * (size_t)WG_MAX_BLOCKS * WG_RIDER_ROWS, stream);
-        if (q) { scratch = q; part_floats = need; }
-        else {                                // an arena below one GEMM's need (callers size it with wgrad_arena_floats(): never) --
+        float* q = wgrad_defer_take(defer, need + cs_need + vec_need, stream);
+        if (q) scratch = q;
+        else {                                // an arena below one GEMM's need (callers size it with wgrad_arena_floats()) --
             wgrad_defer_flush(defer, stream); // run what is queued, then this GEMM owns `scratch` like a launch of its own
             defer = nullptr;
         }
     }
+    if (!defer && need + cs_need + vec_need > wgrad_scratch_floats()) {
+        // continuing would write past the caller's scratch.  With a queue the GEMM is skipped and the queue's owner (gnr_bwd /
+        // gnr_upsample_bwd) returns an error; arenas sized by wgrad_arena_floats(batch, ...) never get here
+        if (owner) { owner->failed = true; return; }
+        fprintf(stderr, "gnr: weight gradient %d x %d over %d image(s): %zu floats of split-K scratch needed, %zu available\n", n_valid, k_valid,
+                batch, need + cs_need + vec_need, wgrad_scratch_floats());
+        abort();
+    }
     wp.partial = scratch;
-    float* cs_part = scratch + part_floats;
-    float* vec_part = cs_part + (size_t)WG_MAX_BLOCKS * WG_RIDER_ROWS;
+    float* cs_part = scratch + need;
+    float* vec_part = cs_part + cs_need;
     wp.colsum_part = cs_part;
     wp.vec = with_vec ? vec : nullptr;
     wp.vec_part = vec_part;
@@ -1303,8 +1326,7 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
     WgradReduceParams rp{};
     rp.partial = scratch; rp.splits = splits; rp.tiles_n = wp.tiles_n; rp.tiles_k = wp.tiles_k;
     rp.tn_rows = TN; rp.tk_cols = TK;
-    rp.cs_q = pipe_xk ? 2 * wp.tiles_k : 1; rp.vs_q = pipe_xk ? 2 * wp.tiles_n : 1;       // (wgrad3_tr_kernel's share layout)
-    if (two_wave) { rp.cs_q = 4 * wp.tiles_k; rp.vs_q = 1; }
+    rp.cs_q = cs_q; rp.vs_q = vs_q;
     rp.n_valid = n_crop; rp.k_valid = k_crop; rp.dW = dW; rp.ldw = ldw; rp.col_off = col_off; rp.enc_map = enc_map;
     rp.colsum_part = cs_part; rp.colsum_out = colsum_out; rp.colsum_ld = colsum_ld; rp.batch = batch; rp.spi = (int)spi;
     rp.vec_part = vec_part; rp.vec_out = vec_out ? vec_out : nullptr;

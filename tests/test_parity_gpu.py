@@ -269,6 +269,20 @@ def _grads_hip(p, face, eyes, n_samples, t_rand, dev, precision="fp32", hidden=3
     return out, leaves, fp, ep
 
 
+def _grads_hip_sum(p, face, eyes, n_samples, t_rand, dev, precision="fp32"):
+    """As _grads_hip with a loss that is a plain sum over images and rays (no 1 / B factor)."""
+    pd = _to(p, dev)
+    leaves = {k: pd[k].clone().requires_grad_(True) for k in ("R", "T", "shape_code", "gaze", "appea_code")}
+    fp = {k: v.to(dev).clone().requires_grad_(True) for k, v in face.items()}
+    ep = {k: v.to(dev).clone().requires_grad_(True) for k, v in eyes.items()}
+    out = render.render_two_stream(pd["xy"], leaves["R"], leaves["T"], pd["Kinv"], leaves["shape_code"],
+                                   leaves["gaze"], leaves["appea_code"], fp, ep, n_samples=n_samples,
+                                   t_rand=t_rand.to(dev), precision=precision)
+    loss = sum((out["feat_" + t] ** 2).sum() * 1e-3 + out["bg_alpha_" + t].sum() for t in ("face", "eyes"))
+    loss.backward()
+    return out, leaves, fp, ep
+
+
 def _check_grad(name, got, ref):
     got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
     scale = max(float(ref.abs().max()), 1e-30)
@@ -479,6 +493,36 @@ def test_edge_sizes_forward_and_backward(n_samples, n_rays, batch, precision):
         for tag, hp, op in (("face", fp, fo), ("eyes", ep, eo)):
             for name in ("RGB_layer_2.weight", "RGB_layer_0.weight", "density_module.weight", "FeaExt_module_7.bias"):
                 _check_grad("%s.%s" % (tag, name), hp[name].grad, op[name].grad)
+
+
+def test_more_images_than_workgroup_slots():
+    """144 images x 16 rays x 32 samples in ONE call against the same images as two calls of 72: per-image gradients equal, weight
+    gradients = the sum of the halves'.  With more images than one round of workgroups a weight-gradient GEMM runs one split per
+    image, and until round 5 its rider shares (bias column sums, the density-head dot) outgrew their fixed scratch from 65 images
+    on -- wrong `density_module.weight` / bias gradients, from 129 images on also overwritten partial tiles."""
+    dev = _dev()
+    B, n_rays, n_samples = 144, 16, 32
+    sub = (torch.arange(n_rays) * 251 + 5) % 4096
+    p = synth.synth_problem(64, batch=B, camera="3", seed=21, ray_subset=sub)
+    face = synth.hash_mlp_params("face", seed=6, density_scale=10.0)
+    eyes = synth.hash_mlp_params("eyes", seed=6, density_scale=10.0)
+    t_rand = synth.synth_jitter(B, n_rays, n_samples, seed=9)
+
+    def run(lo, hi):
+        q = {k: v[lo:hi].contiguous() for k, v in p.items()}
+        out, leaves, fp, ep = _grads_hip_sum(q, face, eyes, n_samples, t_rand[lo:hi], dev)
+        return {k: v.grad.double().cpu() for k, v in leaves.items()}, {k: v.grad.double().cpu() for k, v in fp.items()}, \
+            {k: v.grad.double().cpu() for k, v in ep.items()}
+
+    full = run(0, B)
+    a, b = run(0, B // 2), run(B // 2, B)
+    for k in full[0]:                                  # per-image inputs: the halves side by side
+        ref = torch.cat([a[0][k], b[0][k]], 0)
+        assert float((full[0][k] - ref).norm() / ref.norm().clamp_min(1e-30)) <= 1e-5, k
+    for tag, i in (("face", 1), ("eyes", 2)):
+        for k in full[i]:
+            ref = a[i][k] + b[i][k]
+            assert float((full[i][k] - ref).norm() / ref.norm().clamp_min(1e-30)) <= 2e-5, "%s.%s" % (tag, k)
 
 
 def test_empty_and_invalid_inputs_are_rejected():
