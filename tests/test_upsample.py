@@ -124,11 +124,11 @@ def test_hip_vs_reference_fixture(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("feat_nc,side,img,min_feat,batch", [(20, 16, 128, 6, 2), (258, 32, 64, 32, 1), (7, 32, 256, 3, 3),
-                                                            (258, 16, 32, 32, 40)])
+                                                            (258, 16, 32, 32, 40), (12, 16, 256, 4, 1)])
 def test_hip_vs_oracle_live(feat_nc, side, img, min_feat, batch):
     """Other shapes: 3 blocks from a 16x16 map, a single block, odd channel counts that are no multiple of 4; 40 stacked maps
     (3 B + 1 at B = 13: more (image, tile) pairs than one round of workgroups -- the rider shares of the weight-gradient GEMMs
-    outgrew their scratch there until round 5)."""
+    outgrew their scratch there until round 5); four blocks (GNR_UPSAMPLE_MAX_BLOCKS)."""
     dev = _dev()
     n_blocks = int(np.log2(img) - np.log2(side))
     params = synth.hash_renderer_params(seed=9, feat_nc=feat_nc, n_blocks=n_blocks, min_feat=min_feat, weight_scale=2.0)
