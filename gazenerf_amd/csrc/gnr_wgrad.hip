@@ -1367,8 +1367,9 @@ void launch_wgrad_img(const float* A, int lda, int n_valid, const float* B, int 
                       colsum_ld, nullptr, nullptr, scratch, stream, false, pixels_per_image, n_valid, k_valid, false, defer);
 }
 
-// per-image sum of a per-sample vector: out[b] = sum_{s in image b} v[s]   (density bias gradient)
-__global__ __launch_bounds__(256) void vecsum_kernel(const float* __restrict__ v, long per_image, float* __restrict__ out) {
+// per-image sum of a per-sample vector: out[b * out_stride] = sum_{s in image b} v[s]   (density bias gradient); one workgroup per
+// image, fixed order (round 5: one launch for all images; until then one launch per image)
+__global__ __launch_bounds__(256) void vecsum_kernel(const float* __restrict__ v, long per_image, float* __restrict__ out, int out_stride) {
     __shared__ float red[256];
     const int b = blockIdx.x, tid = threadIdx.x;
     float acc = 0.0f;
@@ -1379,14 +1380,11 @@ __global__ __launch_bounds__(256) void vecsum_kernel(const float* __restrict__ v
         if (tid < s) red[tid] += red[tid + s];
         __syncthreads();
     }
-    if (tid == 0) out[b] = red[0];
+    if (tid == 0) out[(long)b * out_stride] = red[0];
 }
 
 void launch_vecsum(const float* v, int batch, long per_image, float* out, int out_stride, hipStream_t stream) {
-    // out[b * out_stride]: written through a strided view by launching per image
-    for (int b = 0; b < batch; ++b)
-        hipLaunchKernelGGL(vecsum_kernel, dim3(1), dim3(256), 0, stream, v + (long)b * per_image, per_image,
-                           out + (long)b * out_stride);
+    hipLaunchKernelGGL(vecsum_kernel, dim3((unsigned)batch), dim3(256), 0, stream, v, per_image, out, out_stride);
 }
 
 }  // namespace gnr
