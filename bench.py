@@ -290,9 +290,13 @@ def guard_stdout():
     original descriptor."""
     global _RESULT_FD
     if _RESULT_FD is None:
-        sys.stdout.flush()
-        _RESULT_FD = os.dup(1)
-        os.dup2(2, 1)
+        try:
+            sys.stdout.flush()
+            fd = os.dup(1)
+            os.dup2(2, 1)
+            _RESULT_FD = fd
+        except OSError:          # no usable stderr / stdout descriptor: print the line the ordinary way
+            _RESULT_FD = None
 
 
 def emit_result(res):

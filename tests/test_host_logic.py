@@ -54,6 +54,22 @@ def test_bench_flop_constant_matches_survey():
     assert macs == 1351680 and bench.FLOP_PER_SAMPLE_STREAM == 2 * macs
 
 
+def test_bench_stdout_carries_the_result_line_and_nothing_else():
+    """bench.guard_stdout / emit_result (round 5): whatever a library, a child process or a stray print writes to file descriptor 1
+    during the run ends up in stderr; stdout holds the one JSON line (RCCL printed its NCCL_DEBUG=VERSION banner behind it)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, os; sys.path.insert(0, %r); import bench; bench.guard_stdout(); print('library chatter'); "
+            "os.system('echo child chatter'); bench.emit_result({'ok': 1})" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout) == {"ok": 1} and r.stdout.count("\n") == 1
+    assert "library chatter" in r.stderr and "child chatter" in r.stderr
+
+
 def test_packed_weight_cache_invalidation():
     """render.PackedWeightCache (round-2 advice): a reallocated workspace must forget its key at once (a call that
     raises before store() must not leave the OLD key describing the NEW buffer), and the key includes data_ptr."""
