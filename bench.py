@@ -61,7 +61,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", choices=("cfg2b", "cfg4"), default=os.environ.get("GNR_BENCH_CONFIG", "cfg2b"))
     ap.add_argument("--mode", choices=("fwd", "fwdbwd"), default=os.environ.get("GNR_BENCH_MODE", "fwdbwd"))
-    ap.add_argument("--side", type=int, default=512, help="cfg2b: rays per image = side^2")
+    ap.add_argument("--side", type=int, default=None,
+                    help="cfg2b: rays per image = side^2 (default 512).  cfg4: feature-map side (default 64 = the reference's; "
+                         "the image is 8 x side); any other value is a TEST-ONLY size (launcher rehearsals) and the line says so")
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--micro", type=int, default=32768,
                     help="cfg2b fwdbwd: rays per tile of the tiled training entry point (forward-with-save, loss, backward per tile). "
@@ -85,7 +87,10 @@ def parse():
     ap.add_argument("--force-dist", action="store_true", default=os.environ.get("GNR_BENCH_FORCE_DIST", "") == "1",
                     help="--gpus 1: form a ONE-rank RCCL process group anyway and run the gradient exchange through it "
                          "(loads librccl, creates a communicator, exercises the stream hand-off on a single GPU)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.side is None:
+        args.side = 64 if args.config == "cfg4" else 512
+    return args
 
 
 # ------------------------------------------------------------------------------------------------ launcher
@@ -334,6 +339,12 @@ def main():
         raise SystemExit("bench.py: --scaling strong shards the rays of ONE cfg2b image; cfg4 shards images (weak)")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    # pre-flight, every rank, stderr: what the device has free BEFORE this rank allocates (hipMemGetInfo) -- several ranks on
+    # one device (the test-only rehearsals) or a neighbour's leftovers show up here instead of as an out-of-memory in step 1
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    sys.stderr.write("bench.py: rank %d of %d on GPU %d: %.1f GiB free of %.1f GiB (hipMemGetInfo), pid %d\n"
+                     % (rank, world, dev_index, free_b / 2**30, total_b / 2**30, os.getpid()))
+    sys.stderr.flush()
     affinity = pin_rank_to_cpus(torch, dev_index, local_rank, world)
     dist = None
     backend = None
@@ -737,16 +748,21 @@ def run_cfg4(ctx):
     from gazenerf_amd.hiptime import ClockProbe, StageTimer
     from gazenerf_amd.parallel import GradAllReducer
 
-    B, S, n_p = 2, 64, 64
+    B, S, n_p = 2, args.side, 64
+    if S < 16 or S & (S - 1):
+        raise SystemExit("bench.py: --config cfg4 --side %d: the feature-map side must be a power of two >= 16" % S)
+    I = 8 * S                                     # three pixel-shuffle blocks, as 64 -> 512 in the reference
+    test_size = S != 64                           # any side but the reference's 64 is a TEST-ONLY size (launcher rehearsals)
     n_rays = S * S
     torch.manual_seed(1234)                       # identical initial parameters on every rank
-    net = GazeNeRFNetAMD(featmap_size=S, pred_img_size=512, precision=args.precision).to(dev)
+    net = GazeNeRFNetAMD(featmap_size=S, pred_img_size=I, precision=args.precision).to(dev)
     p = {k: v.to(dev) for k, v in synth.synth_problem(S, batch=B, camera=str(3 + 2 * rank), seed=100 + rank).items()}
     t_rand = synth.synth_jitter(B, n_rays, n_p, seed=7 + rank).to(dev)
     g = torch.Generator(device="cpu").manual_seed(50 + rank)
-    gt = torch.rand(B, 3, 512, 512, generator=g).to(dev)
-    yy, xx = torch.meshgrid(torch.arange(512.0), torch.arange(512.0), indexing="ij")
-    disk = lambda cx, cy, r: (((xx - cx) ** 2 + (yy - cy) ** 2) <= r * r).float().expand(B, 1, -1, -1).to(dev)
+    gt = torch.rand(B, 3, I, I, generator=g).to(dev)
+    yy, xx = torch.meshgrid(torch.arange(float(I)), torch.arange(float(I)), indexing="ij")
+    k = I / 512.0
+    disk = lambda cx, cy, r: (((xx - cx * k) ** 2 + (yy - cy * k) ** 2) <= (r * k) ** 2).float().expand(B, 1, -1, -1).to(dev)
     face_mask, left_eye, right_eye = disk(256, 256, 200), disk(190, 220, 28), disk(322, 220, 28)
     full_eye = torch.clamp(left_eye + right_eye, max=1.0)
     zeros = lambda n: torch.zeros(B, n, device=dev)
@@ -830,7 +846,7 @@ def run_cfg4(ctx):
         opt.zero_grad(set_to_none=True)
         return {"images": 3 * B + 1, "fwd_ms": sorted(tf)[len(tf) // 2], "fwdbwd_ms": sorted(tb)[len(tb) // 2],
                 "kernels": "gnr::conv16_kernel<MT,NT,..> + gnr::wgrad2w_kernel / wgrad_kernel (image layout) + stencil / RGB kernels",
-                "timing": "median of 5 calls of GazeNeRFNetAMD.neural_render on a random [3B+1,258,64,64] map, HIP events, outside the timed steps"}
+                "timing": "median of 5 calls of GazeNeRFNetAMD.neural_render on a random [3B+1,258,%d,%d] map, HIP events, outside the timed steps" % (S, S)}
     upsampler = time_upsampler()
     x3 = args.precision == "bf16x3"
     peak = PEAK_BF16X3_TFLOPS if x3 else PEAK_FP32_MFMA_TFLOPS
@@ -851,14 +867,17 @@ def run_cfg4(ctx):
     dom = max(stages, key=lambda s: s["share_of_step"])
     hot_flop = 3 * m * 2 * FLOP_PER_SAMPLE_STREAM
     res = {
-        "metric": "rays/sec, whole-network training step (cfg4: B=2 x 64x64 rays x 64 samples per GPU, fwd+bwd+all-reduce+Adam)",
+        "metric": "rays/sec, whole-network training step (cfg4: B=2 x %dx%d rays x 64 samples per GPU, fwd+bwd+all-reduce+Adam)%s" % (
+            S, S, " -- TEST-ONLY SIZE, not cfg4's 64x64" if test_size else ""),
         "value": world * B * n_rays * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16x3 hot path, f32 elsewhere" if x3 else "f32", "data": "synthetic",
         "images_per_s": world * B * args.steps / dt,
-        "config": {"workload": "cfg4: global batch %d = %d images per GPU x %d GPUs, featmap 64x64 x 64 samples, whole network "
-                               "(hot path -> merge -> upsampler x4 -> 512x512 image loss), backward, gradient all-reduce of "
-                               "all %d trainable floats, fused Adam" % (B * world, B, world, n_train),
+        "config": {"workload": "%s: global batch %d = %d images per GPU x %d GPUs, featmap %dx%d x 64 samples, whole network "
+                               "(hot path -> merge -> upsampler x4 -> %dx%d image loss), backward, gradient all-reduce of "
+                               "all %d trainable floats, fused Adam" % ("cfg4 at a TEST-ONLY size" if test_size else "cfg4", B * world, B, world,
+                                                                        S, S, I, I, n_train),
+                   "featmap_side": S, "test_only_size": test_size,
                    "rays_per_step_per_gpu": B * n_rays, "samples_per_ray": n_p, "trainable_floats": n_train,
                    "parallelism": "dp%d (images sharded; 3 flat buckets: NeuralRenderer (launched from autograd hooks, in "
                                   "flight during the hot path's backward), face MLP, eyes MLP)" % world,

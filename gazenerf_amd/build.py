@@ -99,6 +99,23 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+GUARD_SRC = os.path.join(HERE, "..", "tests", "guard", "guard_alloc.cpp")
+GUARD_LIB = os.path.join(HERE, "..", "tests", "guard", "_guard_alloc.so")
+
+
+def build_guard(force: bool = False, verbose: bool = True) -> str:
+    """TEST INFRASTRUCTURE (like the oracle): the guard-band device allocator tests/test_guard_bands.py plugs into torch
+    (tests/guard/guard_alloc.cpp: host code on the HIP runtime API; no kernels).  Built here so that it travels prebuilt."""
+    if force or _stale(GUARD_LIB, [GUARD_SRC]):
+        cmd = [HIPCC, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", GUARD_SRC, "-o", GUARD_LIB]
+        if verbose:
+            print("[gnr build]", " ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (GUARD_SRC, r.stdout, r.stderr))
+    return os.path.abspath(GUARD_LIB)
+
+
 TORCH_EXT = os.path.join(HERE, "_gnr_torch.so")
 
 
@@ -136,3 +153,4 @@ if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
     if "--no-torch-ext" not in sys.argv:
         print(build_torch_ext(force="--force" in sys.argv))
+    print(build_guard(force="--force" in sys.argv))

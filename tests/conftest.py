@@ -15,6 +15,30 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# ---- order of the GPU run ---------------------------------------------------------------------
+# The driver runs `pytest tests -x -q -m gpu`: the first failure ends the run.  Collection order is alphabetical, which put
+# the launcher / JSON-shape tests of test_bench_contract.py AHEAD of every test that compares the HIP path with the oracle
+# -- one flaky eight-rank rehearsal blanked the whole parity suite in round 5.  The order is now by what a test proves:
+# oracle / fixture parity through the C ABI first, the guard-band harness next, the plain-PyTorch N4 helpers after that,
+# the bench contract (subprocesses, launchers) behind them, and the world-size-8 rehearsals last of all.
+_GPU_ORDER = ("test_parity_gpu", "test_upsample", "test_network", "test_guard_bands", "test_losses", "test_gan", "test_perceptual",
+              "test_data")
+_LAST, _VERY_LAST = len(_GPU_ORDER) + 1, len(_GPU_ORDER) + 2
+
+
+def _gpu_rank(item):
+    if item.get_closest_marker("gpu") is None:
+        return -1                                    # CPU tests keep their place (and are deselected by -m gpu anyway)
+    mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+    if mod == "test_bench_contract":
+        return _VERY_LAST if "world_size_8" in item.name else _LAST
+    return _GPU_ORDER.index(mod) if mod in _GPU_ORDER else len(_GPU_ORDER)
+
+
+def pytest_collection_modifyitems(session, config, items):
+    items.sort(key=_gpu_rank)                        # stable: the order inside a file is unchanged
+
+
 def load_golden(name):
     z = np.load(os.path.join(GOLD, name + ".npz"))
     conv = lambda a: a.item() if a.ndim == 0 else (a if a.dtype.kind in "US" else torch.from_numpy(a))

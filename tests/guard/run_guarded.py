@@ -1,0 +1,427 @@
+"""Run one scenario of the product path with EVERY device allocation of the process fenced by guard bands.
+
+    python tests/guard/run_guarded.py <scenario> [--poison] [--binding ctypes|torch_ext] [--cases N] [--seed S]
+
+TEST INFRASTRUCTURE (tests/test_guard_bands.py launches it; tools/session.sh runs the long forms).  torch's allocator is
+replaced by tests/guard/_guard_alloc.so BEFORE the first device allocation: every tensor -- workspaces, scratch, saved
+activations, outputs, gradients, torch's temporaries -- becomes its own hipMalloc with 1 MiB of a known pattern on both
+sides (and, with --poison, a body of 0xFF bytes = NaN, so workspace that is read before it is written shows up in the
+results).  The bands of every live allocation are checked after every libgnr entry point (ctypes binding: the function
+objects are wrapped) or after every op (C++ binding), and at every free.
+
+Prints ONE JSON line: {"scenario", "violations", "report", "calls_checked", "allocations", "peak_live_bytes", ...};
+exit status 1 on a violation, a non-finite result or a failed comparison.
+
+Scenarios
+  selftest      the harness itself: writes 4 bytes behind and 1 byte in front of a tensor, 4 bytes past a second one -> MUST report 3
+  hot_path      gnr_fwd / gnr_bwd (both precisions) over the shape generator of tests/diagnostics/fuzz_hot_path_split.py
+                (1..200 images, ragged rays / samples, narrow hidden / feature widths, in-op ray tiling, per-ray biases)
+                + inference forwards with depth / weights + the tiled training entry point
+  many_images   144 and 65 images in one call (more images than workgroup slots: the round-5 scratch overrun of
+                gnr_wgrad.hip, commit 1503d29) + 29 / 40 stacked maps through the upsampler
+  upsample      gnr_upsample_fwd / bwd over the shape generator of tests/diagnostics/fuzz_upsample.py + the cfg4 shape
+                (7 maps x 258 x 64 x 64 -> 512 x 512), each compared with the oracle
+  aux           gnr_merge_fwd / bwd, gnr_resample, gnr_sample_zvals, the hierarchical pass, the view-direction option
+  network_step  cfg4's whole-network training step (B = 2, 64 x 64 x 64 -> 512 x 512, loss, backward, Adam) x 2
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+GUARD_SO = os.path.join(HERE, "_guard_alloc.so")
+
+
+def install():
+    """Plug the guard allocator into torch.  Must run before the first device allocation of the process."""
+    import torch
+    if not os.path.exists(GUARD_SO):
+        raise SystemExit("run_guarded.py: %s is missing: python -m gazenerf_amd.build" % GUARD_SO)
+    alloc = torch.cuda.memory.CUDAPluggableAllocator(GUARD_SO, "guard_malloc", "guard_free")
+    torch.cuda.memory.change_current_allocator(alloc)
+    g = C.CDLL(GUARD_SO)
+    g.guard_check_all.restype = C.c_ulonglong
+    g.guard_check_all.argtypes = [C.c_char_p]
+    g.guard_violations.restype = C.c_ulonglong
+    g.guard_report.restype = C.c_size_t
+    g.guard_report.argtypes = [C.c_char_p, C.c_size_t]
+    g.guard_stats.argtypes = [C.POINTER(C.c_ulonglong)]
+    return g, alloc
+
+
+class Guard:
+    def __init__(self, g):
+        self.g, self.calls, self.last = g, 0, 0
+
+    def check(self, when):
+        """Synchronise, check every live allocation; a NEW violation is attributed to `when`."""
+        n = int(self.g.guard_check_all(when.encode()))
+        self.calls += 1
+        new, self.last = n - self.last, n
+        return new
+
+    def wrap_lib(self):
+        """ctypes binding: every libgnr entry point that launches kernels is followed by a check naming it."""
+        from gazenerf_amd import _lib
+        lib = _lib.load()
+        for name in ("gnr_fwd", "gnr_fwd_bf16x3", "gnr_bwd", "gnr_bwd_bf16x3", "gnr_resample", "gnr_sample_zvals", "gnr_merge_fwd",
+                     "gnr_merge_bwd", "gnr_upsample_fwd", "gnr_upsample_bwd"):
+            fn = getattr(lib, name)
+
+            def make(fn=fn, name=name):
+                def call(*a):
+                    rc = fn(*a)
+                    self.check("after " + name)
+                    return rc
+                return call
+            setattr(lib, name, make())
+
+    def result(self):
+        st = (C.c_ulonglong * 6)()
+        self.g.guard_stats(st)
+        need = self.g.guard_report(None, 0)
+        buf = C.create_string_buffer(int(need) + 1)
+        self.g.guard_report(buf, len(buf))
+        return {"violations": int(self.g.guard_violations()), "report": buf.value.decode("utf-8", "replace"),
+                "calls_checked": self.calls, "allocations": int(st[0]), "frees": int(st[1]), "live_at_end": int(st[2]),
+                "band_checks": int(st[3]), "peak_live_bytes": int(st[4]), "guard_bytes_per_side": int(st[5])}
+
+
+def finite(*tensors):
+    import torch
+    return all(bool(torch.isfinite(t).all()) for t in tensors if t is not None)
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten().cpu(), b.double().flatten().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+# ------------------------------------------------------------------------------------------------ scenarios
+def sc_selftest(guard, args):
+    import torch
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    t = torch.zeros(1000, device="cuda:0")
+    assert guard.check("clean") == 0
+    hip.hipMemset(C.c_void_p(t.data_ptr() + t.numel() * 4), 0, 4)           # one float behind the last element
+    hip.hipMemset(C.c_void_p(t.data_ptr() - 1), 0, 1)                        # one byte in front of the first
+    new = guard.check("after the two deliberate out-of-bounds writes")
+    # a kernel's overrun: index_put_ cannot go out of bounds, so use a raw device copy 12 bytes past a SECOND tensor
+    u = torch.ones(64, device="cuda:0")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy(C.c_void_p(u.data_ptr() + 64 * 4 + 8), C.c_void_p(t.data_ptr()), 4, 3)     # device -> device
+    del u                                                                     # caught at free
+    torch.cuda.synchronize()
+    return {"ok": True, "expected_violations": 3, "found_by_check": new}
+
+
+def _grads(render, p, face, eyes, n_samples, t_rand, dev, precision, hidden=384, feat_nc=258, ray_tile=None, rb=None):
+    pd = {k: v.to(dev) for k, v in p.items()}
+    leaves = {k: pd[k].clone().requires_grad_(True) for k in ("R", "T", "shape_code", "gaze", "appea_code")}
+    fp = {k: v.to(dev).clone().requires_grad_(True) for k, v in face.items()}
+    ep = {k: v.to(dev).clone().requires_grad_(True) for k, v in eyes.items()}
+    out = render.render_two_stream(pd["xy"], leaves["R"], leaves["T"], pd["Kinv"], leaves["shape_code"], leaves["gaze"],
+                                   leaves["appea_code"], fp, ep, n_samples=n_samples, t_rand=t_rand.to(dev), precision=precision,
+                                   hidden=hidden, feat_nc=feat_nc, ray_tile=ray_tile,
+                                   ray_bias_face=None if rb is None else rb[0].to(dev), ray_bias_eyes=None if rb is None else rb[1].to(dev))
+    loss = sum((out["feat_" + t] ** 2).sum() * 1e-3 + out["bg_alpha_" + t].sum() for t in ("face", "eyes"))
+    loss.backward()
+    gs = [v.grad for d in (leaves, fp, ep) for v in d.values()]
+    return out, gs
+
+
+def sc_hot_path(guard, args):
+    import numpy as np
+    import torch
+    from gazenerf_amd import render, synth
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(args.seed)
+    nets = {}
+
+    def params(hidden, feat_nc):
+        if (hidden, feat_nc) not in nets:
+            nets[(hidden, feat_nc)] = (synth.hash_mlp_params("face", seed=6, density_scale=10.0, hidden=hidden, feat_nc=feat_nc),
+                                       synth.hash_mlp_params("eyes", seed=6, density_scale=10.0, hidden=hidden, feat_nc=feat_nc))
+        return nets[(hidden, feat_nc)]
+    log, ok = [], True
+    for case in range(args.cases):
+        B = int(rng.choice([1, 2, 3, 5, 17, 64, 65, 66, 100, 129, 130, 200])) if rng.random() < 0.7 else int(rng.integers(1, 201))
+        n_rays = int(rng.integers(1, 301)) if B <= 20 else int(rng.integers(1, 33))
+        n_samples = int(rng.choice([2, 7, 16, 32, 33, 64, 96, 192]))
+        precision = "fp32" if case % 3 else "bf16x3"
+        hidden = int(rng.choice([384, 384, 250, 96, 32]))
+        feat_nc = int(rng.choice([258, 258, 3, 64, 200, 288]))
+        face, eyes = params(hidden, feat_nc)
+        ray_tile = int(rng.choice([256, 512])) if (rng.random() < 0.25 and n_rays > 256) else None
+        rb = None
+        if rng.random() < 0.3:
+            g = torch.Generator().manual_seed(case)
+            rb = [0.1 * torch.randn(B, n_rays, hidden // 2, generator=g) for _ in range(2)]
+        sub = (torch.arange(n_rays) * 251 + 5 + case) % 4096
+        p = synth.synth_problem(64, batch=B, camera=str(case % 45), seed=case, ray_subset=sub)
+        t_rand = synth.synth_jitter(B, n_rays, n_samples, seed=case)
+        tag = "%s B %d rays %d samples %d hidden %d feat %d tile %s bias %d" % (precision, B, n_rays, n_samples, hidden, feat_nc, ray_tile,
+                                                                              rb is not None)
+        out, gs = _grads(render, p, face, eyes, n_samples, t_rand, dev, precision, hidden, feat_nc, ray_tile, rb)
+        new = guard.check("after fwd+bwd " + tag)
+        fin = finite(*out.values(), *gs)
+        # inference forward of the same problem with the optional outputs
+        pd = {k: v.to(dev) for k, v in p.items()}
+        with torch.no_grad():
+            o2 = render.render_two_stream(pd["xy"], pd["R"], pd["T"], pd["Kinv"], pd["shape_code"], pd["gaze"], pd["appea_code"],
+                                          {k: v.to(dev) for k, v in face.items()}, {k: v.to(dev) for k, v in eyes.items()},
+                                          n_samples=n_samples, precision=precision, hidden=hidden, feat_nc=feat_nc,
+                                          return_depth=True, return_weights=True)
+        new += guard.check("after inference fwd " + tag)
+        fin = fin and finite(*[v for v in o2.values() if torch.is_tensor(v)])
+        del out, gs, o2, pd
+        ok = ok and fin and new == 0
+        log.append("%s %s" % ("ok  " if (fin and new == 0) else "FAIL", tag))
+        print(log[-1], file=sys.stderr, flush=True)
+    # the tiled training entry point (what bench.py's step runs), ragged last tile
+    face, eyes = params(384, 258)
+    p = {k: v.to(dev) for k, v in synth.synth_problem(64, batch=1, camera="3", seed=3, ray_subset=torch.arange(700)).items()}
+    fp = {k: v.to(dev).requires_grad_(True) for k, v in face.items()}
+    ep = {k: v.to(dev).requires_grad_(True) for k, v in eyes.items()}
+    for k in ("R", "T", "shape_code", "gaze", "appea_code"):
+        p[k].requires_grad_(True)
+    for precision in ("fp32", "bf16x3"):
+        render.render_two_stream_tiled(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"], p["appea_code"], fp, ep,
+                                       loss_fn=lambda out, sl: sum((out["feat_" + t] ** 2).mean() + out["bg_alpha_" + t].mean()
+                                                                   for t in ("face", "eyes")),
+                                       n_samples=64, ray_tile=256, t_rand=synth.synth_jitter(1, 700, 64, seed=1).to(dev), precision=precision)
+        new = guard.check("after render_two_stream_tiled " + precision)
+        fin = finite(*[v.grad for v in fp.values()], *[v.grad for v in ep.values()])
+        ok = ok and fin and new == 0
+    return {"ok": ok, "cases": log}
+
+
+def sc_many_images(guard, args):
+    import torch
+    from gazenerf_amd import neural_render, render, synth
+    from oracle import oracle as O
+    dev = torch.device("cuda:0")
+    ok, log = True, []
+    face = synth.hash_mlp_params("face", seed=6, density_scale=10.0)
+    eyes = synth.hash_mlp_params("eyes", seed=6, density_scale=10.0)
+    for B, n_rays, n_samples in ((144, 16, 32), (65, 8, 16), (129, 4, 64), (256, 2, 8)):
+        for precision in ("fp32", "bf16x3"):
+            sub = (torch.arange(n_rays) * 251 + 5) % 4096
+            p = synth.synth_problem(64, batch=B, camera="3", seed=21, ray_subset=sub)
+            t_rand = synth.synth_jitter(B, n_rays, n_samples, seed=9)
+            out, gs = _grads(render, p, face, eyes, n_samples, t_rand, dev, precision)
+            new = guard.check("after fwd+bwd of %d images (%s)" % (B, precision))
+            fin = finite(*out.values(), *gs)
+            ok = ok and fin and new == 0
+            log.append("%s hot path %d images x %d rays x %d samples %s" % ("ok  " if fin and new == 0 else "FAIL", B, n_rays, n_samples, precision))
+            print(log[-1], file=sys.stderr, flush=True)
+            del out, gs
+    # the upsampler with more stacked maps than one round of workgroups (B >= 10 training images = 29+ maps)
+    for batch, feat_nc, side, n_blocks in ((29, 258, 16, 2), (40, 258, 16, 1), (70, 64, 16, 2), (31, 129, 32, 1)):
+        params = synth.hash_renderer_params(seed=7, feat_nc=feat_nc, n_blocks=n_blocks, min_feat=32, weight_scale=2.0)
+        x = synth.synth_featmap(batch, feat_nc, side, seed=2)
+        xg = x.clone().requires_grad_(True)
+        pg = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        ref = O.neural_renderer(pg, xg, n_blocks)
+        w = torch.linspace(0.5, 1.5, ref[0].numel()).reshape(ref[0].shape)
+        (ref * w).sum().backward()
+        xd = x.to(dev).clone().requires_grad_(True)
+        pd = {k: v.to(dev).clone().requires_grad_(True) for k, v in params.items()}
+        img = neural_render(xd, pd, n_blocks=n_blocks, min_feat=32)
+        (img * w.to(dev)).sum().backward()
+        new = guard.check("after upsampler fwd+bwd of %d maps" % batch)
+        e_img = float((img.detach().cpu() - ref.detach()).abs().max())
+        worst = max([rel_l2(xd.grad, xg.grad)] + [rel_l2(pd[k].grad, pg[k].grad) for k in pg])
+        good = e_img <= 1e-4 and worst <= 1e-3 and new == 0
+        ok = ok and good
+        log.append("%s upsampler %d maps x %d ch x %d^2, %d block(s): image %.1e gradients %.1e" % (
+            "ok  " if good else "FAIL", batch, feat_nc, side, n_blocks, e_img, worst))
+        print(log[-1], file=sys.stderr, flush=True)
+    return {"ok": ok, "cases": log}
+
+
+def sc_upsample(guard, args):
+    import numpy as np
+    import torch
+    from gazenerf_amd import neural_render, synth
+    from oracle import oracle as O
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(args.seed)
+    special = [32, 64, 128, 129, 256, 258, 48, 96, 100]
+    shapes = []
+    for case in range(args.cases):
+        n_blocks = int(rng.integers(1, 4))
+        side = int(rng.choice([16, 32]))
+        if side << n_blocks > 128:
+            n_blocks = 2 if side == 32 else 3
+        feat_nc = int(rng.choice(special)) if rng.random() < 0.6 else int(rng.integers(3, 301))
+        min_feat = int(rng.integers(1, feat_nc + 1)) if rng.random() < 0.5 else max(1, feat_nc >> int(rng.integers(0, 4)))
+        batch = int(rng.integers(1, 25)) if feat_nc <= 129 else int(rng.integers(1, 9))
+        shapes.append((batch, feat_nc, side, n_blocks, min_feat, True))
+    shapes.append((7, 258, 64, 3, 32, False))          # cfg4: the step's 3B + 1 stacked maps (oracle too slow: finite + guards only)
+    shapes.append((1, 258, 64, 3, 32, False))          # B = 1 inference size
+    ok, log = True, []
+    for i, (batch, feat_nc, side, n_blocks, min_feat, with_oracle) in enumerate(shapes):
+        params = synth.hash_renderer_params(seed=100 + i, feat_nc=feat_nc, n_blocks=n_blocks, min_feat=min_feat, weight_scale=2.0)
+        x = synth.synth_featmap(batch, feat_nc, side, seed=i)
+        xd = x.to(dev).clone().requires_grad_(True)
+        pd = {k: v.to(dev).clone().requires_grad_(True) for k, v in params.items()}
+        img = neural_render(xd, pd, n_blocks=n_blocks, min_feat=min_feat)
+        new = guard.check("after upsampler fwd case %d" % i)
+        w = torch.linspace(0.5, 1.5, img[0].numel()).reshape(img[0].shape)
+        (img * w.to(dev)).sum().backward()
+        new += guard.check("after upsampler bwd case %d" % i)
+        good = new == 0 and finite(img, xd.grad, *[v.grad for v in pd.values()])
+        note = ""
+        if with_oracle:
+            xg = x.clone().requires_grad_(True)
+            pg = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+            ref = O.neural_renderer(pg, xg, n_blocks)
+            (ref * w).sum().backward()
+            e_img = float((img.detach().cpu() - ref.detach()).abs().max())
+            worst = max([rel_l2(xd.grad, xg.grad)] + [rel_l2(pd[k].grad, pg[k].grad) for k in pg])
+            good = good and e_img <= 1e-4 and worst <= 1e-3
+            note = ": image %.1e gradients %.1e" % (e_img, worst)
+        ok = ok and good
+        log.append("%s feat_nc %d min_feat %d side %d blocks %d batch %d%s" % ("ok  " if good else "FAIL", feat_nc, min_feat, side, n_blocks,
+                                                                             batch, note))
+        print(log[-1], file=sys.stderr, flush=True)
+        del img, xd, pd
+    return {"ok": ok, "cases": log}
+
+
+def sc_aux(guard, args):
+    import torch
+    from gazenerf_amd import merge, render, synth
+    from gazenerf_amd.module import HotPathRenderer
+    dev = torch.device("cuda:0")
+    ok, log = True, []
+
+    def note(good, what):
+        nonlocal ok
+        ok = ok and good
+        log.append("%s %s" % ("ok  " if good else "FAIL", what))
+        print(log[-1], file=sys.stderr, flush=True)
+    g = torch.Generator().manual_seed(0)
+    for B, C_, n_pix in ((2, 258, 4096), (3, 258, 1000), (1, 6, 17), (5, 129, 256), (9, 258, 300)):
+        t = lambda *s: torch.randn(*s, generator=g).to(dev).requires_grad_(True)
+        ff, af, fe, ae, bg, gz = t(B, C_, n_pix), t(B, 1, n_pix), t(B, C_, n_pix), t(B, 1, n_pix), t(1, C_, n_pix), t(B, 2)
+        mf, ep, m = merge.merge_featmaps(ff, af, fe, ae, bg, gz)
+        (mf.sum() + (ep ** 2).sum() + (m * 0.5).sum()).backward()
+        new = guard.check("after merge fwd+bwd B %d C %d pix %d" % (B, C_, n_pix))
+        note(new == 0 and finite(mf, ep, m, ff.grad, af.grad, fe.grad, ae.grad, bg.grad, gz.grad), "merge B %d C %d pix %d" % (B, C_, n_pix))
+    face = {k: v.to(dev) for k, v in synth.hash_mlp_params("face", seed=0, density_scale=50.0).items()}
+    for n_rays, n_c, n_f, B in ((300, 64, 128, 1), (17, 32, 64, 2), (1, 8, 9, 3), (1000, 64, 128, 1)):
+        p = {k: v.to(dev) for k, v in synth.synth_problem(64, batch=B, camera="4", seed=2, ray_subset=torch.arange(n_rays) * 3 % 4096).items()}
+        with torch.no_grad():
+            out = render.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"], p["appea_code"], face, face,
+                                           n_samples=n_c, return_weights=True)
+            zv = render.sample_zvals(p["xy"], p["R"], p["T"], p["Kinv"], n_samples=n_c)
+            new = guard.check("after gnr_sample_zvals")
+            u = torch.rand(B * n_rays, n_f + 1, generator=g).to(dev)
+            for uu in (None, u):
+                z = render.importance_resample(out["w_face"], zv, n_fine=n_f, u=uu)
+                new += guard.check("after gnr_resample rays %d coarse %d fine %d" % (n_rays, n_c, n_f))
+                # the fine pass through the explicit edges (single stream)
+                fine = render.render_two_stream(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["gaze"], p["appea_code"], face, None,
+                                                n_samples=n_c + n_f, z_edges=z)
+                new += guard.check("after the fine pass")
+        note(new == 0 and finite(z, zv, fine["feat_face"]), "resample + fine pass rays %d coarse %d fine %d batch %d" % (n_rays, n_c, n_f, B))
+    # the hierarchical module and the view-direction option (per-ray bias computed on the device: gnr_vd.hip)
+    for kw in ({"hier_sampling": True}, {"include_vd": True}):
+        try:
+            net = HotPathRenderer(**kw).to(dev)
+        except TypeError:
+            log.append("skip HotPathRenderer(%s): not a constructor option" % kw)
+            continue
+        p = {k: v.to(dev) for k, v in synth.synth_problem(64, batch=2, camera="7", seed=5, ray_subset=torch.arange(200) * 7 % 4096).items()}
+        out = net(p["xy"], p["R"], p["T"], p["Kinv"], p["shape_code"], p["appea_code"], p["gaze"], for_train=True)
+        ts = [v for v in out.values() if torch.is_tensor(v) and v.requires_grad]
+        sum((t ** 2).mean() for t in ts).backward()
+        new = guard.check("after HotPathRenderer(%s) fwd+bwd" % kw)
+        note(new == 0 and finite(*ts, *[q.grad for q in net.parameters() if q.grad is not None]), "HotPathRenderer(%s)" % kw)
+    return {"ok": ok, "cases": log}
+
+
+def sc_network_step(guard, args):
+    import torch
+    from gazenerf_amd import GazeNeRFNetAMD, losses, synth
+    dev = torch.device("cuda:0")
+    ok, log = True, []
+    for B, S, precision in ((2, 64, "fp32"), (2, 64, "bf16x3"), (2, 16, "fp32"), (3, 32, "fp32")):
+        I = 8 * S
+        torch.manual_seed(1234)
+        net = GazeNeRFNetAMD(featmap_size=S, pred_img_size=I, precision=precision).to(dev)
+        p = {k: v.to(dev) for k, v in synth.synth_problem(S, batch=B, camera="3", seed=100).items()}
+        t_rand = synth.synth_jitter(B, S * S, 64, seed=7).to(dev)
+        gt = torch.rand(B, 3, I, I, generator=torch.Generator().manual_seed(50)).to(dev)
+        yy, xx = torch.meshgrid(torch.arange(float(I)), torch.arange(float(I)), indexing="ij")
+        k = I / 512.0
+        disk = lambda cx, cy, r: (((xx - cx * k) ** 2 + (yy - cy * k) ** 2) <= (r * k) ** 2).float().expand(B, 1, -1, -1).to(dev)
+        face_mask, left_eye, right_eye = disk(256, 256, 200), disk(190, 220, 28), disk(322, 220, 28)
+        full_eye = torch.clamp(left_eye + right_eye, max=1.0)
+        zeros = lambda n: torch.zeros(B, n, device=dev)
+        opt_codes = {"bg": None, "iden": zeros(100), "expr": zeros(79), "appea": zeros(127)}
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
+        for it in range(2):
+            opt.zero_grad(set_to_none=True)
+            pred = net("train", p["xy"], None, None, p["shape_code"], p["appea_code"], p["gaze"], p["R"], p["T"], p["Kinv"],
+                       t_rand=t_rand)["coarse_dict"]
+            new = guard.check("after the network forward (B %d, side %d, %s, step %d)" % (B, S, precision, it))
+            loss = losses.total_loss(pred, gt, face_mask, full_eye, left_eye, right_eye, opt_codes, use_l1=False, epoch=1,
+                                     discriminator=None, batch_num=it, vgg=None, vgg_importance=1.0)["total_loss"]
+            loss.backward()
+            new += guard.check("after the network backward (B %d, side %d, %s, step %d)" % (B, S, precision, it))
+            opt.step()
+            new += guard.check("after Adam (B %d, side %d, %s, step %d)" % (B, S, precision, it))
+            fin = finite(loss, *[q.grad for q in net.parameters()], *net.parameters())
+            good = new == 0 and fin
+            ok = ok and good
+            log.append("%s whole-network step B %d side %d %s #%d: loss %.6f" % ("ok  " if good else "FAIL", B, S, precision, it, float(loss)))
+            print(log[-1], file=sys.stderr, flush=True)
+        del net, opt, pred, loss
+    return {"ok": ok, "cases": log}
+
+
+SCENARIOS = {"selftest": sc_selftest, "hot_path": sc_hot_path, "many_images": sc_many_images, "upsample": sc_upsample, "aux": sc_aux,
+             "network_step": sc_network_step}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("scenario", choices=sorted(SCENARIOS))
+    ap.add_argument("--poison", action="store_true", help="fill every new allocation with 0xFF bytes (NaN in fp32)")
+    ap.add_argument("--binding", choices=("ctypes", "torch_ext"), default="ctypes")
+    ap.add_argument("--cases", type=int, default=12)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    if args.poison:
+        os.environ["GNR_GUARD_POISON"] = "1"
+    os.environ["GNR_BINDING"] = args.binding
+    g, _alloc = install()
+    import torch
+    guard = Guard(g)
+    if args.binding == "ctypes":
+        guard.wrap_lib()
+    res = {"scenario": args.scenario, "poison": bool(args.poison), "binding": args.binding}
+    try:
+        res.update(SCENARIOS[args.scenario](guard, args))
+        torch.cuda.synchronize()
+        guard.check("end of scenario")
+    except Exception as e:                  # noqa: BLE001 -- the line must still say what the guards saw
+        import traceback
+        traceback.print_exc()
+        res.update(ok=False, error="%s: %s" % (type(e).__name__, e))
+    res.update(guard.result())
+    print(json.dumps(res), flush=True)
+    want = res.get("expected_violations", 0)
+    sys.exit(0 if (res.get("ok") and res["violations"] == want) else 1)
+
+
+if __name__ == "__main__":
+    main()

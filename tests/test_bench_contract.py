@@ -4,6 +4,8 @@ two ranks itself (gloo override, both on one GPU: test-only) and reporting the w
 same under an external torch.distributed.run; the cfg4 whole-network step with all 5 015 714 gradients exchanged."""
 import json
 import os
+import re
+import socket
 import subprocess
 import sys
 
@@ -17,12 +19,37 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
 TWO_ON_ONE = {"GNR_BENCH_DEVICE": "0", "GNR_BENCH_BACKEND": "gloo"}
 
 
+def _free_port():
+    """A port that was free a moment ago (bound, read, released) -- never a fixed number: a collision on a shared host is one
+    more way to lose the run (VERDICT round 5, weak #9)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _why(stderr):
+    """What a failed bench.py run said about ITSELF: every `bench.py: rank k of N failed: ...` line with the traceback behind
+    the first one, the pre-flight memory lines, then the tail.  torch.distributed.run's summary table, which is all the last
+    2000 characters hold, names the ranks but not the error (round 5 lost the cause of a red driver run that way)."""
+    lines = stderr.splitlines()
+    failed = [i for i, l in enumerate(lines) if re.search(r"bench\.py: rank \d+ of \d+ failed", l)]
+    out = ["--- ranks that failed (%d) ---" % len(failed)] + [lines[i] for i in failed]
+    if failed:
+        out += ["--- traceback behind the first ---"] + lines[failed[0] + 1:failed[0] + 40]
+    first_tb = next((i for i, l in enumerate(lines) if l.startswith("Traceback (most recent call last)")), None)
+    if first_tb is not None and not failed:
+        out += ["--- first traceback ---"] + lines[first_tb:first_tb + 40]
+    out += ["--- memory pre-flight ---"] + [l for l in lines if "hipMemGetInfo" in l][:16]
+    out += ["--- stderr tail ---", stderr[-1500:]]
+    return "\n".join(out)
+
+
 def _run(cmd, env=None, strict=False):
     e = dict(os.environ)
     e.pop("WORLD_SIZE", None)
     e.update(env or {})
     r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 0, _why(r.stderr)
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]   # launcher / gloo chatter is not JSON
     assert len(lines) == 1, r.stdout[-2000:]
     if strict:      # NOTHING but the line on stdout (round 5: RCCL's NCCL_DEBUG=VERSION banner used to follow it -- bench.guard_stdout)
@@ -71,7 +98,7 @@ def test_gpus_flag_launches_the_ranks_itself():
 
 def test_two_ranks_under_an_external_launcher_report_the_aggregate():
     d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-              "--master-port", "29533", "bench.py", "--gpus", "2", "--side", "64", "--steps", "1", "--warmup", "1", "--no-alt"],
+              "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--side", "64", "--steps", "1", "--warmup", "1", "--no-alt"],
              env=TWO_ON_ONE)
     assert d["n_gpus"] == 2 and "cpu_baseline" not in d
     assert abs(d["value"] - 2 * 64 * 64 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
@@ -146,19 +173,23 @@ def test_world_size_8_rehearsal_through_the_self_launcher(what):
     reported -- so the driver's first 8-GPU RCCL run measures instead of debugging.  Step being scaled:
     trainer/gazenerf_trainer.py:478-534 (cfg4); the B = 1 render loop utils/render_utils.py:199-219 (strong)."""
     if what == "cfg4":
-        d = _run([sys.executable, "bench.py", "--gpus", "8", "--config", "cfg4", "--steps", "2", "--warmup", "1"], env=TWO_ON_ONE)
-        assert d["config"]["trainable_floats"] == 5015714
+        # the LAUNCHER is under test, not 8 x 16 GiB of saved activations on one device (round 5: the driver's box lost three
+        # ranks at the full size): cfg4's test-only 16 x 16 feature map (128 x 128 images), 0.3 GiB per rank
+        d = _run([sys.executable, "bench.py", "--gpus", "8", "--config", "cfg4", "--side", "16", "--steps", "2", "--warmup", "1"],
+                 env=TWO_ON_ONE)
+        n_train = 5015714 - 258 * (64 * 64 - 16 * 16)                 # bg_featmap [1, 258, S, S] is a parameter
+        assert d["config"]["trainable_floats"] == n_train and d["config"]["test_only_size"] is True and "TEST-ONLY" in d["metric"]
         ar = d["allreduce"]
-        assert ar["floats"] == 5015714 and ar["bytes"] == 4 * 5015714 and ar["buckets"] == 3 and ar["world_size_formed"] == 8
+        assert ar["floats"] == n_train and ar["bytes"] == 4 * n_train and ar["buckets"] == 3 and ar["world_size_formed"] == 8
         assert ar["calls_timed"] == 2 and ar["ms"] > 0
-        assert abs(d["value"] - 8 * 2 * 4096 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+        assert abs(d["value"] - 8 * 2 * 256 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     else:
-        d = _run([sys.executable, "bench.py", "--gpus", "8", "--scaling", "strong", "--micro", "4096", "--steps", "1", "--warmup", "1",
-                  "--no-alt"], env=TWO_ON_ONE)
-        assert d["scaling"] == "strong" and d["config"]["rays_per_step_per_gpu"] == 512 * 512 // 8
+        d = _run([sys.executable, "bench.py", "--gpus", "8", "--scaling", "strong", "--side", "128", "--micro", "1024", "--steps", "1",
+                  "--warmup", "1", "--no-alt"], env=TWO_ON_ONE)
+        assert d["scaling"] == "strong" and d["config"]["rays_per_step_per_gpu"] == 128 * 128 // 8
         assert d["allreduce"]["floats"] == 2 * 1518979 and d["allreduce"]["world_size_formed"] == 8
-        assert abs(d["value"] - 512 * 512 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
-        assert {s["stage"]: s["launches_timed"] for s in d["stages"]}["fwd_mlp"] == 8        # 32768 rays per rank / 4096
+        assert abs(d["value"] - 128 * 128 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+        assert {s["stage"]: s["launches_timed"] for s in d["stages"]}["fwd_mlp"] == 2        # 2048 rays per rank / 1024
     assert d["n_gpus"] == 8 and "cpu_baseline" not in d and d["distributed"]["world_size_formed"] == 8
     host = d["host"]
     enq = host["host_enqueue_ms_per_step"][0]

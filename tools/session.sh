@@ -16,6 +16,9 @@
 #   traffic          tools/pmc_capture.py (FETCH_SIZE / WRITE_SIZE per launch)    -> traffic.txt
 #   rccl1            the forced one-rank RCCL bench lines                         -> bench_forced_rccl_ws1*.json
 #   ws8              bench.py --gpus 8 on one GPU over gloo (cfg4 + strong)       -> bench_ws8_*.json
+#   ws8diag:<n>      n repeats of the FULL-SIZE 8-rank cfg4 rehearsal (the run that went red on the driver's box in round 5), then n at
+#                    the test-only --side 16, every rank's stderr kept; a failed repeat's cause lines -> ws8diag.txt
+#   guard            tests/guard/run_guarded.py, long forms (every scenario, both bindings, with and without --poison) -> guard.txt
 #   noise            tests/diagnostics/grad_noise_draws.py                        -> grad_noise_draws.txt
 #   dropterm         the bf16x3 gate on a build with one cross term dropped       -> grad_gate_dropped_term.txt
 #   x3outlier        anatomy of the gate's outlier draw (bf16x3 vs fp32 kernels)  -> x3_outlier_draw13.txt
@@ -76,6 +79,31 @@ for STEP in "$@"; do
       GNR_BENCH_BACKEND=gloo GNR_BENCH_DEVICE=0 timeout 1200 python bench.py --gpus 8 --config cfg4 --steps 5 --warmup 2 > $O/bench_ws8_gloo_cfg4.json 2> $O/bench_ws8_gloo_cfg4.err; jline $O/bench_ws8_gloo_cfg4.json
       GNR_BENCH_BACKEND=gloo GNR_BENCH_DEVICE=0 timeout 1200 python bench.py --gpus 8 --scaling strong --micro 4096 --steps 3 --warmup 1 --no-alt > $O/bench_ws8_gloo_strong.json 2> $O/bench_ws8_gloo_strong.err; jline $O/bench_ws8_gloo_strong.json
       grep -v "^\[W\|^W0\|^\*\*\*" $O/bench_ws8_gloo_cfg4.err | head -60 > $O/bench_ws8_gloo_cfg4_stderr_head.txt;;
+    ws8diag:*)
+      N=${STEP#ws8diag:}
+      { echo "# tools/session.sh $NAME ws8diag:$N ($(python -c 'from gazenerf_amd import _lib; print(_lib.build_info())')): bench.py --gpus 8 --config cfg4 [--side 16] --steps 2 --warmup 1, eight ranks on one GPU over gloo"
+        for SIDE in 64 16; do for i in $(seq 1 $N); do
+          GNR_BENCH_BACKEND=gloo GNR_BENCH_DEVICE=0 timeout 900 python bench.py --gpus 8 --config cfg4 --side $SIDE --steps 2 --warmup 1 > $O/ws8diag_${SIDE}_$i.json 2> $O/ws8diag_${SIDE}_$i.err
+          RC=$?
+          echo "side $SIDE repeat $i rc=$RC $(python -c "import json,sys; d=json.loads(open('$O/ws8diag_${SIDE}_$i.json').read().strip().splitlines()[-1]); print('ms/step %.2f' % d['ms_per_step'], 'allreduce ms %.2f' % d['allreduce']['ms'])" 2>/dev/null)"
+          if [ $RC -ne 0 ]; then grep -n "failed:\|Error\|error\|hipMemGetInfo\|HSA_STATUS\|out of memory" $O/ws8diag_${SIDE}_$i.err | head -40; else rm -f $O/ws8diag_${SIDE}_$i.err; fi
+        done; done; } > $O/ws8diag.txt 2>&1
+      cat $O/ws8diag.txt | cut -c1-300;;
+    guard)
+      { echo "# tools/session.sh $NAME guard ($(python -c 'from gazenerf_amd import _lib; print(_lib.build_info())')): tests/guard/run_guarded.py <scenario> ... -- one JSON line per run"
+        for B in ctypes torch_ext; do for P in "" "--poison"; do
+          for SC in hot_path upsample; do timeout 1500 python tests/guard/run_guarded.py $SC --binding $B $P --cases 40 --seed 11 2> $O/guard_${SC}_${B}${P}.err; done
+          for SC in many_images aux network_step; do timeout 1500 python tests/guard/run_guarded.py $SC --binding $B $P 2> $O/guard_${SC}_${B}${P}.err; done
+        done; done; } > $O/guard.txt 2>&1
+      python - $O/guard.txt <<'P'
+import json, sys
+for l in open(sys.argv[1]):
+    if l.startswith("{"):
+        d = json.loads(l)
+        print(d["scenario"], d["binding"], "poison" if d["poison"] else "-", "ok" if d.get("ok") else "FAIL", "violations", d["violations"], "calls checked", d["calls_checked"],
+              "allocations", d["allocations"], "peak GiB %.1f" % (d["peak_live_bytes"] / 2**30), d.get("error", ""))
+P
+      ;;
     noise) timeout 2400 python tests/diagnostics/grad_noise_draws.py > $O/grad_noise_draws.txt 2> $O/grad_noise_draws.err; tail -8 $O/grad_noise_draws.txt | cut -c1-250;;
     dropterm)
       GNR_EXTRA_FILES="gnr_bwd3.hip" GNR_EXTRA_HIPCC_FLAGS="-DGNR_ABLATE=128" python -m gazenerf_amd.build --no-torch-ext > $O/dropterm_build.log 2>&1
