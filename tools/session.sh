@@ -19,6 +19,7 @@
 #   ws8diag:<n>      n repeats of the FULL-SIZE 8-rank cfg4 rehearsal (the run that went red on the driver's box in round 5), then n at
 #                    the test-only --side 16, every rank's stderr kept; a failed repeat's cause lines -> ws8diag.txt
 #   guard            tests/guard/run_guarded.py, long forms (every scenario, both bindings, with and without --poison) -> guard.txt
+#   hostspin[:args]  tools/host_spin_probe.sh: per-thread CPU time + native backtraces of the default bench while its steps run -> hostspin/
 #   noise            tests/diagnostics/grad_noise_draws.py                        -> grad_noise_draws.txt
 #   dropterm         the bf16x3 gate on a build with one cross term dropped       -> grad_gate_dropped_term.txt
 #   x3outlier        anatomy of the gate's outlier draw (bf16x3 vs fp32 kernels)  -> x3_outlier_draw13.txt
@@ -104,6 +105,7 @@ for l in open(sys.argv[1]):
               "allocations", d["allocations"], "peak GiB %.1f" % (d["peak_live_bytes"] / 2**30), d.get("error", ""))
 P
       ;;
+    hostspin*) A=${STEP#hostspin}; A=${A#:}; bash tools/host_spin_probe.sh $NAME/hostspin${A:+_}${A// /_} $A 2>&1 | tail -40;;
     noise) timeout 2400 python tests/diagnostics/grad_noise_draws.py > $O/grad_noise_draws.txt 2> $O/grad_noise_draws.err; tail -8 $O/grad_noise_draws.txt | cut -c1-250;;
     dropterm)
       GNR_EXTRA_FILES="gnr_bwd3.hip" GNR_EXTRA_HIPCC_FLAGS="-DGNR_ABLATE=128" python -m gazenerf_amd.build --no-torch-ext > $O/dropterm_build.log 2>&1
