@@ -49,6 +49,7 @@ PEAK_BF16X3_TFLOPS = 16.0 * PEAK_FP32_MFMA_TFLOPS / 3.0
 HBM_PEAK_GBS = 8000.0
 HBM_STREAM_GBS = 6290.0                       # measured float4 copy on MI355X (same table): what a streaming kernel can reach
 PEAK_CLOCK_MHZ = 2400.0                       # the clock both MFMA peaks are quoted at
+FEAT_NC, FEAT_PAD = 258, 288                  # opt.featmap_nc; the saved activation layout's padded feature axis (csrc/gnr_internal.h)
 # the weight-gradient stage: its main kernel instance first (the 384^2 layers), then what else runs inside the bracket
 WGRAD_KERNEL = {False: "gnr::wgrad2w_kernel<false, false, 6, 3> + its other instances (<.., 3, 3>: 96 x 192, <.., 6, 1>: 192 x 64) + gnr::wgrad_reduce_batch_kernel (one launch for the 13 split-K reductions)",
                 True: "gnr::wgrad3_tr_kernel<3, false> + its other instances + gnr::wgrad_reduce_batch_kernel"}
@@ -652,7 +653,10 @@ def run_cfg2b(ctx):
             # gradients + 3 scalars.  The layout pads the feature axis to 288 (18 tiles of 16): the padded figure is
             # reported beside it, and `frac` is the algorithmic one.
             per = lambda ch: m * (ch * 4 + 8 + 8) + rays_per_launch * (ch * 4 + 4 + 8)
-            nbytes, nbytes_pad = per(258), per(288)
+            # three channel counts, all derived from the problem: the algorithm's feat_nc; what comp_bwd_kernel
+            # READS since round 5 (the 16-channel groups that hold real channels); the saved layout's FEAT_PAD
+            feat_nc, feat_read, feat_layout = FEAT_NC, (FEAT_NC + 15) & ~15, FEAT_PAD
+            nbytes, nbytes_read, nbytes_pad = per(feat_nc), per(feat_read), per(feat_layout)
             a = mean(stage_ms["comp_bwd"])
             gbs, gbs_pad = nbytes / (a * 1e-3) / 1e9, nbytes_pad / (a * 1e-3) / 1e9
             tr, src = pmc_traffic("gnr::comp_bwd_kernel", rays_per_launch, n_p)
@@ -661,11 +665,14 @@ def run_cfg2b(ctx):
                            "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "peak_measured_stream": HBM_STREAM_GBS,
                            "frac_of_measured_stream": gbs / HBM_STREAM_GBS,
                            "achieved_incl_padding": gbs_pad, "frac_incl_padding": gbs_pad / HBM_PEAK_GBS,
-                           "peak_basis": "frac: algorithmic bytes (258 feature channels) against the 8.0 TB/s HBM3E spec; "
+                           "peak_basis": "frac: algorithmic bytes (%d feature channels) against the 8.0 TB/s HBM3E spec; "
                                          "frac_of_measured_stream: against the 6.29 TB/s a float4 copy achieves on this chip "
-                                         "(MI355X_MICROARCH.md chip-level table); *_incl_padding: the 288-channel layout's bytes",
+                                         "(MI355X_MICROARCH.md chip-level table); bytes_per_launch_read: the %d channels the kernel "
+                                         "reads; *_incl_padding: the %d-channel layout's bytes" % (feat_nc, feat_read, feat_layout),
                            "avg_ms": a, "launches_timed": len(stage_ms["comp_bwd"]),
-                           "bytes_per_launch": nbytes, "bytes_per_launch_incl_padding": nbytes_pad, "traffic": tr,
+                           "bytes_per_launch": nbytes, "bytes_per_launch_read": nbytes_read, "bytes_per_launch_incl_padding": nbytes_pad,
+                           "channels": {"algorithmic": feat_nc, "read_by_kernel": feat_read, "saved_layout": feat_layout},
+                           "traffic_over_read": tr / nbytes_read if tr else None, "traffic": tr,
                            "traffic_over_algorithmic": tr / nbytes if tr else None, "traffic_source": src,
                            "share_of_step": a * 2 * launches_per_step / ms})
         step_flop = (3 if fwdbwd else 1) * n_local * n_p * 2 * FLOP_PER_SAMPLE_STREAM      # this rank's share

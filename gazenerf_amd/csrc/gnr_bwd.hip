@@ -423,6 +423,29 @@ struct BwdScratch {
     int geo_blocks;
 };
 
+// The arena of one weight set's queued weight-gradient GEMMs: wgrad_arena_floats()'s bound raised to the largest single need
+// of the GEMMs run_bwd launches (step 5) -- in either precision, since the workspace is sized before the precision is known.
+// Sized from the launchers' own plan; tests/test_host_logic.py sweeps the batch on the CPU.
+static size_t bwd_wgrad_arena_floats(const GnrProblem* p) {
+    const long cpi = (long)p->n_rays * ((p->n_samples + CHUNK - 1) / CHUNK);
+    WgradShape g[16];
+    int n = 0;
+    auto add = [&](int lda, int nv, int ldb, int kv, int vec, int x3, int small) { g[n++] = WgradShape{lda, nv, ldb, kv, cpi, 0, vec, x3, small}; };
+    for (int x3 = 0; x3 < 2; ++x3) {
+        if (!x3 && p->feat_nc > 192 && p->feat_nc <= 288) {
+            add(FEAT_PAD, 192, H2, H2, 0, 0, 0);
+            add(FEAT_PAD, p->feat_nc - 192, H2, H2, 0, 0, 1);
+        } else {
+            add(FEAT_PAD, p->feat_nc, H2, H2, 0, x3, 0);
+        }
+        add(H2, H2, H, H, 0, x3, 0);            // RGB_layer_1
+        add(H, H, H, H, 1, x3, 0);              // RGB_layer_0 with the density-head rider
+        add(H, H, H, H, 0, x3, 0);              // the trunk's 384 x 384 layers
+        add(H, H, ENC_PAD, ENC_PAD, 0, x3, 0);  // the encoding columns of layers 0 and 5
+    }
+    return wgrad_arena_floats_for(g, n, p->batch, H, H);
+}
+
 static size_t carve_bwd(const GnrProblem* p, char* base, BwdScratch* sc) {
     const int cpr = (p->n_samples + CHUNK - 1) / CHUNK;
     const size_t n_rays_total = (size_t)p->batch * p->n_rays;
@@ -449,7 +472,7 @@ static size_t carve_bwd(const GnrProblem* p, char* base, BwdScratch* sc) {
     s.geo_part = take((size_t)p->batch * s.geo_blocks * 12);
     s.dbias = take((size_t)(N_CHAIN + 1) * p->batch * H);
     s.cs_part = nullptr;
-    s.wg_part = take(wgrad_arena_floats(p->batch, H, H));           // partial tiles of every weight-gradient GEMM of one weight set (gnr_wgrad.h)
+    s.wg_part = take(bwd_wgrad_arena_floats(p));           // partial tiles of every weight-gradient GEMM of one weight set (gnr_wgrad.h)
     s.vd = vd_on_device(p) ? take(vd_bwd_floats(p, 2)) : nullptr;
     if (sc) *sc = s;
     return off;
@@ -547,7 +570,7 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
         if (s == 0) stage_mark(GNR_STAGE_WGRAD, 0, st);
         // the split-K reductions of the GEMMs below are queued and run as ONE launch behind the last GEMM (gnr_wgrad.h)
         WgradDefer wd;
-        wgrad_defer_init(&wd, sc.wg_part, wgrad_arena_floats(p->batch, H, H));
+        wgrad_defer_init(&wd, sc.wg_part, bwd_wgrad_arena_floats(p));
         // GEMM shapes = the kernels' (H, H2); the last two arguments crop the written gradient to the network's width
         if (!bf16x3 && p->feat_nc > 192 && p->feat_nc <= 288) {
             // RGB_layer_2 (258 x 192): as ONE product its rows pad to two 192-row tiles, the second two-thirds empty

@@ -9,7 +9,7 @@
 // tests/diagnostics/cpu_bf16x3_grad_probe.py: gradients of a bf16x3 step sit inside the reference's own fp32-vs-fp64
 // noise on every tensor (worst rel-L2 9.96e-3 against 1.01e-2 for plain fp32; 3e-5 where fp32 has 3e-6).
 #include "gnr_bwd_common.h"
-#define CHAIN3_DUMP_BRANCH 1      // see gnr_chain3.h
+namespace gnr { constexpr bool kChain3DumpBranch = true; }       // see gnr_chain3.h
 #include "gnr_chain3.h"
 
 namespace gnr {

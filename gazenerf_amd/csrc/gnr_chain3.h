@@ -275,13 +275,12 @@ __device__ __forceinline__ QDump qdump(float* dst, int C, long chunk, int j, int
     return q;
 }
 
-// CHAIN3_DUMP_BRANCH (a per-translation-unit setting of the product, not an experiment switch): test qd.base at run time as well.  The branch splits the unrolled layer code
+// kChain3DumpBranch (a per-translation-unit constant of the product that every includer declares BEFORE this header -- a C++ constant, not a
+// preprocessor switch, so no -D on a compiler command line can flip it: ADVICE round 5): test qd.base at run time as well.  The branch splits the unrolled layer code
 // into basic blocks, which pins the hand-made instruction order better than sched_barrier does (pure MFMAs still move
 // across those before machine scheduling): measured on bwd3_chain_kernel 6.5 ms with the branch, 6.9 ms without; on
 // fwd3_kernel<true> the same branch cost 190 spilled registers and 1.3 ms.  Compiler behaviour, re-measure on upgrades.
-#ifndef CHAIN3_DUMP_BRANCH
-#define CHAIN3_DUMP_BRANCH 0
-#endif
+static_assert(kChain3DumpBranch || !kChain3DumpBranch, "declare `namespace gnr { constexpr bool kChain3DumpBranch = ...; }` before including gnr_chain3.h");
 
 struct XfLateNone {
     __device__ __forceinline__ void operator()(int, int, const f32x4&) const {}
@@ -299,7 +298,7 @@ __device__ __forceinline__ void convert_quad(f32x16& src, int r, BTile& dst, int
     unsigned h0, l0, h1, l1;
     split_pair(v.x, v.y, h0, l0);
     split_pair(v.z, v.w, h1, l1);
-    if (DUMP && !(ABL & 32) && (!CHAIN3_DUMP_BRANCH || qd.base)) {     // the training dump: the split itself (quads with bit 2 set: halves swapped)
+    if (DUMP && !(ABL & 32) && (!kChain3DumpBranch || qd.base)) {     // the training dump: the split itself (quads with bit 2 set: halves swapped)
         u32x4* p = (u32x4*)(qd.base + (8 * t + 2 * (r >> 2)) * 512 + (((r >> 2) & 1) ? qd.s1 : qd.s0));
         dump_store(p, (r >> 3) ? u32x4{l0, l1, h0, h1} : u32x4{h0, h1, l0, l1});
     }
@@ -331,7 +330,7 @@ __device__ __forceinline__ void conv_mid(ConvQuad& c) {
 template <bool DUMP>
 __device__ __forceinline__ void conv_finish(const ConvQuad& c, int r, BTile& dst, int t, const QDump& qd) {
     const unsigned l1 = lo_pair(c.v.z, c.v.w, c.h1);
-    if (DUMP && !(ABL & 32) && (!CHAIN3_DUMP_BRANCH || qd.base)) {
+    if (DUMP && !(ABL & 32) && (!kChain3DumpBranch || qd.base)) {
         u32x4* p = (u32x4*)(qd.base + (8 * t + 2 * (r >> 2)) * 512 + (((r >> 2) & 1) ? qd.s1 : qd.s0));
         dump_store(p, (r >> 3) ? u32x4{c.l0, l1, c.h0, c.h1} : u32x4{c.h0, c.h1, c.l0, l1});
     }

@@ -53,7 +53,7 @@ namespace {
 #ifndef GNR_C16_ABL
 #define GNR_C16_ABL 0       // timing experiments (wrong results; tools/ab_n1.sh): 1 no epilogue, 2 B rows of k-block 0 only, 4 A of k-block 0
                             // only, 8 (blur_lds) no stencil / MFMAs, 16 (blur_lds) no halo loads, 32 epilogue without its loads, 64 epilogue without its stores, 128 stores folded into
-                            // a 1 MiB window (L2-resident), 256 no persistent workgroups (conv16_persist_kernel off: same results)
+                            // a 1 MiB window (L2-resident)
 #endif
 constexpr int WPB = 4;       // waves per workgroup: they share a row slice (the A stream hits in L1) and take adjacent pixels
 constexpr float LEAK16 = 0.2f;
@@ -138,7 +138,7 @@ __device__ __forceinline__ void conv16_epilogue_prefetch(const Conv16Params& cp,
     }
 }
 
-template <int MT, int NT, bool PRE = false, bool RIDER = true>       // RIDER = false: the instance never carries the RGB branch (cp.rgb_w == NULL)
+template <int MT, int NT, bool PRE = false, bool RIDER = true>       // RIDER = false: an instance that never carries the RGB branch (none at present)
 __device__ __forceinline__ void conv16_plain_epilogue(const Conv16Params& cp, f32x4 (&acc)[MT][NT], int b, int n, int m0, int g,
                                                       const float* rgbw, const Conv16EpiPre<MT, NT>* pre = nullptr) {
     typedef typename Pix<NT>::T pv;
@@ -237,7 +237,8 @@ __device__ __forceinline__ void conv16_plain_epilogue(const Conv16Params& cp, f3
     }
 }
 
-// The PixelShuffleUpsample tail as an epilogue (conv16_kernel<.., SHUF> and its persistent form share it): register e of
+// The PixelShuffleUpsample tail as an epilogue of conv16_kernel<.., SHUF> (a function of its own since round 6, when a persistent form of
+// the kernel shared it: profiles/r6_n1_experiments.txt -- measured slower, removed): register e of
 // acc[mt][t] is channel m0 + 16 mt + 4 g + e at pixel n + t of image b.
 template <int MT, int NT>
 __device__ __forceinline__ void conv16_shuffle_epilogue(const Conv16Params& cp, f32x4 (&acc)[MT][NT], int b, int n, int m0, int g) {
@@ -479,138 +480,6 @@ __global__ __launch_bounds__(64 * WPB, 2) void conv16_kernel(const Conv16Params 
         conv16_shuffle_epilogue<MT, NT>(cp, acc, b, n, m0, g);
     } else {
         conv16_plain_epilogue<MT, NT>(cp, acc, b, n, m0, g, rgbw);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// conv16_persist_kernel (round 6): conv16_kernel<MT, NT, SHUF, false> as a PERSISTENT workgroup.
-// profiles/r3_n1_conv16_experiments.txt / r5_n1_roofline.txt: the main loops of the 30-GFLOP GEMMs run at 0.85-0.90 of the peak,
-// the launches at 0.62-0.68 -- "the epilogue's stores add their duration".  What adds it is the turnover, not the stores: a
-// workgroup's slot is free only when its last store has been acknowledged, the next workgroup is then dispatched, loads its
-// first operand block with nothing in flight, and every slot of the chip does so at about the same time (the rounds of a
-// launch of identical tiles stay in phase).  Here the grid is one round of resident workgroups and each walks its XCD's item
-// range with a stride: the NEXT tile's first operand block is requested into the operand buffer that the current tile's last
-// k-block has just freed -- before that block's MFMAs -- and the epilogue's stores are issued with those loads in flight and
-// never waited for; the wave goes straight on to the next tile's MFMAs.  No extra registers (the prefetch lives in a dead
-// buffer), same arithmetic in the same order: results are bit-identical to conv16_kernel's.
-// The operand buffer a tile starts in alternates when the number of k-blocks is odd (block i of a tile that starts in buffer
-// S sits in buffer (S + i) & 1, and the next tile's block 0 must take the buffer block nkb - 1 does not use): two tile bodies
-// with static buffer indices, ODD walks them alternately.
-// ---------------------------------------------------------------------------------------------------------------
-template <int MT, int NT, bool SHUF, bool ODD>
-__global__ __launch_bounds__(64 * WPB, 4) void conv16_persist_kernel(const Conv16Params cp) {
-    typedef typename Pix<NT>::T pv;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int li = lane & 15, g = lane >> 4;
-    const int slices = cp.plan.slices;
-    const unsigned items = (unsigned)((long)cp.batch * cp.P / (16 * WPB * NT)) * (unsigned)slices;
-    const unsigned per_xcd = (items + 7u) >> 3;
-    // workgroup j lives on XCD j & 7 (round-robin dispatch) and walks that XCD's contiguous item range [xcd per_xcd, ...) from
-    // local index j >> 3 with stride gridDim.x >> 3: at any time the resident workgroups of an XCD hold CONSECUTIVE items (row
-    // slice fastest), so the slices of one pixel tile still re-read its B rows from the same L2 -- conv16_kernel's order
-    const unsigned xcd = blockIdx.x & 7u, stride = gridDim.x >> 3;
-    const unsigned first = xcd * per_xcd;
-    const unsigned lim = first >= items ? 0u : (items - first < per_xcd ? items - first : per_xcd);
-    unsigned loc = blockIdx.x >> 3;
-    if (loc >= lim) return;
-    const int nkb = cp.plan.nkb;
-    const unsigned voffA = (unsigned)lane * 16u;
-    const unsigned rowB = (unsigned)cp.P * 4u;                    // bytes per k row
-    // (no RGB rider here: it rides on one-slice GEMMs, M <= 32 with this tile, and those are the blur-fused instances)
-
-    // one tile's addressing: scalars but for the B offset of the lane
-    struct Tile { __amdgpu_buffer_rsrc_t rsA, rsB; unsigned voffB; int b, p0, m0; };
-    auto decode = [&](unsigned item) {
-        Tile t;
-        const unsigned pt = item / (unsigned)slices;
-        const int ms = (int)(item - pt * (unsigned)slices);
-        const unsigned pixg = pt * (unsigned)(16 * WPB * NT) + (unsigned)wave * (unsigned)(16 * NT);     // batch * P < 2^31
-        t.b = (int)(pixg / (unsigned)cp.P);
-        t.p0 = (int)(pixg - (unsigned)t.b * (unsigned)cp.P);      // the wave's first pixel inside image b
-        t.m0 = ms * (16 * MT);
-        t.rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(cp.At + (long)ms * nkb * (MT * 256)), 0, nkb * (MT * 1024), 0x00020000);
-        t.rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(cp.B + (long)t.b * cp.b_batch), 0, (int)((long)cp.K * cp.P * 4), 0x00020000);
-        t.voffB = ((unsigned)g * (unsigned)cp.P + (unsigned)(t.p0 + NT * li)) * 4u;
-        return t;
-    };
-
-    f32x4 acc[MT][NT];
-    f32x4 Aq[2][MT];
-    pv Bq[2][4];
-    auto load_a = [&](const Tile& t, int kb, f32x4 (&A)[MT]) {
-        const unsigned sa = (unsigned)__builtin_amdgcn_readfirstlane(kb * (MT * 1024));      // keep the stream offset scalar
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-            A[mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(t.rsA, voffA, (int)(sa + (unsigned)mt * 1024u), 0));
-    };
-    auto load_b = [&](const Tile& t, int kb, pv (&Bv)[4]) {
-        const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)kb * 16u * rowB));
-#pragma unroll
-        for (int s = 0; s < 4; ++s) Bv[s] = Pix<NT>::load(t.rsB, t.voffB, sb + (unsigned)s * 4u * rowB);
-    };
-    auto compute = [&](const f32x4 (&A)[MT], const pv (&Bv)[4]) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[mt][t] = mfma16c(A[mt][s], Bv[s][t], acc[mt][t]);
-    };
-
-    Tile cur = decode(first + loc);
-    load_b(cur, 0, Bq[0]);
-    load_a(cur, 0, Aq[0]);
-    // One tile whose block 0 waits in operand buffer S (static).  Returns false after the workgroup's last tile.
-    auto tile = [&](auto S_) -> bool {
-        constexpr int S = decltype(S_)::value;
-        const unsigned nloc = loc + stride;
-        const bool more = nloc < lim;                             // uniform
-        Tile nxt = cur;
-        if (more) nxt = decode(first + nloc);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[mt][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        int kb = 0;
-        for (; kb + 1 < nkb; kb += 2) {
-            load_b(cur, kb + 1, Bq[S ^ 1]);
-            load_a(cur, kb + 1, Aq[S ^ 1]);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(Aq[S], Bq[S]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kb + 2 < nkb) {
-                load_b(cur, kb + 2, Bq[S]);
-                load_a(cur, kb + 2, Aq[S]);
-            } else if (more) {                                    // (even nkb) buffer S is free: the next tile starts in it
-                load_b(nxt, 0, Bq[S]);
-                load_a(nxt, 0, Aq[S]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            compute(Aq[S ^ 1], Bq[S ^ 1]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (ODD) {                                      // block nkb - 1 sits in buffer S; S ^ 1 is free: the next tile starts THERE
-            if (more) {
-                load_b(nxt, 0, Bq[S ^ 1]);
-                load_a(nxt, 0, Aq[S ^ 1]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            compute(Aq[S], Bq[S]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        const int n = cur.p0 + NT * li;                           // this lane's NT consecutive pixels
-        if constexpr (SHUF) conv16_shuffle_epilogue<MT, NT>(cp, acc, cur.b, n, cur.m0, g);
-        else conv16_plain_epilogue<MT, NT, false, false>(cp, acc, cur.b, n, cur.m0, g, nullptr);
-        cur = nxt;
-        loc = nloc;
-        return more;
-    };
-    for (;;) {
-        if (!tile(std::integral_constant<int, 0>{})) break;
-        if constexpr (ODD) {
-            if (!tile(std::integral_constant<int, 1>{})) break;
-        }
     }
 }
 
@@ -1136,36 +1005,8 @@ struct Variant { int MT, NT; bool blur; };
 const Variant kVariants[] = {{2, 4, true}, {4, 4, true}, {8, 4, false}, {9, 2, true}, {11, 2, false}, {13, 2, false}};
 constexpr int kUnshuffleMT[] = {2, 3, 4};
 
-// One round of resident workgroups of conv16_persist_kernel (workgroups per CU from the runtime's occupancy calculation x CUs,
-// a multiple of the eight XCDs); 0 = unknown: run the one-tile-per-workgroup kernel.  Computed once per instance.
-template <int MT, int NT, bool SHUF, bool ODD>
-unsigned persist_grid() {
-    static const unsigned grid = [] {
-        int per_cu = 0, dev = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv16_persist_kernel<MT, NT, SHUF, ODD>, 64 * WPB, 0) != hipSuccess ||
-            hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            return 0u;
-        return per_cu > 0 && cus > 0 ? (unsigned)(per_cu * cus) & ~7u : 0u;
-    }();
-    return grid;
-}
-template <int MT, int NT, bool SHUF>
-bool launch_persist(const Conv16Params& cp, unsigned blocks, hipStream_t st) {
-    if (GNR_C16_ABL & 256) return false;                       // A/B: every GEMM on the one-tile-per-workgroup kernel
-    if (cp.rgb_w) return false;                                // the RGB rider stays on conv16_kernel (one-slice GEMMs only)
-    const bool odd = cp.plan.nkb & 1;
-    const unsigned grid = odd ? persist_grid<MT, NT, SHUF, true>() : persist_grid<MT, NT, SHUF, false>();
-    if (grid == 0 || blocks <= grid) return false;             // a single round: nothing to overlap
-    if (odd) hipLaunchKernelGGL((conv16_persist_kernel<MT, NT, SHUF, true>), dim3(grid), dim3(64 * WPB), 0, st, cp);
-    else hipLaunchKernelGGL((conv16_persist_kernel<MT, NT, SHUF, false>), dim3(grid), dim3(64 * WPB), 0, st, cp);
-    return true;
-}
-
 template <int MT, int NT>
 void launch_variant(const Conv16Params& cp, unsigned blocks, hipStream_t st) {
-    if constexpr (MT == 2 && NT == 4) {        // the tile every multi-round GEMM of the reference's channel schedule takes
-        if (cp.shuffle ? launch_persist<MT, NT, true>(cp, blocks, st) : launch_persist<MT, NT, false>(cp, blocks, st)) return;
-    }
     if (cp.shuffle) hipLaunchKernelGGL((conv16_kernel<MT, NT, true, false>), dim3(blocks), dim3(64 * WPB), 0, st, cp);
     else hipLaunchKernelGGL((conv16_kernel<MT, NT, false, false>), dim3(blocks), dim3(64 * WPB), 0, st, cp);
 }
@@ -1300,6 +1141,11 @@ int launch_upchain(const UpChainParams& cp, hipStream_t st) {
 }
 
 int launch_conv16(const Conv16Params& cp, hipStream_t st) {
+    // the folded x.repeat adjoint exists in the plain epilogue of the NT == 4 instances only (conv16_plain_epilogue); any other
+    // route would drop it silently -- and its caller has switched `accumulate` off, so d(net) would be wrong without an error
+    if (cp.dres_from && (cp.plan.NT != 4 || cp.shuffle || cp.sign_in))
+        return fail("conv16: dres_from needs a plain NT == 4 instance (plan %d x %d, shuffle %d, un-shuffle %d)", cp.plan.MT, cp.plan.NT,
+                    cp.shuffle, cp.sign_in != nullptr);
     if (cp.plan.NT == 8) {
         const long witems = (long)cp.batch * cp.W * (cp.W / 32) / WPB * cp.plan.slices;
         const unsigned wblocks = (unsigned)(8 * ((witems + 7) / 8));

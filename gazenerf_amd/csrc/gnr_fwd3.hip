@@ -14,6 +14,7 @@
 //     workgroup into an LDS ring by LDS-DMA and read from there by all four waves (one barrier per 4 rows);
 //   * the density head is still an fp32 VALU dot (folded into the conversion of h7); ray geometry, encoding (fp32
 //     sincosf, then split), compositing and combine are shared with the fp32 path.
+namespace gnr { constexpr bool kChain3DumpBranch = false; }      // see gnr_chain3.h
 #include "gnr_chain3.h"
 
 namespace gnr {

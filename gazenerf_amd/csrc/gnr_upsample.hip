@@ -891,6 +891,23 @@ static size_t up_colsum_floats(const UpDims& d, int batch, int level) {
     return (((size_t)(d.ch[level] + 1) * wgs * 3) + 63) & ~(size_t)63;
 }
 
+// The arena of the call's queued weight-gradient GEMMs: wgrad_arena_floats()'s bound raised to the largest single need of the three
+// products per block (dW feat_layers at the block's output size, dW layer_2, dW layer_1) as launch_wgrad_img's LDS-staged route
+// plans them -- the route a product takes when the register-fed kernel (gnr_wgrad16.hip, which fits its split count to the arena)
+// declines it.  Sized from the launchers' own plan; tests/test_host_logic.py sweeps the batch on the CPU.
+static size_t up_wgrad_arena_floats(const GnrUpsampleProblem* p, const UpDims& d) {
+    WgradShape g[3 * UP_MAX];
+    int n = 0;
+    for (int i = 0; i < d.n_blocks; ++i) {
+        const int C = d.ch[i], Cn = d.ch[i + 1];
+        const long P = (long)d.side[i] * d.side[i], P4 = 4 * P;
+        g[n++] = WgradShape{Cn, Cn, C, C, P4 / CHUNK, P4, 0, 0, 0};
+        g[n++] = WgradShape{4 * C, 4 * C, 2 * C, 2 * C, P / CHUNK, P, 0, 0, 0};
+        g[n++] = WgradShape{2 * C, 2 * C, C, C, P / CHUNK, P, 0, 0, 0};
+    }
+    return wgrad_arena_floats_for(g, n, p->batch, 4 * d.ch[0], 2 * d.ch[0]);
+}
+
 static size_t up_carve_bwd(const GnrUpsampleProblem* p, const UpDims& d, char* base, UpScratch* s) {
     size_t off = 0;
     auto take = [&](size_t bytes) { char* q = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return q; };
@@ -913,7 +930,7 @@ static size_t up_carve_bwd(const GnrUpsampleProblem* p, const UpDims& d, char* b
         cs_floats += up_colsum_floats(d, p->batch, i);
     }
     z.colsum = (float*)take(cs_floats * 4);
-    z.wg = (float*)take(wgrad_arena_floats(p->batch, 4 * d.ch[0], 2 * d.ch[0]) * 4);      // layer_2 of block 0 is the largest product
+    z.wg = (float*)take(up_wgrad_arena_floats(p, d) * 4);      // layer_2 of block 0 is the largest product
     if (s) *s = z;
     return off;
 }
@@ -1095,7 +1112,7 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
     };
     // the split-K reductions of the nine weight-gradient GEMMs are queued and run as ONE launch at the end of the call
     WgradDefer wd;
-    wgrad_defer_init(&wd, t.wg, wgrad_arena_floats(p->batch, 4 * d.ch[0], 2 * d.ch[0]));
+    wgrad_defer_init(&wd, t.wg, up_wgrad_arena_floats(p, d));
 
     // Blur and the 1x1 convolution act on different axes (pixels / channels) and commute: with g = blur^T(dhid)
     //   dWf = g u^T,  dbf = sum g (= sum dhid: blur's rows sum to 1),  du = Wf^T g,

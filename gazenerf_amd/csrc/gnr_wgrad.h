@@ -69,6 +69,17 @@ size_t wgrad_scratch_floats();
 // images: four single-GEMM scratches, or what that product's partial tiles + rider shares need when there are more (image, tile)
 // pairs than one round of workgroups -- the partial tiles of a GEMM grow with the batch then.
 size_t wgrad_arena_floats(int batch, int max_m, int max_k);
+// One weight-gradient GEMM as its launcher will see it: what launch_wgrad / launch_wgrad_img plan from.
+struct WgradShape {
+    int lda, n_valid, ldb, k_valid;
+    long chunks_per_image, pixels_per_image;      // pixels_per_image == 0: chunk-channel-major dumps (the MLP); > 0: channels-first images
+    int with_vec, bf16x3, small_tiles;
+};
+// Scratch floats (partial tiles + rider shares) the GEMM's PLAN needs over `batch` images -- the same host-only plan the launch runs.
+size_t wgrad_need_floats(const WgradShape& g, int batch);
+// The arena a caller must provide for its list of GEMMs: wgrad_arena_floats()'s bound, raised to the largest single need of the list
+// (so a GEMM can always take its scratch from an empty arena: sized from the plan, not from a hand bound).
+size_t wgrad_arena_floats_for(const WgradShape* gemms, int n, int batch, int max_m, int max_k);
 
 #ifdef __HIPCC__
 // wgrad16_reduce_kernel's body: dW[n][k] = sum_s partial[s][n][k] (s ascending: fixed order), bias[n] = the last padded

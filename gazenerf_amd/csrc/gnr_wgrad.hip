@@ -35,6 +35,7 @@
 #include <cstdlib>
 #include <type_traits>
 
+namespace gnr { constexpr bool kChain3DumpBranch = false; }      // see gnr_chain3.h
 #include "gnr_chain3.h"
 #include "gnr_wgrad.h"
 
@@ -1170,6 +1171,112 @@ static int choose_tile(int n_valid, int k_valid, bool vec) {
     return best;
 }
 
+// Host-only plan of one weight-gradient GEMM (split from the launch so that the scratch a GEMM really needs --
+// partial tiles + rider shares -- can be computed where workspaces are SIZED, gnr_workspace_bytes / gnr_upsample_workspace_bytes,
+// and checked there against wgrad_arena_floats() for every batch: tests/test_host_logic.py sweeps 1..512 images on the CPU).
+struct WgradPlan {
+    int pipe_xk, xa, xb, cfg, TN, TK, tiles_n, tiles_k, linear_map, splits, cs_q, vs_q;
+    bool half_rows, img2w, two_wave, unsupported;
+    long spi, chunks_per_split;
+    unsigned blocks;
+    size_t need, cs_need, vec_need;
+};
+static WgradPlan wgrad_plan(int lda, int n_valid, int ldb, int k_valid, int batch, long chunks_per_image, long pixels_per_image,
+                            bool with_vec, bool bf16x3, bool small_tiles) {
+    WgradPlan pl{};
+    // chunk-channel-major fp32 operands of the MLP's shapes go to the pipelined one-workgroup-per-CU kernel
+    // (192-row tiles; K = 64 for the encoding columns); everything else to the two-workgroups-per-CU kernel
+    int pipe_xk = 0;
+    if (!bf16x3 && pixels_per_image == 0 && n_valid <= 384 && (k_valid == 64 || k_valid == 192 || k_valid == 384) &&
+        (!with_vec || (n_valid > 192 && k_valid == 384)))        // the density rider needs the 2 x 2 tile grid
+        pipe_xk = k_valid == 64 ? 1 : 3;
+    // small_tiles: a product far below the 192-row tile (the 66 rows RGB_layer_2 has beyond its first 192) takes a 96 x 192 tile
+    // of the two-wave kernel (round 5; until then a 96 x 96 tile of wgrad_kernel) instead of a 192 x 192 tile that would be
+    // two-thirds padding; other shapes keep wgrad_kernel's per-shape tiles
+    const bool half_rows = small_tiles && !bf16x3 && !with_vec && pipe_xk == 3 && n_valid <= 96 && k_valid == 192;
+    if (small_tiles && !bf16x3 && !with_vec && !half_rows) pipe_xk = 0;
+    // bf16x3: pre-split QHL dumps of the chain kernels -> the transposing-read kernel (192-row tiles)
+    if (bf16x3 && pixels_per_image == 0 && n_valid <= 384 && lda % 32 == 0 && ldb % 32 == 0 &&
+        (k_valid == 64 || k_valid == 192 || k_valid == 384) && (!with_vec || (n_valid > 192 && k_valid == 384)))
+        pipe_xk = k_valid == 64 ? 1 : 3;
+    if (bf16x3 && !pipe_xk) { pl.unsupported = true; return pl; }      // (the launch reports it)
+    // channels-first images (the upsampler's 1x1 convolutions): the same pipelined kernel through its image addressing
+    // when the 192 x 192 tiles are reasonably full (measured against wgrad_kernel's per-shape tiles: DESIGN.md 3.5)
+    bool img2w = false;
+    if (!bf16x3 && pixels_per_image > 0 && !with_vec && pixels_per_image % CHUNK == 0) {
+        const int tn = (n_valid + 191) / 192, tk = (k_valid + 191) / 192;
+        const double fill = (double)n_valid * k_valid / ((double)tn * tk * 192.0 * 192.0);
+        img2w = fill >= 0.45 && tk <= 3;
+    }
+    if (img2w) pipe_xk = 3;
+    // the two-wave kernel's tile: (16-row tiles per wave, 16-column tiles per wave) -> (32 xa) x (64 xb) per workgroup
+    int xa = half_rows ? 3 : 6, xb = pipe_xk;
+    // Round 5: three of the upsampler's narrow products on instances of the two-wave kernel sized to them (ring of four: their
+    // chunk periods are 0.9-1.7 us) instead of wgrad_kernel's 32x32x2 tiles, two workgroups per CU
+    if (!(PABL & 8) && !img2w && !bf16x3 && pixels_per_image > 0 && !with_vec && pixels_per_image % CHUNK == 0) {
+        if (n_valid % 128 == 0 && k_valid == 128) { xa = 4; xb = 2; }                                  // 256 x 128 (layer_2 at 64 channels)
+        else if (n_valid == 128 && k_valid == 64) { xa = 4; xb = 1; }                                  // layer_1 at 64 channels
+        else if (n_valid > 32 && n_valid <= 64 && k_valid > 64 && k_valid <= 192) { xa = 2; xb = 3; }  // 64 x 129 (feat_layers)
+        if (xb) { img2w = true; pipe_xk = 3; }
+    }
+    const bool two_wave = !bf16x3 && pipe_xk != 0;        // (K = 64 never comes with the density rider: see above)
+    const int cfg = pipe_xk ? 0 : choose_tile(n_valid, k_valid, with_vec);
+    const int TN = two_wave ? 32 * xa : (pipe_xk ? 192 : kTileCfgs[cfg].tn), TK = two_wave ? 64 * xb : (pipe_xk ? 64 * pipe_xk : kTileCfgs[cfg].tk);
+    pl.tiles_n = (n_valid + TN - 1) / TN;
+    pl.tiles_k = (k_valid + TK - 1) / TK;
+    const int tiles = pl.tiles_n * pl.tiles_k;
+    // Split count: the kernel places split s on XCD s % 8 (32 CUs x 2 resident workgroups = 64 slots
+    // per XCD; the pipelined kernel runs one workgroup per CU: 32 slots).  Every XCD must get the SAME number of
+    // workgroups and fill whole rounds, otherwise the launch waits for one XCD's straggler round (113 splits instead
+    // of 112 cost 40 %): splits = 8 * floor(slots / tiles), made divisible by the batch: ONE round of workgroups.
+    // (Two rounds ran the GEMM no faster and doubled the partial tiles the reduce kernel has to sum.)
+    // (the 128-thread 32 x 64 tile: four workgroups per CU)
+    long splits_total = 8L * ((pipe_xk ? 32 : (cfg == 6 ? 128 : 64)) / tiles);
+    if (splits_total < 8) splits_total = 8;
+    long spi = splits_total / batch;
+    if (img2w) {
+        // (split, tile) pairs are spread over the XCDs as one contiguous range each (linear_map): any count that fills
+        // the 256 one-workgroup CUs once
+        pl.linear_map = 1;
+        spi = 256 / ((long)batch * tiles);
+    }
+    if (spi < 1) spi = 1;
+    if (spi > chunks_per_image) spi = chunks_per_image;
+    while ((long)batch * spi * tiles > WG_MAX_BLOCKS && spi > 1) --spi;
+    pl.chunks_per_split = (chunks_per_image + spi - 1) / spi;
+    const int splits = batch * (int)spi;
+    const unsigned blocks = img2w ? (unsigned)(8 * (((long)splits * tiles + 7) / 8)) : (unsigned)(8 * ((splits + 7) / 8) * tiles);
+    // rider shares per split: the two-wave kernel 4 tiles_k column-sum shares, wgrad3_tr_kernel 2 tiles_k / 2 tiles_n, wgrad_kernel 1
+    const int cs_q = two_wave ? 4 * pl.tiles_k : (pipe_xk ? 2 * pl.tiles_k : 1);
+    const int vs_q = two_wave ? 1 : (pipe_xk ? 2 * pl.tiles_n : 1);
+    // scratch of this GEMM: [partial tiles][column-sum shares][vector shares], each at its exact size (round 5: the shares had a
+    // fixed 1024 x 192 floats each, sized for ONE round of workgroups -- more images than workgroup slots, e.g. 40 stacked maps
+    // through the upsampler's 18-tile product or > 64 images through the MLP, wrote past it into the next GEMM's partial tiles:
+    // wrong bias gradients, tests/test_upsample.py::test_hip_vs_oracle_live[258-16-32-32-40]).  Queued (gnr_wgrad.h) the GEMM takes
+    // what it needs from the caller's arena; alone it owns `scratch` (wgrad_scratch_floats()) and must fit it.
+    const size_t need = ((size_t)blocks * TN * TK + 63) & ~(size_t)63;
+    const size_t cs_need = ((size_t)splits * cs_q * pl.tiles_n * TN + 63) & ~(size_t)63;
+    const size_t vec_need = with_vec ? (((size_t)splits * vs_q * pl.tiles_k * TK + 63) & ~(size_t)63) : 0;
+    pl.pipe_xk = pipe_xk; pl.half_rows = half_rows; pl.img2w = img2w; pl.xa = xa; pl.xb = xb; pl.two_wave = two_wave; pl.cfg = cfg;
+    pl.TN = TN; pl.TK = TK; pl.spi = spi; pl.splits = splits; pl.blocks = blocks; pl.cs_q = cs_q; pl.vs_q = vs_q;
+    pl.need = need; pl.cs_need = cs_need; pl.vec_need = vec_need;
+    return pl;
+}
+
+size_t wgrad_need_floats(const WgradShape& g, int batch) {
+    const WgradPlan pl = wgrad_plan(g.lda, g.n_valid, g.ldb, g.k_valid, batch, g.chunks_per_image, g.pixels_per_image, g.with_vec != 0,
+                                    g.bf16x3 != 0, g.small_tiles != 0);
+    return pl.unsupported ? 0 : pl.need + pl.cs_need + pl.vec_need;
+}
+size_t wgrad_arena_floats_for(const WgradShape* gemms, int n, int batch, int max_m, int max_k) {
+    size_t a = wgrad_arena_floats(batch, max_m, max_k);
+    for (int i = 0; i < n; ++i) {
+        const size_t need = wgrad_need_floats(gemms[i], batch);
+        if (need > a) a = need;
+    }
+    return a;
+}
+
 // dW[n_valid x k_valid] (+ col_off, optional encoding-slot map) = A^T B over all chunks.
 // Optional: colsum_out[b][n] = per-image column sums of A; vec_out[k] = vec^T B.
 // n_crop x k_crop (<= n_valid x k_valid): the part of the product that is written out -- a network narrower than the
@@ -1194,86 +1301,22 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
     wp.b_s16 = (wp.a_s16 && enc_map == 0) ? 1 : 0;
     wp.clk = clock_probe_slot(GNR_STAGE_WGRAD);
     const bool with_vec = vec_out != nullptr;
-    // chunk-channel-major fp32 operands of the MLP's shapes go to the pipelined one-workgroup-per-CU kernel
-    // (192-row tiles; K = 64 for the encoding columns); everything else to the two-workgroups-per-CU kernel
-    int pipe_xk = 0;
-    if (!bf16x3 && pixels_per_image == 0 && n_valid <= 384 && (k_valid == 64 || k_valid == 192 || k_valid == 384) &&
-        (!with_vec || (n_valid > 192 && k_valid == 384)))        // the density rider needs the 2 x 2 tile grid
-        pipe_xk = k_valid == 64 ? 1 : 3;
-    // small_tiles: a product far below the 192-row tile (the 66 rows RGB_layer_2 has beyond its first 192) takes a 96 x 192 tile
-    // of the two-wave kernel (round 5; until then a 96 x 96 tile of wgrad_kernel) instead of a 192 x 192 tile that would be
-    // two-thirds padding; other shapes keep wgrad_kernel's per-shape tiles
-    const bool half_rows = small_tiles && !bf16x3 && !with_vec && pipe_xk == 3 && n_valid <= 96 && k_valid == 192;
-    if (small_tiles && !bf16x3 && !with_vec && !half_rows) pipe_xk = 0;
-    // bf16x3: pre-split QHL dumps of the chain kernels -> the transposing-read kernel (192-row tiles)
-    if (bf16x3 && pixels_per_image == 0 && n_valid <= 384 && lda % 32 == 0 && ldb % 32 == 0 &&
-        (k_valid == 64 || k_valid == 192 || k_valid == 384) && (!with_vec || (n_valid > 192 && k_valid == 384)))
-        pipe_xk = k_valid == 64 ? 1 : 3;
-    if (bf16x3 && !pipe_xk) {
+    const WgradPlan pl = wgrad_plan(lda, n_valid, ldb, k_valid, batch, chunks_per_image, pixels_per_image, with_vec, bf16x3, small_tiles);
+    if (pl.unsupported) {
         // QHL dumps have no other reader; gnr_api.hip admits only the reference's layer widths, so this is a bug
         fprintf(stderr, "gnr: bf16x3 weight gradient asked for an unsupported shape (%d x %d, ld %d / %d)\n", n_valid, k_valid, lda, ldb);
         abort();
     }
-    // channels-first images (the upsampler's 1x1 convolutions): the same pipelined kernel through its image addressing
-    // when the 192 x 192 tiles are reasonably full (measured against wgrad_kernel's per-shape tiles: DESIGN.md 3.5)
-    bool img2w = false;
-    if (!bf16x3 && pixels_per_image > 0 && !with_vec && pixels_per_image % CHUNK == 0) {
-        const int tn = (n_valid + 191) / 192, tk = (k_valid + 191) / 192;
-        const double fill = (double)n_valid * k_valid / ((double)tn * tk * 192.0 * 192.0);
-        img2w = fill >= 0.45 && tk <= 3;
-    }
-    if (img2w) pipe_xk = 3;
-    // the two-wave kernel's tile: (16-row tiles per wave, 16-column tiles per wave) -> (32 xa) x (64 xb) per workgroup
-    int xa = half_rows ? 3 : 6, xb = pipe_xk;
-    // Round 5: three of the upsampler's narrow products on instances of the two-wave kernel sized to them (ring of four: their
-    // chunk periods are 0.9-1.7 us) instead of wgrad_kernel's 32x32x2 tiles, two workgroups per CU
-    if (!(PABL & 8) && !img2w && !bf16x3 && pixels_per_image > 0 && !with_vec && pixels_per_image % CHUNK == 0) {
-        if (n_valid % 128 == 0 && k_valid == 128) { xa = 4; xb = 2; }                                  // 256 x 128 (layer_2 at 64 channels)
-        else if (n_valid == 128 && k_valid == 64) { xa = 4; xb = 1; }                                  // layer_1 at 64 channels
-        else if (n_valid > 32 && n_valid <= 64 && k_valid > 64 && k_valid <= 192) { xa = 2; xb = 3; }  // 64 x 129 (feat_layers)
-        if (xb) { img2w = true; pipe_xk = 3; }
-    }
-    const bool two_wave = !bf16x3 && pipe_xk != 0;        // (K = 64 never comes with the density rider: see above)
-    const int cfg = pipe_xk ? 0 : choose_tile(n_valid, k_valid, with_vec);
-    const int TN = two_wave ? 32 * xa : (pipe_xk ? 192 : kTileCfgs[cfg].tn), TK = two_wave ? 64 * xb : (pipe_xk ? 64 * pipe_xk : kTileCfgs[cfg].tk);
-    wp.tiles_n = (n_valid + TN - 1) / TN;
-    wp.tiles_k = (k_valid + TK - 1) / TK;
-    const int tiles = wp.tiles_n * wp.tiles_k;
-    // Split count: the kernel places split s on XCD s % 8 (32 CUs x 2 resident workgroups = 64 slots
-    // per XCD; the pipelined kernel runs one workgroup per CU: 32 slots).  Every XCD must get the SAME number of
-    // workgroups and fill whole rounds, otherwise the launch waits for one XCD's straggler round (113 splits instead
-    // of 112 cost 40 %): splits = 8 * floor(slots / tiles), made divisible by the batch: ONE round of workgroups.
-    // (Two rounds ran the GEMM no faster and doubled the partial tiles the reduce kernel has to sum.)
-    // (the 128-thread 32 x 64 tile: four workgroups per CU)
-    long splits_total = 8L * ((pipe_xk ? 32 : (cfg == 6 ? 128 : 64)) / tiles);
-    if (splits_total < 8) splits_total = 8;
-    long spi = splits_total / batch;
-    if (img2w) {
-        // (split, tile) pairs are spread over the XCDs as one contiguous range each (linear_map): any count that fills
-        // the 256 one-workgroup CUs once
-        wp.linear_map = 1;
-        spi = 256 / ((long)batch * tiles);
-    }
-    if (spi < 1) spi = 1;
-    if (spi > chunks_per_image) spi = chunks_per_image;
-    while ((long)batch * spi * tiles > WG_MAX_BLOCKS && spi > 1) --spi;
+    const int pipe_xk = pl.pipe_xk, xa = pl.xa, xb = pl.xb, cfg = pl.cfg, TN = pl.TN, TK = pl.TK, splits = pl.splits, cs_q = pl.cs_q, vs_q = pl.vs_q;
+    const bool half_rows = pl.half_rows, two_wave = pl.two_wave;
+    const long spi = pl.spi;
+    const unsigned blocks = pl.blocks;
+    const size_t need = pl.need, cs_need = pl.cs_need, vec_need = pl.vec_need;
+    wp.tiles_n = pl.tiles_n; wp.tiles_k = pl.tiles_k; wp.linear_map = pl.linear_map;
     wp.batch = batch; wp.spi = (int)spi;
     wp.chunks_per_image = chunks_per_image;
-    wp.chunks_per_split = (chunks_per_image + spi - 1) / spi;
-    const int splits = batch * (int)spi;
-    const unsigned blocks = img2w ? (unsigned)(8 * (((long)splits * tiles + 7) / 8)) : (unsigned)(8 * ((splits + 7) / 8) * tiles);
-    // rider shares per split: the two-wave kernel 4 tiles_k column-sum shares, wgrad3_tr_kernel 2 tiles_k / 2 tiles_n, wgrad_kernel 1
-    const int cs_q = two_wave ? 4 * wp.tiles_k : (pipe_xk ? 2 * wp.tiles_k : 1);
-    const int vs_q = two_wave ? 1 : (pipe_xk ? 2 * wp.tiles_n : 1);
-    // scratch of this GEMM: [partial tiles][column-sum shares][vector shares], each at its exact size (round 5: the shares had a
-    // fixed 1024 x 192 floats each, sized for ONE round of workgroups -- more images than workgroup slots, e.g. 40 stacked maps
-    // through the upsampler's 18-tile product or > 64 images through the MLP, wrote past it into the next GEMM's partial tiles:
-    // wrong bias gradients, tests/test_upsample.py::test_hip_vs_oracle_live[258-16-32-32-40]).  Queued (gnr_wgrad.h) the GEMM takes
-    // what it needs from the caller's arena; alone it owns `scratch` (wgrad_scratch_floats()) and must fit it.
+    wp.chunks_per_split = pl.chunks_per_split;
     WgradDefer* const owner = defer;
-    const size_t need = ((size_t)blocks * TN * TK + 63) & ~(size_t)63;
-    const size_t cs_need = ((size_t)splits * cs_q * wp.tiles_n * TN + 63) & ~(size_t)63;
-    const size_t vec_need = with_vec ? (((size_t)splits * vs_q * wp.tiles_k * TK + 63) & ~(size_t)63) : 0;
     if (defer) {
         float* q = wgrad_defer_take(defer, need + cs_need + vec_need, stream);
         if (q) scratch = q;

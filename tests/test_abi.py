@@ -81,19 +81,23 @@ def test_timing_switches_do_not_compile_without_the_experimental_macro(tmp_path)
 
 def test_every_compile_time_switch_is_in_the_experimental_guard():
     """a `#ifdef GNR_*` switch missing from gnr_internal.h's guard list would let a hand build with it report
-    experimental=0.  The list is checked against a grep of the sources, so a new switch cannot be forgotten."""
+    experimental=0.  The list is checked against a grep of the sources, so a new switch cannot be forgotten.  ADVICE round 5:
+    the grep takes EVERY identifier of every conditional line, whatever its prefix (CHAIN3_DUMP_BRANCH had slipped out of
+    the GNR_ namespace and with it out of this test; it is a C++ constant now), minus the compiler's own macros."""
     import re
     csrc = os.path.join(ROOT, "gazenerf_amd", "csrc")
     guard = open(os.path.join(csrc, "gnr_internal.h")).read()
     guard = guard[guard.index("#if !defined(GNR_EXPERIMENTAL_BUILD)"):guard.index("#error")]
     listed = set(re.findall(r"defined\((GNR_\w+)\)", guard)) - {"GNR_EXPERIMENTAL_BUILD"}
-    not_switches = {"GNR_BUILD_INFO", "GNR_SOURCE_HASH", "GNR_EXPERIMENTAL_BUILD", "GNR_H_"}
+    # not switches of a build: the build-info strings, the include guards, what the compiler itself defines, the operators
+    not_switches = {"GNR_BUILD_INFO", "GNR_SOURCE_HASH", "GNR_EXPERIMENTAL_BUILD", "GNR_H_", "__HIPCC__", "__cplusplus", "defined"}
     used = set()
     for name in os.listdir(csrc):
         if name.endswith((".hip", ".h", ".cpp")):
             for line in open(os.path.join(csrc, name)):
-                if re.match(r"\s*#\s*(if|ifdef|ifndef|elif)\b", line):
-                    used |= set(re.findall(r"\bGNR_\w+", line))
+                m = re.match(r"\s*#\s*(if|ifdef|ifndef|elif)\b(.*)", line)
+                if m:
+                    used |= set(re.findall(r"\b[A-Za-z_]\w*", m.group(2).split("//")[0].split("/*")[0]))
     used -= not_switches
     assert used == listed, (sorted(used - listed), sorted(listed - used))
     assert len(listed) <= 12

@@ -207,6 +207,8 @@ def test_host_enqueue_time_is_reported_at_one_rank():
     hb = d["roofline_hbm"]                             # priced on the algorithm's 258 channels, the layout's 288 beside it
     assert abs(hb["frac_incl_padding"] / hb["frac"] - hb["bytes_per_launch_incl_padding"] / hb["bytes_per_launch"]) < 1e-9
     assert hb["bytes_per_launch"] == 4096 * 64 * (258 * 4 + 16) + 4096 * (258 * 4 + 12)
+    assert hb["bytes_per_launch_read"] == 4096 * 64 * (272 * 4 + 16) + 4096 * (272 * 4 + 12)          # what comp_bwd_kernel reads
+    assert hb["channels"] == {"algorithmic": 258, "read_by_kernel": 272, "saved_layout": 288}
 
 
 # ----------------------------------------------------------------------------------------------- RCCL (round 4)

@@ -174,3 +174,35 @@ def test_tiled_training_entry_accumulates_like_one_backward(monkeypatch):
     for a, t in zip(g1, leaves):
         assert torch.allclose(2 * a, t.grad, rtol=1e-4, atol=1e-5)
     assert face["frozen"].grad is None
+
+
+def test_backward_scratch_is_sized_for_every_batch(lib_built):
+    """the arena of the queued weight-gradient GEMMs was a hand bound (batch x padded area x 3/2); it is now
+    that bound RAISED to the largest need of the call's own GEMM list, computed by the launchers' host-only plan
+    (wgrad_plan -> wgrad_arena_floats_for, gnr_wgrad.hip) at sizing time.  No GPU needed: the size queries run the plan for
+    every batch from 1 to 512 (both callers: 13 MLP GEMMs per weight set in either precision, three products per upsampler
+    block) -- they must succeed, grow monotonically, and stay linear in the batch once the batch dominates (a plan whose
+    split count ran away would show as a jump)."""
+    import ctypes as C
+
+    from gazenerf_amd import _lib
+    lib = _lib.load()
+    q = _lib.GnrProblem()
+    q.n_rays, q.n_samples, q.hidden, q.feat_nc = 16, 32, 384, 258
+    q.xy = q.R = q.T = q.Kinv = 1                      # sizes only: checked for NULL, never dereferenced
+    u = _lib.GnrUpsampleProblem()
+    u.feat_nc, u.featmap_size, u.n_blocks, u.min_feat, u.x = 258, 16, 2, 32, 1
+    for what in ("mlp", "upsampler"):
+        sizes = []
+        for b in range(1, 513):
+            if what == "mlp":
+                q.batch = b
+                n = lib.gnr_workspace_bytes(C.byref(q), 2, _lib.WS_BWD)
+            else:
+                u.batch = b
+                n = lib.gnr_upsample_workspace_bytes(C.byref(u), _lib.UP_WS_BWD)
+            assert n > 0, (what, b, lib.gnr_last_error())
+            sizes.append(n)
+        assert all(b2 >= b1 for b1, b2 in zip(sizes, sizes[1:])), what
+        steps = [b2 - b1 for b1, b2 in zip(sizes[256:], sizes[257:])]        # batch 257..512: every image adds the same share
+        assert max(steps) <= 1.5 * min(steps) + 4096, (what, min(steps), max(steps))

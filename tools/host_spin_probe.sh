@@ -9,9 +9,11 @@ NAME=$1; shift
 O=$R/gpurun_out/$NAME
 mkdir -p $O
 cd $R
-python bench.py --steps 12 --warmup 2 --no-alt --no-cpu-baseline --no-one-call "$@" > $O/bench.json 2> $O/bench.err &
+python bench.py --steps 30 --warmup 2 --no-alt --no-cpu-baseline --no-one-call "$@" > $O/bench.json 2> $O/bench.err &
 PID=$!
-sleep ${PROBE_DELAY:-45}
+# the pre-flight line marks the end of the imports; the workload is built and the two warm-up steps run in the next seconds
+for i in $(seq 1 300); do grep -q hipMemGetInfo $O/bench.err 2>/dev/null && break; sleep 1; done
+sleep ${PROBE_DELAY:-10}
 threads() { for t in /proc/$PID/task/*; do
     read -r -a f < $t/stat 2>/dev/null || continue
     echo "$(basename $t) $(cat $t/comm 2>/dev/null | tr ' ' '_') ${f[13]} ${f[14]}"; done; }
