@@ -85,6 +85,10 @@ def parse():
     ap.add_argument("--gan-loss", action="store_true", help="cfg4: + use_patch_gan_loss (discriminator update, then the generator term)")
     ap.add_argument("--no-one-call", action="store_true", help="skip the extra timing of the one-call (in-op tiled) training path")
     ap.add_argument("--pg-timeout", type=float, default=180.0, help="seconds before a stuck rendezvous / collective aborts")
+    ap.add_argument("--sync", choices=("auto", "spin", "yield", "blocking"), default=os.environ.get("GNR_BENCH_SYNC", "auto"),
+                    help="hipSetDeviceFlags(hipDeviceSchedule*) before the device context exists: how a host thread waits when the HIP "
+                         "runtime makes it wait (a full queue, a synchronize).  auto = the runtime's default.  `blocking` parks the thread "
+                         "on an interrupt instead of polling: what N ranks sharing a host's cores want (host.cpu_share in the line)")
     ap.add_argument("--force-dist", action="store_true", default=os.environ.get("GNR_BENCH_FORCE_DIST", "") == "1",
                     help="--gpus 1: form a ONE-rank RCCL process group anyway and run the gradient exchange through it "
                          "(loads librccl, creates a communicator, exercises the stream hand-off on a single GPU)")
@@ -338,6 +342,15 @@ def main():
                          % (rank, dev_index, n_dev, args.gpus))
     if args.scaling == "strong" and args.config != "cfg2b":
         raise SystemExit("bench.py: --scaling strong shards the rays of ONE cfg2b image; cfg4 shards images (weak)")
+    sync_rc = None
+    if args.sync != "auto":
+        # before the primary context of the device exists (torch creates it at the first allocation / set_device)
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        flag = {"spin": 0x1, "yield": 0x2, "blocking": 0x4}[args.sync]       # hipDeviceScheduleSpin / Yield / BlockingSync
+        sync_rc = [int(hip.hipSetDevice(dev_index)), int(hip.hipSetDeviceFlags(flag))]
+        if sync_rc != [0, 0]:
+            sys.stderr.write("bench.py: rank %d: hipSetDevice / hipSetDeviceFlags(%s) returned %s: the runtime's default stays\n" % (rank, args.sync, sync_rc))
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     # pre-flight, every rank, stderr: what the device has free BEFORE this rank allocates (hipMemGetInfo) -- several ranks on
@@ -381,10 +394,17 @@ def main():
                 raise RuntimeError("pre-flight all-reduce returned %s, expected %d" % (probe.item(), world))
         ctx = dict(args=args, rank=rank, world=world, dev=dev, dist=dist, backend=backend, torch=torch, host={})
         res = run_cfg4(ctx) if args.config == "cfg4" else run_cfg2b(ctx)
+        # every rank, stderr: what this rank held at its peak (several ranks on one device -- the test-only rehearsals -- add up)
+        free_e, _ = torch.cuda.mem_get_info(dev)
+        sys.stderr.write("bench.py: rank %d of %d: peak %.1f GiB allocated / %.1f GiB reserved by this rank; %.1f GiB free on GPU %d now\n"
+                         % (rank, world, torch.cuda.max_memory_allocated(dev) / 2**30, torch.cuda.max_memory_reserved(dev) / 2**30,
+                            free_e / 2**30, dev_index))
+        sys.stderr.flush()
         if rank == 0:
             from gazenerf_amd import _lib
             res["build"] = _lib.build_info()          # gnr_build_info(): source hash (checked against the tree at load), flags
-            res["host"] = dict(ctx["host"], cpu_affinity=affinity, cores_available="%d (%s)" % available_cores())
+            res["host"] = dict(ctx["host"], cpu_affinity=affinity, cores_available="%d (%s)" % available_cores(),
+                               sync={"mode": args.sync, "hipSetDevice_hipSetDeviceFlags_rc": sync_rc})
             if dist:
                 res["distributed"] = {"backend": backend, "world_size_formed": dist.get_world_size(),
                                       "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None,

@@ -19,7 +19,8 @@
 #   ws8diag:<n>      n repeats of the FULL-SIZE 8-rank cfg4 rehearsal (the run that went red on the driver's box in round 5), then n at
 #                    the test-only --side 16, every rank's stderr kept; a failed repeat's cause lines -> ws8diag.txt
 #   guard            tests/guard/run_guarded.py, long forms (every scenario, both bindings, with and without --poison) -> guard.txt
-#   hostspin[:args]  tools/host_spin_probe.sh: per-thread CPU time + native backtraces of the default bench while its steps run -> hostspin/
+#   hostspin[:args]  tools/host_spin_probe.sh: per-thread CPU time / state / wait channel of the default bench while its steps run -> hostspin/
+#   syncab           the default bench under --sync auto | blocking | yield, 6 steps each: ms_per_step and host.cpu_share   -> syncab.txt
 #   noise            tests/diagnostics/grad_noise_draws.py                        -> grad_noise_draws.txt
 #   dropterm         the bf16x3 gate on a build with one cross term dropped       -> grad_gate_dropped_term.txt
 #   x3outlier        anatomy of the gate's outlier draw (bf16x3 vs fp32 kernels)  -> x3_outlier_draw13.txt
@@ -48,7 +49,7 @@ P
 for STEP in "$@"; do
   echo "=== $STEP ($(date +%H:%M:%S))"
   case $STEP in
-    tests) timeout 2400 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log; tail -5 $O/pytest.log;;
+    tests) timeout 2400 python -m pytest tests -m gpu -x -q --durations=25 > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log; tail -5 $O/pytest.log;;
     tests:*) timeout 1500 python -m pytest tests -m gpu -x -q -k "${STEP#tests:}" > $O/pytest_k.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_k.log; tail -15 $O/pytest_k.log;;
     smoke) python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2;;
     n1)
@@ -87,6 +88,7 @@ for STEP in "$@"; do
           GNR_BENCH_BACKEND=gloo GNR_BENCH_DEVICE=0 timeout 900 python bench.py --gpus 8 --config cfg4 --side $SIDE --steps 2 --warmup 1 > $O/ws8diag_${SIDE}_$i.json 2> $O/ws8diag_${SIDE}_$i.err
           RC=$?
           echo "side $SIDE repeat $i rc=$RC $(python -c "import json,sys; d=json.loads(open('$O/ws8diag_${SIDE}_$i.json').read().strip().splitlines()[-1]); print('ms/step %.2f' % d['ms_per_step'], 'allreduce ms %.2f' % d['allreduce']['ms'])" 2>/dev/null)"
+          grep "peak .* GiB allocated" $O/ws8diag_${SIDE}_$i.err | sed 's/^bench.py: /    /' | head -8       # per-rank memory: 8 ranks share ONE device here
           if [ $RC -ne 0 ]; then grep -n "failed:\|Error\|error\|hipMemGetInfo\|HSA_STATUS\|out of memory" $O/ws8diag_${SIDE}_$i.err | head -40; else rm -f $O/ws8diag_${SIDE}_$i.err; fi
         done; done; } > $O/ws8diag.txt 2>&1
       cat $O/ws8diag.txt | cut -c1-300;;
@@ -105,6 +107,21 @@ for l in open(sys.argv[1]):
               "allocations", d["allocations"], "peak GiB %.1f" % (d["peak_live_bytes"] / 2**30), d.get("error", ""))
 P
       ;;
+    syncab)
+      { echo "# tools/session.sh $NAME syncab: python bench.py --steps 6 --warmup 2 --no-alt --no-cpu-baseline --no-one-call --sync <mode>; then cfg4 --steps 10 --warmup 3"
+        for M in auto blocking yield auto blocking; do
+          timeout 600 python bench.py --steps 6 --warmup 2 --no-alt --no-cpu-baseline --no-one-call --sync $M > $O/syncab_$M.json 2> $O/syncab_$M.err
+          python -c "
+import json; d=json.loads(open('$O/syncab_$M.json').read().strip().splitlines()[-1]); e=d['host']['host_enqueue_ms_per_step'][0]
+print('cfg2b sync %-8s ms/step %8.2f  enqueue ms %8.2f  cpu ms %8.2f  cpu_share %.2f  rc %s' % ('$M', d['ms_per_step'], e['ms'], e['cpu_ms'], e['cpu_share'], d['host']['sync']['hipSetDevice_hipSetDeviceFlags_rc']))"
+        done
+        for M in auto blocking; do
+          timeout 600 python bench.py --config cfg4 --steps 10 --warmup 3 --no-cpu-baseline --sync $M > $O/syncab_cfg4_$M.json 2> $O/syncab_cfg4_$M.err
+          python -c "
+import json; d=json.loads(open('$O/syncab_cfg4_$M.json').read().strip().splitlines()[-1]); e=d['host']['host_enqueue_ms_per_step'][0]
+print('cfg4  sync %-8s ms/step %8.2f  enqueue ms %8.2f  cpu ms %8.2f  cpu_share %.2f' % ('$M', d['ms_per_step'], e['ms'], e['cpu_ms'], e['cpu_share']))"
+        done; } > $O/syncab.txt 2>&1
+      cat $O/syncab.txt;;
     hostspin*) A=${STEP#hostspin}; A=${A#:}; bash tools/host_spin_probe.sh $NAME/hostspin${A:+_}${A// /_} $A 2>&1 | tail -40;;
     noise) timeout 2400 python tests/diagnostics/grad_noise_draws.py > $O/grad_noise_draws.txt 2> $O/grad_noise_draws.err; tail -8 $O/grad_noise_draws.txt | cut -c1-250;;
     dropterm)
