@@ -353,7 +353,11 @@ def sc_network_step(guard, args):
     from gazenerf_amd import GazeNeRFNetAMD, losses, synth
     dev = torch.device("cuda:0")
     ok, log = True, []
-    for B, S, precision in ((2, 64, "fp32"), (2, 64, "bf16x3"), (2, 16, "fp32"), (3, 32, "fp32")):
+    # (images, side, precision, steps); the poisoned run keeps the full-size fp32 step and one small side (every fresh 16 GiB
+    # workspace is then filled with NaN bytes first: the driver's GPU run has a time limit)
+    configs = (((2, 64, "fp32", 1), (2, 16, "fp32", 1)) if args.poison else
+               ((2, 64, "fp32", 2), (2, 64, "bf16x3", 1), (2, 16, "fp32", 1), (3, 32, "fp32", 1)))
+    for B, S, precision, n_steps in configs:
         I = 8 * S
         torch.manual_seed(1234)
         net = GazeNeRFNetAMD(featmap_size=S, pred_img_size=I, precision=precision).to(dev)
@@ -368,7 +372,7 @@ def sc_network_step(guard, args):
         zeros = lambda n: torch.zeros(B, n, device=dev)
         opt_codes = {"bg": None, "iden": zeros(100), "expr": zeros(79), "appea": zeros(127)}
         opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
-        for it in range(2):
+        for it in range(n_steps):
             opt.zero_grad(set_to_none=True)
             pred = net("train", p["xy"], None, None, p["shape_code"], p["appea_code"], p["gaze"], p["R"], p["T"], p["Kinv"],
                        t_rand=t_rand)["coarse_dict"]

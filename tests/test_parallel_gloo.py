@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the multi-GPU plumbing of gazenerf_amd.parallel.
+"""CPU, world_size 2 (and one case at 8) over gloo: the multi-GPU plumbing of gazenerf_amd.parallel.
 The render op itself needs no collective (rays/images are independent); these tests cover the
 sharding helpers and the one exchange the training path adds: the flat-bucket gradient all-reduce."""
 import os
@@ -249,3 +249,42 @@ def _forced_case(rank, world):
 def test_force_collective_issues_the_exchange_at_claimed_world_size_one():
     res = _run(_forced_case)
     assert res == {0: True, 1: True}
+
+
+def _eight_rank_case(rank, world):
+    """The shapes of the 8-GPU runs (BASELINE cfg4 and the strong-scaled cfg2b render), on CPU: global batch 16 = 2 images per
+    rank; one 512 x 512-ray image as eight contiguous blocks of 32 768 rays, gathered back bit for bit; the three-bucket
+    exchange of cfg4's parameter groups (scaled down: same bucket structure, hook-driven first bucket) averaged over 8."""
+    lo, hi = parallel.shard_images(16, rank, world)
+    ok = (hi - lo) == 2 and lo == 2 * rank
+    xy = synth.pixel_grid(512)
+    local = parallel.shard_rays(xy, rank, world)
+    ok = ok and local.shape[-1] == 32768 and torch.equal(local, xy[:, :, 32768 * rank:32768 * (rank + 1)])
+    feat = local[:, :1, :] + 1000.0 * rank
+    full = parallel.gather_rays(feat, 512 * 512, world)
+    ok = ok and full.shape[-1] == 262144 and all(
+        torch.equal(full[:, :, 32768 * r:32768 * (r + 1)], xy[:, :1, 32768 * r:32768 * (r + 1)] + 1000.0 * r) for r in range(world))
+    nr = [torch.nn.Parameter(torch.ones(7, 3)), torch.nn.Parameter(torch.ones(11))]          # "NeuralRenderer": gradients first
+    face, eyes = [torch.nn.Parameter(torch.ones(9))], [torch.nn.Parameter(torch.ones(5, 2))]
+    red = parallel.GradAllReducer([nr, face, eyes], world)
+    red.arm_overlap()
+    for it in range(2):
+        for p in nr + face + eyes:
+            p.grad = None
+        red.begin_step()
+        h = (face[0] * (rank + 1.0)).sum() + (eyes[0] * 2.0).sum()
+        ((nr[0] * h).sum() + (nr[1] * (rank + 1.0)).sum()).backward()
+        first_in_flight = 0 in red._inflight
+        red.all_reduce(check_complete=True)
+        rs = [r + 1.0 for r in range(world)]
+        ok = ok and first_in_flight
+        ok = ok and torch.allclose(nr[1].grad, torch.full((11,), sum(rs) / world))
+        ok = ok and torch.allclose(nr[0].grad, torch.full((7, 3), sum(9.0 * r + 20.0 for r in rs) / world))
+        ok = ok and torch.allclose(face[0].grad, torch.full((9,), sum(21.0 * r for r in rs) / world))
+        ok = ok and torch.allclose(eyes[0].grad, torch.full((5, 2), 42.0))
+    return bool(ok) and red.n_buckets == 3
+
+
+def test_eight_ranks_cfg4_and_strong_scaling_shapes():
+    res = _run(_eight_rank_case, world=8)
+    assert res == {r: True for r in range(8)}
