@@ -461,7 +461,11 @@ def timed_loop(ctx, step, reset):
     # host_enqueue_ms_per_step (max over ranks): `ms` = wall time of the step's host code up to its last launch.  Well below
     # ms_per_step = the host runs ahead of the GPU.  Equal to it = EITHER the rank is launch-bound OR the HIP queue is full and
     # the launches block on the GPU (what a healthy GPU-bound step looks like once the queue has filled) -- `cpu_ms` tells them
-    # apart: the CPU time this process really spent on those launches.  cpu_ms well below ms_per_step = the host has slack.
+    # apart: the CPU time this process really spent over the steps, ALL its threads (the autograd engine's included).
+    # cpu_share = cpu_ms / ms_per_step.  Measured (rounds 5-6): cfg4 0.20 -- the host has slack; cfg2b 1.6-1.9 -- NOT slack: the
+    # step's host code is blocked for 80-86 % of the step and the process still burns more than one and a half cores, i.e. the
+    # blocked threads poll.  `--sync blocking` asks the runtime to park them instead; host.sync in the
+    # line says what was asked, cpu_share what it bought.
     ctx["host"].setdefault("host_enqueue_ms_per_step", []).append(
         {"leg": ctx.get("leg", "main"), "ms": enq / args.steps * 1e3, "cpu_ms": cpu / args.steps * 1e3,
          "ms_per_step": dt / args.steps * 1e3, "share": enq / dt if dt > 0 else None,

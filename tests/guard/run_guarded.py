@@ -39,8 +39,9 @@ GUARD_SO = os.path.join(HERE, "_guard_alloc.so")
 def install():
     """Plug the guard allocator into torch.  Must run before the first device allocation of the process."""
     import torch
-    if not os.path.exists(GUARD_SO):
-        raise SystemExit("run_guarded.py: %s is missing: python -m gazenerf_amd.build" % GUARD_SO)
+    if not os.path.exists(GUARD_SO):                 # normally prebuilt (__graft_entry__.build()); hipcc is on the GPU box too
+        from gazenerf_amd import build as B
+        B.build_guard(verbose=False)
     alloc = torch.cuda.memory.CUDAPluggableAllocator(GUARD_SO, "guard_malloc", "guard_free")
     torch.cuda.memory.change_current_allocator(alloc)
     g = C.CDLL(GUARD_SO)
