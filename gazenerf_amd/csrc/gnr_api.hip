@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <string>
 
+#include "gnr_canary.h"
 #include "gnr_internal.h"
 
 namespace gnr {
@@ -43,6 +44,90 @@ int fail(const char* fmt, ...) {
 }
 
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+#ifdef GNR_CANARY
+// ---- carve-internal canaries (gnr_canary.h): experimental builds only -------------------------------------------------
+namespace {
+constexpr unsigned CANARY_WORD = 0xC5C5C5C5u;
+constexpr int CANARY_MAX = 2048;
+struct CanaryGap { void* at; const char* what; int index; bool fill; };
+thread_local CanaryGap t_gaps[CANARY_MAX];
+thread_local int t_n_gaps = 0;
+thread_local bool t_fill = true, t_overflow = false;
+__global__ void canary_fill_kernel(void* const* gaps, int n) {
+    if ((int)blockIdx.x < n) {
+        unsigned* g = (unsigned*)gaps[blockIdx.x];
+        for (int i = threadIdx.x; i < (int)(CANARY_BYTES / 4); i += blockDim.x) g[i] = CANARY_WORD;
+    }
+}
+__global__ void canary_fill_one_kernel(unsigned* g) {
+    for (int i = threadIdx.x; i < (int)(CANARY_BYTES / 4); i += blockDim.x) g[i] = CANARY_WORD;
+}
+__global__ void canary_check_kernel(void* const* gaps, int n, unsigned* result) {      // result: {bad words, first bad gap + 1}
+    if ((int)blockIdx.x >= n) return;
+    const unsigned* g = (const unsigned*)gaps[blockIdx.x];
+    unsigned bad = 0;
+    for (int i = threadIdx.x; i < (int)(CANARY_BYTES / 4); i += blockDim.x) bad += g[i] != CANARY_WORD;
+    if (bad) {
+        atomicAdd(result, bad);
+        atomicMin(result + 1, (unsigned)blockIdx.x);
+    }
+}
+// device staging for the gap table and the result (an experimental build may allocate: include/gnr.h's rule is the product's)
+struct CanaryDev { void** table; unsigned* result; };
+CanaryDev canary_dev() {
+    static thread_local CanaryDev d{nullptr, nullptr};
+    if (!d.table) {
+        (void)hipMalloc((void**)&d.table, CANARY_MAX * sizeof(void*));
+        (void)hipMalloc((void**)&d.result, 2 * sizeof(unsigned));
+    }
+    return d;
+}
+}  // namespace
+void canary_begin(bool fill) { t_n_gaps = 0; t_fill = fill; t_overflow = false; }
+void canary_fill_mode(bool fill) { t_fill = fill; }
+void canary_note(void* gap, const char* what, int index) {
+    if (t_n_gaps >= CANARY_MAX) { t_overflow = true; return; }
+    t_gaps[t_n_gaps++] = CanaryGap{gap, what, index, t_fill};
+}
+void canary_note_now(void* gap, const char* what, int index, hipStream_t st) {
+    if (t_n_gaps >= CANARY_MAX) { t_overflow = true; return; }
+    t_gaps[t_n_gaps++] = CanaryGap{gap, what, index, false};       // filled here, not by canary_arm
+    hipLaunchKernelGGL(canary_fill_one_kernel, dim3(1), dim3(256), 0, st, (unsigned*)gap);
+}
+void canary_arm(hipStream_t st) {
+    void* host[CANARY_MAX];
+    int n = 0;
+    for (int i = 0; i < t_n_gaps; ++i)
+        if (t_gaps[i].fill) host[n++] = t_gaps[i].at;
+    if (!n) return;
+    const CanaryDev d = canary_dev();
+    (void)hipStreamSynchronize(st);                       // the table is re-used from call to call
+    (void)hipMemcpy(d.table, host, n * sizeof(void*), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(canary_fill_kernel, dim3((unsigned)n), dim3(256), 0, st, (void* const*)d.table, n);
+    (void)hipStreamSynchronize(st);                       // (the table is rewritten by canary_check)
+}
+int canary_check(hipStream_t st, const char* entry) {
+    if (t_overflow) return fail("%s: canary table overflow (more than %d regions)", entry, CANARY_MAX);
+    if (!t_n_gaps) return 0;
+    void* host[CANARY_MAX];
+    for (int i = 0; i < t_n_gaps; ++i) host[i] = t_gaps[i].at;
+    const CanaryDev d = canary_dev();
+    (void)hipStreamSynchronize(st);
+    const unsigned init[2] = {0u, 0xFFFFFFFFu};
+    (void)hipMemcpy(d.table, host, t_n_gaps * sizeof(void*), hipMemcpyHostToDevice);
+    (void)hipMemcpy(d.result, init, sizeof init, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(canary_check_kernel, dim3((unsigned)t_n_gaps), dim3(256), 0, st, (void* const*)d.table, t_n_gaps, d.result);
+    unsigned res[2] = {0, 0};
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(res, d.result, sizeof res, hipMemcpyDeviceToHost);
+    if (res[0] == 0) return 0;
+    const CanaryGap& g = t_gaps[res[1] < (unsigned)t_n_gaps ? res[1] : 0];
+    fprintf(stderr, "gnr canary: %s: %u word(s) overwritten; first damaged gap: behind region #%d of %s (%d gaps checked)\n", entry, res[0],
+            g.index, g.what, t_n_gaps);
+    return fail("%s: carve-internal canary overwritten: %u word(s), first behind region #%d of %s", entry, res[0], g.index, g.what);
+}
+#endif
 
 int check_problem(const GnrProblem* p, int n_streams) {
     if (!p) return fail("gnr: problem is NULL");
@@ -95,9 +180,15 @@ size_t carve_fwd(const GnrProblem* p, int n_streams, bool save, char* base, FwdP
     const size_t n_chunks = (size_t)p->batch * p->n_rays * cpr;
     const size_t M = n_chunks * CHUNK;
     size_t off = 0;
+    int region = 0;
     auto take = [&](size_t floats) {
         float* ptr = base ? (float*)(base + off) : nullptr;
         off += align_up(floats * sizeof(float));
+        if (CANARY_BYTES) {                                   // experimental builds (gnr_canary.h): a gap behind every region
+            if (base) canary_note(base + off, "carve_fwd", region);
+            off += CANARY_BYTES;
+        }
+        ++region;
         return ptr;
     };
     if (fp) {
@@ -220,7 +311,9 @@ static int fwd_impl(const GnrProblem* p, const GnrWeights* face, const GnrWeight
     hipStream_t st = (hipStream_t)stream;
 
     FwdParams fp{};
+    canary_begin(true);
     carve_fwd(p, n_streams, save, (char*)workspace, &fp);
+    canary_arm(st);
     fp.want_wl = (out->weights[0] || (n_streams > 1 && out->weights[1])) ? 1 : 0;
     fp.clk = clock_probe_slot(GNR_STAGE_FWD_MLP);
     const GnrWeights* ws_in[2] = {face, eyes};
@@ -253,6 +346,7 @@ static int fwd_impl(const GnrProblem* p, const GnrWeights* face, const GnrWeight
     launch_combine(cp, st);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("gnr_fwd: launch failed: %s", hipGetErrorString(e));
+    if (canary_check(st, "gnr_fwd")) return 1;
     return 0;
 }
 

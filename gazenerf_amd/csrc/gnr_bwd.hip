@@ -14,6 +14,7 @@
 #include <atomic>
 
 #include "gnr_bwd_common.h"
+#include "gnr_canary.h"
 #include "gnr_wgrad.h"
 
 namespace gnr {
@@ -451,9 +452,15 @@ static size_t carve_bwd(const GnrProblem* p, char* base, BwdScratch* sc) {
     const size_t n_rays_total = (size_t)p->batch * p->n_rays;
     const size_t n_chunks = n_rays_total * cpr, M = n_chunks * CHUNK;
     size_t off = 0;
+    int region = 0;
     auto take = [&](size_t floats) {
         float* ptr = base ? (float*)(base + off) : nullptr;
         off += align_up(floats * sizeof(float));
+        if (CANARY_BYTES) {                                   // experimental builds (gnr_canary.h): a gap behind every region
+            if (base) canary_note(base + off, "carve_bwd", region);
+            off += CANARY_BYTES;
+        }
+        ++region;
         return ptr;
     };
     BwdScratch s{};
@@ -492,9 +499,12 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
     if (!scratch || scratch_bytes < need_scr)
         return fail("gnr_bwd: scratch too small (%zu < %zu bytes)", scratch_bytes, need_scr);
     if (((uintptr_t)saved & 255) || ((uintptr_t)scratch & 255)) return fail("gnr_bwd: workspaces must be 256-byte aligned");
+    canary_begin(false);                    // the saved workspace's gaps were filled by gnr_fwd: checked, never refilled
     carve_fwd(p, n_streams, true, (char*)saved, &fp);
     BwdScratch sc{};
+    canary_fill_mode(true);
     carve_bwd(p, (char*)scratch, &sc);
+    canary_arm(st);
 
     const int cpr = fp.chunks_per_ray;
     const long n_rays_total = (long)p->batch * p->n_rays;
@@ -636,6 +646,7 @@ int run_bwd(const GnrProblem* p, int n_streams, const GnrWeights* const* w, cons
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("gnr_bwd: launch failed: %s", hipGetErrorString(e));
+    if (canary_check(st, "gnr_bwd")) return 1;
     return 0;
 }
 

@@ -28,6 +28,7 @@
 #include <type_traits>
 
 #include "../../include/gnr.h"
+#include "gnr_canary.h"
 #include "gnr_conv16.h"
 #include "gnr_device.h"
 #include "gnr_wgrad.h"
@@ -849,7 +850,17 @@ struct UpSaved {                        // kept for the backward
 
 static size_t up_carve(const GnrUpsampleProblem* p, const UpDims& d, char* base, UpSaved* s) {
     size_t off = 0;
-    auto take = [&](size_t bytes) { char* q = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return q; };
+    int region = 0;
+    auto take = [&](size_t bytes) {
+        char* q = base ? base + off : nullptr;
+        off += (bytes + 255) & ~(size_t)255;
+        if (CANARY_BYTES) {                                   // experimental builds (gnr_canary.h): a gap behind every region
+            if (base) canary_note(base + off, "up_carve", region);
+            off += CANARY_BYTES;
+        }
+        ++region;
+        return q;
+    };
     UpSaved z{};
     const size_t B = (size_t)p->batch;
     BlockPlans bp[UP_MAX];
@@ -910,7 +921,17 @@ static size_t up_wgrad_arena_floats(const GnrUpsampleProblem* p, const UpDims& d
 
 static size_t up_carve_bwd(const GnrUpsampleProblem* p, const UpDims& d, char* base, UpScratch* s) {
     size_t off = 0;
-    auto take = [&](size_t bytes) { char* q = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return q; };
+    int region = 0;
+    auto take = [&](size_t bytes) {
+        char* q = base ? base + off : nullptr;
+        off += (bytes + 255) & ~(size_t)255;
+        if (CANARY_BYTES) {
+            if (base) canary_note(base + off, "up_carve_bwd", region);
+            off += CANARY_BYTES;
+        }
+        ++region;
+        return q;
+    };
     size_t big = 0;
     const size_t B = (size_t)p->batch;
     for (int i = 0; i < d.n_blocks; ++i) {
@@ -988,8 +1009,10 @@ int gnr_upsample_fwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, f
     if (!workspace || ws_bytes < need) return fail("gnr_upsample_fwd: workspace too small (%zu < %zu bytes)", ws_bytes, need);
     if ((uintptr_t)workspace & 255) return fail("gnr_upsample_fwd: workspace must be 256-byte aligned");
     UpSaved s;
-    up_carve(p, d, (char*)workspace, &s);
     hipStream_t st = (hipStream_t)stream;
+    canary_begin(true);
+    up_carve(p, d, (char*)workspace, &s);
+    canary_arm(st);
     const int B = p->batch;
 
     // rgb = up(conv_rgb0(x))
@@ -1064,6 +1087,7 @@ int gnr_upsample_fwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, f
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("gnr_upsample_fwd: launch failed: %s", hipGetErrorString(e));
+    if (canary_check(st, "gnr_upsample_fwd")) return 1;
     return 0;
 }
 
@@ -1079,12 +1103,15 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
     if (!scratch || scratch_bytes < need_t) return fail("gnr_upsample_bwd: scratch too small (%zu < %zu bytes)", scratch_bytes, need_t);
     if (((uintptr_t)saved & 255) || ((uintptr_t)scratch & 255)) return fail("gnr_upsample_bwd: workspaces must be 256-byte aligned");
     UpSaved s;
+    hipStream_t st = (hipStream_t)stream;
+    canary_begin(false);                    // the saved workspace's gaps were filled by gnr_upsample_fwd: checked, never refilled
     up_carve(p, d, (char*)saved, &s);
     UpScratch t;
+    canary_fill_mode(true);
     up_carve_bwd(p, d, (char*)scratch, &t);
+    canary_arm(st);
     GnrUpsampleWeightGrads G{};
     if (dw) G = *dw;
-    hipStream_t st = (hipStream_t)stream;
     const int B = p->batch, nb = d.n_blocks;
     const long Pn = (long)d.side[nb] * d.side[nb];
 
@@ -1221,6 +1248,7 @@ int gnr_upsample_bwd(const GnrUpsampleProblem* p, const GnrUpsampleWeights* w, c
     if (wd.failed) return fail("gnr_upsample_bwd: a weight-gradient GEMM needs more split-K scratch than the workspace holds (batch %d)", B);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("gnr_upsample_bwd: launch failed: %s", hipGetErrorString(e));
+    if (canary_check(st, "gnr_upsample_bwd")) return 1;
     return 0;
 }
 

@@ -36,6 +36,7 @@
 #include <type_traits>
 
 namespace gnr { constexpr bool kChain3DumpBranch = false; }      // see gnr_chain3.h
+#include "gnr_canary.h"
 #include "gnr_chain3.h"
 #include "gnr_wgrad.h"
 
@@ -1117,10 +1118,12 @@ void wgrad_defer_flush(WgradDefer* d, hipStream_t st) {
 }
 float* wgrad_defer_take(WgradDefer* d, size_t floats, hipStream_t st) {
     floats = (floats + 63) & ~(size_t)63;
-    if (floats > d->arena_floats) return nullptr;
-    if (d->batch.n >= WG_DEFER_MAX || d->cursor + floats > d->arena_floats) wgrad_defer_flush(d, st);
+    const size_t gap = CANARY_BYTES / 4;                      // experimental builds (gnr_canary.h): a gap behind every sub-allocation
+    if (floats + gap > d->arena_floats) return nullptr;
+    if (d->batch.n >= WG_DEFER_MAX || d->cursor + floats + gap > d->arena_floats) wgrad_defer_flush(d, st);
     float* q = d->arena + d->cursor;
-    d->cursor += floats;
+    d->cursor += floats + gap;
+    if (gap) canary_note_now(q + floats, "the weight-gradient arena (wgrad_defer_take)", d->batch.n, st);
     return q;
 }
 void wgrad_defer_push(WgradDefer* d, const WgradReduceParams& rp, unsigned blocks) {
@@ -1266,7 +1269,8 @@ static WgradPlan wgrad_plan(int lda, int n_valid, int ldb, int k_valid, int batc
 size_t wgrad_need_floats(const WgradShape& g, int batch) {
     const WgradPlan pl = wgrad_plan(g.lda, g.n_valid, g.ldb, g.k_valid, batch, g.chunks_per_image, g.pixels_per_image, g.with_vec != 0,
                                     g.bf16x3 != 0, g.small_tiles != 0);
-    return pl.unsupported ? 0 : pl.need + pl.cs_need + pl.vec_need;
+    // (+ the experimental build's gaps: behind each of the three sub-blocks and behind the sub-allocation itself)
+    return pl.unsupported ? 0 : pl.need + pl.cs_need + pl.vec_need + 4 * (CANARY_BYTES / 4) + 64;
 }
 size_t wgrad_arena_floats_for(const WgradShape* gemms, int n, int batch, int max_m, int max_k) {
     size_t a = wgrad_arena_floats(batch, max_m, max_k);
@@ -1317,15 +1321,16 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
     wp.chunks_per_image = chunks_per_image;
     wp.chunks_per_split = pl.chunks_per_split;
     WgradDefer* const owner = defer;
+    const size_t gap = CANARY_BYTES / 4;          // experimental builds: [partial tiles] gap [column-sum shares] gap [vector shares] gap
     if (defer) {
-        float* q = wgrad_defer_take(defer, need + cs_need + vec_need, stream);
+        float* q = wgrad_defer_take(defer, need + cs_need + vec_need + 3 * gap, stream);
         if (q) scratch = q;
         else {                                // an arena below one GEMM's need (callers size it with wgrad_arena_floats()) --
             wgrad_defer_flush(defer, stream); // run what is queued, then this GEMM owns `scratch` like a launch of its own
             defer = nullptr;
         }
     }
-    if (!defer && need + cs_need + vec_need > wgrad_scratch_floats()) {
+    if (!defer && need + cs_need + vec_need + 3 * gap > wgrad_scratch_floats()) {
         // continuing would write past the caller's scratch.  With a queue the GEMM is skipped and the queue's owner (gnr_bwd /
         // gnr_upsample_bwd) returns an error; arenas sized by wgrad_arena_floats(batch, ...) never get here
         if (owner) { owner->failed = true; return; }
@@ -1334,8 +1339,18 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
         abort();
     }
     wp.partial = scratch;
-    float* cs_part = scratch + need;
-    float* vec_part = cs_part + cs_need;
+    float* cs_part = scratch + need + gap;
+    float* vec_part = cs_part + cs_need + gap;
+#if defined(GNR_CANARY) && GNR_CANARY == 2
+    // the harness's own self-test (tools/session.sh <name> canary): the column-sum shares start 64 floats late, so their last 64
+    // floats land in the gap behind them -- the round-5 overrun in miniature; every call with a bias gradient must then FAIL
+    if (colsum_out) cs_part += 64;
+#endif
+    if (gap) {      // (the round-5 overrun: the column-sum shares of one GEMM running into what lay behind them)
+        canary_note_now(scratch + need, "a weight-gradient GEMM's scratch: partial tiles", 0, stream);
+        canary_note_now(cs_part + cs_need, "a weight-gradient GEMM's scratch: column-sum shares", 1, stream);
+        canary_note_now(vec_part + vec_need, "a weight-gradient GEMM's scratch: vector shares", 2, stream);
+    }
     wp.colsum_part = cs_part;
     wp.vec = with_vec ? vec : nullptr;
     wp.vec_part = vec_part;

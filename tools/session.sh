@@ -19,6 +19,9 @@
 #   ws8diag:<n>      n repeats of the FULL-SIZE 8-rank cfg4 rehearsal (the run that went red on the driver's box in round 5), then n at
 #                    the test-only --side 16, every rank's stderr kept; a failed repeat's cause lines -> ws8diag.txt
 #   guard            tests/guard/run_guarded.py, long forms (every scenario, both bindings, with and without --poison) -> guard.txt
+#   canary           libgnr.so rebuilt with -DGNR_CANARY=1 (gaps with a pattern between the carved regions of every workspace, filled before and
+#                    compared after every entry point: csrc/gnr_canary.h), the two fuzzers + the parity / upsampler / network tests on it, then
+#                    -DGNR_CANARY=2 (a deliberate 64-float overrun inside a GEMM's scratch) must FAIL; product build restored   -> canary.txt
 #   hostspin[:args]  tools/host_spin_probe.sh: per-thread CPU time / state / wait channel of the default bench while its steps run -> hostspin/
 #   syncab           the default bench under --sync auto | blocking | yield, 6 steps each: ms_per_step and host.cpu_share   -> syncab.txt
 #   noise            tests/diagnostics/grad_noise_draws.py                        -> grad_noise_draws.txt
@@ -122,6 +125,21 @@ import json; d=json.loads(open('$O/syncab_cfg4_$M.json').read().strip().splitlin
 print('cfg4  sync %-8s ms/step %8.2f  enqueue ms %8.2f  cpu ms %8.2f  cpu_share %.2f' % ('$M', d['ms_per_step'], e['ms'], e['cpu_ms'], e['cpu_share']))"
         done; } > $O/syncab.txt 2>&1
       cat $O/syncab.txt;;
+    canary)
+      CF="gnr_api.hip,gnr_bwd.hip,gnr_upsample.hip,gnr_wgrad.hip"
+      { echo "# tools/session.sh $NAME canary: carve-internal canaries (gazenerf_amd/csrc/gnr_canary.h)"
+        GNR_EXTRA_FILES="$CF" GNR_EXTRA_HIPCC_FLAGS="-DGNR_CANARY=1" python -m gazenerf_amd.build --no-torch-ext > $O/canary_build1.log 2>&1; echo "build -DGNR_CANARY=1 rc=$?"
+        export GNR_ALLOW_EXPERIMENTAL_LIB=1
+        timeout 300 python tests/diagnostics/canary_selftest.py expect-clean 2> $O/canary_clean.err | tail -3
+        timeout 1500 python tests/diagnostics/fuzz_hot_path_split.py 40 5 2> $O/canary_fuzz_hot.err | tail -3
+        timeout 1500 python tests/diagnostics/fuzz_upsample.py 40 5 2> $O/canary_fuzz_up.err | tail -3
+        timeout 2400 python -m pytest tests/test_parity_gpu.py tests/test_upsample.py tests/test_network.py -m gpu -q -k "not graph" 2>&1 | tail -6      # (a canary build synchronises inside the entry points: not capturable)
+        GNR_EXTRA_FILES="$CF" GNR_EXTRA_HIPCC_FLAGS="-DGNR_CANARY=2" python -m gazenerf_amd.build --no-torch-ext > $O/canary_build2.log 2>&1; echo "build -DGNR_CANARY=2 rc=$?"
+        timeout 300 python tests/diagnostics/canary_selftest.py expect-hit 2> $O/canary_hit.err | tail -4
+        unset GNR_ALLOW_EXPERIMENTAL_LIB
+        python -m gazenerf_amd.build --no-torch-ext > $O/canary_restore.log 2>&1
+        python -c "from gazenerf_amd import _lib; print('restored:', _lib.build_info())"; } > $O/canary.txt 2>&1
+      cat $O/canary.txt | cut -c1-300;;
     hostspin*) A=${STEP#hostspin}; A=${A#:}; bash tools/host_spin_probe.sh $NAME/hostspin${A:+_}${A// /_} $A 2>&1 | tail -40;;
     noise) timeout 2400 python tests/diagnostics/grad_noise_draws.py > $O/grad_noise_draws.txt 2> $O/grad_noise_draws.err; tail -8 $O/grad_noise_draws.txt | cut -c1-250;;
     dropterm)
