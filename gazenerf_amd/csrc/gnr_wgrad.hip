@@ -1341,6 +1341,7 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
     wp.partial = scratch;
     float* cs_part = scratch + need + gap;
     float* vec_part = cs_part + cs_need + gap;
+    float* const cs_gap = cs_part + cs_need;          // (taken before the self-test below moves cs_part)
 #if defined(GNR_CANARY) && GNR_CANARY == 2
     // the harness's own self-test (tools/session.sh <name> canary): the column-sum shares start 64 floats late, so their last 64
     // floats land in the gap behind them -- the round-5 overrun in miniature; every call with a bias gradient must then FAIL
@@ -1348,7 +1349,7 @@ static void launch_wgrad_impl(const float* A, int lda, int n_valid, const float*
 #endif
     if (gap) {      // (the round-5 overrun: the column-sum shares of one GEMM running into what lay behind them)
         canary_note_now(scratch + need, "a weight-gradient GEMM's scratch: partial tiles", 0, stream);
-        canary_note_now(cs_part + cs_need, "a weight-gradient GEMM's scratch: column-sum shares", 1, stream);
+        canary_note_now(cs_gap, "a weight-gradient GEMM's scratch: column-sum shares", 1, stream);
         canary_note_now(vec_part + vec_need, "a weight-gradient GEMM's scratch: vector shares", 2, stream);
     }
     wp.colsum_part = cs_part;

@@ -235,3 +235,21 @@ def test_torch_extension_builds_and_loads(lib_built):
     x = torch.zeros(1, 2, 4)
     with pytest.raises(RuntimeError, match="no CPU path"):
         ext.render_fwd(x, x, x, x, x, x, x, None, None, [], [], 32, 2.5, -3.5, 384, 258, False, False, False, False, False, None, False, 0, None, None)
+
+
+def test_the_guard_band_allocator_builds_and_exports_its_hooks():
+    """Test infrastructure of tests/test_guard_bands.py (tests/guard/guard_alloc.cpp): built in-tree by
+    `__graft_entry__.build()` like the library, so that it travels prebuilt; the two entry points torch's
+    CUDAPluggableAllocator binds and the harness's own hooks must be there.  (No GPU call here.)"""
+    import subprocess
+
+    from gazenerf_amd import build
+    so = build.build_guard(verbose=False)
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
+    for sym in ("guard_malloc", "guard_free", "guard_check_all", "guard_violations", "guard_stats", "guard_report"):
+        assert (" T " + sym) in out, sym
+    # nothing of the product loads it
+    pkg = os.path.join(ROOT, "gazenerf_amd")
+    for name in os.listdir(pkg):
+        if name.endswith(".py") and name != "build.py":
+            assert "guard_alloc" not in open(os.path.join(pkg, name)).read(), name
