@@ -134,7 +134,19 @@ __device__ __forceinline__ void wstream16_init(WStream16& w, const float* packed
 // (ray set-up, encoding, bias-table fill, compositing) at the same time, with the matrix pipe idle.  The workgroups of
 // the FIRST round that land in an odd wave slot sleep ~25 us once; every later workgroup inherits the offset of the slot
 // it takes over.  (HW_ID bits 3:0 = wave slot within the SIMD.)
+// GNR_SOFTSTART=N (timing experiment, round 6; results unchanged): the first-round workgroup with linear index i additionally
+// sleeps i N / 64 periods of ~3.4 us before it starts -- the chip's matrix load then RAMPS over 512 N / 64 periods (N = 16: ~0.44 ms)
+// instead of stepping up within a few microseconds.  Question behind it (profiles/r4_forward_clock_experiments.txt): is the clock
+// the training forward loses after a backward (2.16-2.25 GHz for a whole 21 ms launch at cfg4's size) a reaction to the STEP?
+#ifndef GNR_SOFTSTART
+#define GNR_SOFTSTART 0
+#endif
 __device__ __forceinline__ void dephase_first_round(unsigned linear_block) {
+    if (GNR_SOFTSTART > 0 && linear_block < 512u) {
+        const int n = (int)(linear_block * (unsigned)GNR_SOFTSTART / 64u);
+#pragma unroll 1
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     if (linear_block < 512u) {                          // 2 workgroups x 256 CUs
         unsigned hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));

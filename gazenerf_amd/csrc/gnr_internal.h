@@ -16,7 +16,8 @@
 // extra flags are given, gnr_build_info() then reports them, and the Python binding refuses such a library unless asked.
 #if !defined(GNR_EXPERIMENTAL_BUILD) &&                                                                                     \
     (defined(GNR_NODUMP_TIMING) || defined(GNR_TEMPORAL_DUMP_TIMING) || defined(GNR_ABL16) || defined(GNR_C16_ABL) ||       \
-     defined(GNR_PIPE_ABL) || defined(GNR_TR_ABL) || defined(GNR_ABLATE) || defined(GNR_WG_RIDERS) || defined(GNR_CANARY))
+     defined(GNR_PIPE_ABL) || defined(GNR_TR_ABL) || defined(GNR_ABLATE) || defined(GNR_WG_RIDERS) || defined(GNR_CANARY) ||  \
+     defined(GNR_SOFTSTART))
 #error "GNR_* timing switches need -DGNR_EXPERIMENTAL_BUILD (python -m gazenerf_amd.build adds it when GNR_EXTRA_HIPCC_FLAGS is set)"
 #endif
 #include <hip/hip_runtime.h>

@@ -22,6 +22,8 @@
 #   canary           libgnr.so rebuilt with -DGNR_CANARY=1 (gaps with a pattern between the carved regions of every workspace, filled before and
 #                    compared after every entry point: csrc/gnr_canary.h), the two fuzzers + the parity / upsampler / network tests on it, then
 #                    -DGNR_CANARY=2 (a deliberate 64-float overrun inside a GEMM's scratch) must FAIL; product build restored   -> canary.txt
+#   softstart:<n,n,..>  the training forward's clock after a backward with the first-round workgroups' start RAMPED (-DGNR_SOFTSTART=n on
+#                    gnr_fwd16.hip, experimental builds; 0 = the product build): tools/stage_loop.py alt at 8192 rays + bench.py --config cfg4 -> softstart.txt
 #   hostspin[:args]  tools/host_spin_probe.sh: per-thread CPU time / state / wait channel of the default bench while its steps run -> hostspin/
 #   syncab           the default bench under --sync auto | blocking | yield, 6 steps each: ms_per_step and host.cpu_share   -> syncab.txt
 #   noise            tests/diagnostics/grad_noise_draws.py                        -> grad_noise_draws.txt
@@ -140,6 +142,22 @@ print('cfg4  sync %-8s ms/step %8.2f  enqueue ms %8.2f  cpu ms %8.2f  cpu_share 
         python -m gazenerf_amd.build --no-torch-ext > $O/canary_restore.log 2>&1
         python -c "from gazenerf_amd import _lib; print('restored:', _lib.build_info())"; } > $O/canary.txt 2>&1
       cat $O/canary.txt | cut -c1-300;;
+    softstart:*)
+      { echo "# tools/session.sh $NAME $STEP: -DGNR_SOFTSTART=n (gnr_chain16.h: first-round workgroup i sleeps i n / 64 x 3.4 us); stage_loop alt 8192 rays, then cfg4"
+        for N in $(echo ${STEP#softstart:} | tr ',' ' '); do
+          if [ "$N" = 0 ]; then python -m gazenerf_amd.build --no-torch-ext > $O/softstart_build_$N.log 2>&1; unset GNR_ALLOW_EXPERIMENTAL_LIB
+          else GNR_EXTRA_FILES="gnr_fwd16.hip" GNR_EXTRA_HIPCC_FLAGS="-DGNR_SOFTSTART=$N" python -m gazenerf_amd.build --no-torch-ext > $O/softstart_build_$N.log 2>&1; export GNR_ALLOW_EXPERIMENTAL_LIB=1; fi
+          echo "== GNR_SOFTSTART=$N ($(python -c 'from gazenerf_amd import _lib; print(_lib.build_info())' 2>/dev/null))"
+          timeout 300 python tools/stage_loop.py alt --rays 8192 --seconds 6 2> $O/softstart_loop_$N.err | tail -2
+          timeout 600 python bench.py --config cfg4 --steps 10 --warmup 3 --no-cpu-baseline > $O/softstart_cfg4_$N.json 2> $O/softstart_cfg4_$N.err
+          python -c "
+import json; d=json.loads(open('$O/softstart_cfg4_$N.json').read().strip().splitlines()[-1])
+print('cfg4 ms/step %.2f ' % d['ms_per_step'] + ' '.join('%s %.3f ms %.0f MHz' % (s['stage'], s['avg_ms'], s.get('clock_mhz') or 0) for s in d['stages']))"
+        done
+        unset GNR_ALLOW_EXPERIMENTAL_LIB
+        python -m gazenerf_amd.build --no-torch-ext > $O/softstart_restore.log 2>&1
+        python -c "from gazenerf_amd import _lib; print('restored:', _lib.build_info())"; } > $O/softstart.txt 2>&1
+      cat $O/softstart.txt | cut -c1-260;;
     hostspin*) A=${STEP#hostspin}; A=${A#:}; bash tools/host_spin_probe.sh $NAME/hostspin${A:+_}${A// /_} $A 2>&1 | tail -40;;
     noise) timeout 2400 python tests/diagnostics/grad_noise_draws.py > $O/grad_noise_draws.txt 2> $O/grad_noise_draws.err; tail -8 $O/grad_noise_draws.txt | cut -c1-250;;
     dropterm)
