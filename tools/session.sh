@@ -114,6 +114,13 @@ P
       ;;
     syncab)
       { echo "# tools/session.sh $NAME syncab: python bench.py --steps 6 --warmup 2 --no-alt --no-cpu-baseline --no-one-call --sync <mode>; then cfg4 --steps 10 --warmup 3"
+        # the HIP runtime's own knobs for the same wait (names from `strings libamdhip64.so`; semantics to be read off the numbers)
+        for E in "DEBUG_CLR_MAX_BATCH_SIZE=100000" "DEBUG_CLR_BATCH_CPU_SYNC_SIZE=100000" "ROC_ACTIVE_WAIT_TIMEOUT=0" "ROC_CPU_WAIT_FOR_SIGNAL=1" "ROC_SIGNAL_POOL_SIZE=4096" "HIP_FORCE_DEV_KERNARG=1" "ROC_AQL_QUEUE_SIZE=65536"; do
+          env $E timeout 600 python bench.py --steps 6 --warmup 2 --no-alt --no-cpu-baseline --no-one-call > $O/syncab_env.json 2> $O/syncab_env.err
+          python -c "
+import json; d=json.loads(open('$O/syncab_env.json').read().strip().splitlines()[-1]); e=d['host']['host_enqueue_ms_per_step'][0]
+print('cfg2b env %-40s ms/step %8.2f  enqueue ms %8.2f  cpu ms %8.2f  cpu_share %.2f' % ('$E', d['ms_per_step'], e['ms'], e['cpu_ms'], e['cpu_share']))" 2>&1 | tail -1
+        done
         for M in auto blocking yield auto blocking; do
           timeout 600 python bench.py --steps 6 --warmup 2 --no-alt --no-cpu-baseline --no-one-call --sync $M > $O/syncab_$M.json 2> $O/syncab_$M.err
           python -c "
