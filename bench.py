@@ -87,8 +87,9 @@ def parse():
     ap.add_argument("--pg-timeout", type=float, default=180.0, help="seconds before a stuck rendezvous / collective aborts")
     ap.add_argument("--sync", choices=("auto", "spin", "yield", "blocking"), default=os.environ.get("GNR_BENCH_SYNC", "auto"),
                     help="hipSetDeviceFlags(hipDeviceSchedule*) before the device context exists: how a host thread waits when the HIP "
-                         "runtime makes it wait (a full queue, a synchronize).  auto = the runtime's default.  `blocking` parks the thread "
-                         "on an interrupt instead of polling: what N ranks sharing a host's cores want (host.cpu_share in the line)")
+                         "runtime makes it wait (a full queue, a synchronize).  `blocking` parks the thread on an interrupt instead of "
+                         "polling.  auto = the runtime's default at ONE rank, `blocking` at N > 1 (ranks share the host's cores; "
+                         "host.cpu_share and host.sync in the line)")
     ap.add_argument("--force-dist", action="store_true", default=os.environ.get("GNR_BENCH_FORCE_DIST", "") == "1",
                     help="--gpus 1: form a ONE-rank RCCL process group anyway and run the gradient exchange through it "
                          "(loads librccl, creates a communicator, exercises the stream hand-off on a single GPU)")
@@ -343,14 +344,18 @@ def main():
     if args.scaling == "strong" and args.config != "cfg2b":
         raise SystemExit("bench.py: --scaling strong shards the rays of ONE cfg2b image; cfg4 shards images (weak)")
     sync_rc = None
-    if args.sync != "auto":
+    # auto: ONE rank keeps the runtime's default (it polls: the lowest wake-up latency, and the host has nothing else to do);
+    # N > 1 ranks share the host's cores -- and a bench box's cgroup -- with each other and with RCCL's proxy threads, and a cfg2b
+    # rank that only launches otherwise burns 1.6-1.9 cores polling (host.cpu_share): they park instead
+    sync_mode = args.sync if args.sync != "auto" else ("blocking" if world > 1 else "auto")
+    if sync_mode != "auto":
         # before the primary context of the device exists (torch creates it at the first allocation / set_device)
         import ctypes
         hip = ctypes.CDLL("libamdhip64.so")
-        flag = {"spin": 0x1, "yield": 0x2, "blocking": 0x4}[args.sync]       # hipDeviceScheduleSpin / Yield / BlockingSync
+        flag = {"spin": 0x1, "yield": 0x2, "blocking": 0x4}[sync_mode]       # hipDeviceScheduleSpin / Yield / BlockingSync
         sync_rc = [int(hip.hipSetDevice(dev_index)), int(hip.hipSetDeviceFlags(flag))]
         if sync_rc != [0, 0]:
-            sys.stderr.write("bench.py: rank %d: hipSetDevice / hipSetDeviceFlags(%s) returned %s: the runtime's default stays\n" % (rank, args.sync, sync_rc))
+            sys.stderr.write("bench.py: rank %d: hipSetDevice / hipSetDeviceFlags(%s) returned %s: the runtime's default stays\n" % (rank, sync_mode, sync_rc))
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     # pre-flight, every rank, stderr: what the device has free BEFORE this rank allocates (hipMemGetInfo) -- several ranks on
@@ -404,7 +409,7 @@ def main():
             from gazenerf_amd import _lib
             res["build"] = _lib.build_info()          # gnr_build_info(): source hash (checked against the tree at load), flags
             res["host"] = dict(ctx["host"], cpu_affinity=affinity, cores_available="%d (%s)" % available_cores(),
-                               sync={"mode": args.sync, "hipSetDevice_hipSetDeviceFlags_rc": sync_rc})
+                               sync={"asked": args.sync, "mode": sync_mode, "hipSetDevice_hipSetDeviceFlags_rc": sync_rc})
             if dist:
                 res["distributed"] = {"backend": backend, "world_size_formed": dist.get_world_size(),
                                       "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None,

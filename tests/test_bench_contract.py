@@ -92,6 +92,9 @@ def test_gpus_flag_launches_the_ranks_itself():
     d = _run([sys.executable, "bench.py", "--gpus", "2", "--side", "64", "--steps", "1", "--warmup", "1", "--no-alt"], env=TWO_ON_ONE)
     assert d["n_gpus"] == 2 and "cpu_baseline" not in d
     assert abs(d["value"] - 2 * 64 * 64 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    # N > 1 ranks park instead of polling when the runtime makes them wait (round 6); one rank keeps the runtime's default
+    assert d["host"]["sync"]["asked"] == "auto" and d["host"]["sync"]["mode"] == "blocking"
+    assert len(d["host"]["sync"]["hipSetDevice_hipSetDeviceFlags_rc"]) == 2      # (the two return codes are in the line; a refusal is not fatal)
     ar = d["allreduce"]
     assert ar["world_size_formed"] == 2 and ar["floats"] == 2 * 1518979 and ar["buckets"] == 2 and ar["ms"] > 0
 
@@ -204,6 +207,7 @@ def test_host_enqueue_time_is_reported_at_one_rank():
     legs = {e["leg"]: e for e in d["host"]["host_enqueue_ms_per_step"]}
     assert set(legs) == {"fp32", "bf16x3"} and all(0 < e["ms"] <= e["ms_per_step"] * 1.001 and e["cpu_ms"] > 0 for e in legs.values())
     assert d["host"]["cpu_affinity"] is None           # one rank keeps the whole mask (the CPU baseline needs it)
+    assert d["host"]["sync"] == {"asked": "auto", "mode": "auto", "hipSetDevice_hipSetDeviceFlags_rc": None}
     hb = d["roofline_hbm"]                             # priced on the algorithm's 258 channels, the layout's 288 beside it
     assert abs(hb["frac_incl_padding"] / hb["frac"] - hb["bytes_per_launch_incl_padding"] / hb["bytes_per_launch"]) < 1e-9
     assert hb["bytes_per_launch"] == 4096 * 64 * (258 * 4 + 16) + 4096 * (258 * 4 + 12)
