@@ -206,3 +206,25 @@ def test_backward_scratch_is_sized_for_every_batch(lib_built):
         assert all(b2 >= b1 for b1, b2 in zip(sizes, sizes[1:])), what
         steps = [b2 - b1 for b1, b2 in zip(sizes[256:], sizes[257:])]        # batch 257..512: every image adds the same share
         assert max(steps) <= 1.5 * min(steps) + 4096, (what, min(steps), max(steps))
+
+
+def test_gpu_collection_order_puts_parity_first_and_launcher_rehearsals_last():
+    """one flaky eight-rank launcher test, collected first (alphabetical order), blanked the whole GPU run under
+    `-x`.  tests/conftest.py orders the GPU items by what they prove; this pins that order (collection needs no GPU)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests", "-m", "gpu", "--collect-only", "-q"], cwd=root, capture_output=True,
+                       text=True, timeout=300)
+    ids = [l for l in r.stdout.splitlines() if "::" in l]
+    assert len(ids) >= 160, r.stdout[-2000:]
+    files = [i.split("::")[0].split("/")[-1] for i in ids]
+    first = {f: files.index(f) for f in set(files)}
+    last = {f: len(files) - 1 - files[::-1].index(f) for f in set(files)}
+    assert files[0] == "test_parity_gpu.py"
+    for earlier, later in (("test_parity_gpu.py", "test_upsample.py"), ("test_upsample.py", "test_network.py"),
+                           ("test_network.py", "test_guard_bands.py"), ("test_guard_bands.py", "test_losses.py")):
+        assert last[earlier] < first[later], (earlier, later)
+    assert all(last[f] < first["test_bench_contract.py"] for f in first if f != "test_bench_contract.py")
+    assert all("world_size_8" in i for i in ids[-2:]) and not any("world_size_8" in i for i in ids[:-2])
