@@ -138,7 +138,7 @@ __device__ __forceinline__ void conv16_epilogue_prefetch(const Conv16Params& cp,
     }
 }
 
-template <int MT, int NT, bool PRE = false, bool RIDER = true>       // RIDER = false: an instance that never carries the RGB branch (none at present)
+template <int MT, int NT, bool PRE = false>
 __device__ __forceinline__ void conv16_plain_epilogue(const Conv16Params& cp, f32x4 (&acc)[MT][NT], int b, int n, int m0, int g,
                                                       const float* rgbw, const Conv16EpiPre<MT, NT>* pre = nullptr) {
     typedef typename Pix<NT>::T pv;
@@ -187,7 +187,7 @@ __device__ __forceinline__ void conv16_plain_epilogue(const Conv16Params& cp, f3
             }
             if ((GNR_C16_ABL & 64) && v[0] != 1.2345f) continue;
             *(pv*)dst = v;
-            if (RIDER && cp.rgb_w) {
+            if (cp.rgb_w) {
 #pragma unroll
                 for (int o = 0; o < 3; ++o) {
                     const float wo = rgbw[o * cp.M + m];
@@ -196,7 +196,7 @@ __device__ __forceinline__ void conv16_plain_epilogue(const Conv16Params& cp, f3
                 }
             }
         }
-    if (RIDER && cp.rgb_w) {
+    if (cp.rgb_w) {
         // Sum over the four lane groups (rows of 16 lanes) with the gfx950 row / half swaps: for four values a, b, c, d
         //   v_permlane16_swap(a, b) -> [a0 b0 a2 b2], [a1 b1 a3 b3]  (rows; sum = a01 b01 a23 b23)
         //   v_permlane32_swap(sum_ab, sum_cd) -> [a01 b01 c01 d01], [a23 b23 c23 d23]  (sum: row g = total of value g)
